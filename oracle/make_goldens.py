@@ -1,0 +1,250 @@
+"""TEST INFRASTRUCTURE — generates tests/golden/*.pt by running the REFERENCE itself.
+
+Run only in the build container (needs /root/reference; never on the GPU box):
+    cd /tmp && python /root/repo/oracle/make_goldens.py [--cmu]
+
+The reference's ``model.py`` imports the third-party ``torchmultimodal`` package, which is not installed
+here.  Its loss lives, adapted, in the reference's own ``utils/contrastive_loss_with_temperature.py``
+and ``utils/distributed.py``; the shim below only re-routes the import to those files (SURVEY.md
+Appendix A).  No reference source is copied: the fixtures written are inputs, weights and outputs.
+
+Fixtures
+  tiny_<case>.pt : 3 modalities (2 embedded-sequence + 1 tabular), dim 32, 2 heads x 16, depth 2, 8 fusion
+                   tokens, combos [3,2]; inputs, initial state_dict, every output, every gradient,
+                   grad-norm, weights after 1 and 2 AdamW steps (lr 1e-3, clip 2.0).
+  cmu_<case>.pt  : CMU-shaped config (N=2538, D=512, L=5) at b=2 with weights from the build's own
+                   deterministic initialiser; pooled embeddings, loss terms, per-parameter grad norms.
+"""
+import argparse
+import os
+import sys
+import types
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(REPO, "tests", "golden")
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference")
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    for name in ("torchmultimodal", "torchmultimodal.utils", "torchmultimodal.modules",
+                 "torchmultimodal.modules.losses"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    import utils.distributed as ud
+    sys.modules["torchmultimodal.utils.distributed"] = ud
+    import utils.contrastive_loss_with_temperature as cl
+    cl.xm = type("XM", (), {"get_ordinal": staticmethod(dist.get_rank)})
+    sys.modules["torchmultimodal.modules.losses.contrastive_loss_with_temperature"] = cl
+    torch.save_real = torch.save
+    torch.save = lambda *a, **k: None          # model.py:94 debug write
+    import model as refmodel
+    import encoders as refenc
+    torch.save = torch.save_real
+    return refmodel, refenc
+
+
+# ---------------------------------------------------------------------------------------------------
+def tiny_model_config(variant: str):
+    enc = {
+        "seqA": {"type": "EmbeddedSequenceEncoder", "input_size": 10, "max_tokens": 12, "embedding_dim": 32},
+        "seqB": {"type": "EmbeddedSequenceEncoder", "input_size": 7, "max_tokens": 9, "embedding_dim": 32},
+        "tab": {"type": "TabularEncoder", "num_embeddings": 11, "max_tokens": 11, "max_value": 100,
+                "embedding_dim": 32},
+    }
+    cfg = dict(encoder_configs=enc, dim=32, depth=2, heads=2, dim_head=16, ff_mult=4, num_fusion_tokens=8,
+               batch_size=4, fcl=True, fcl_root=[0, 1, 2], bimodal_contrastive=False, non_fusion_fcl=False,
+               fusion_combos=[3, 2], zorro=False, eao=False, no_fusion=False, mean_pool=False)
+    if variant == "zorro":
+        cfg.update(zorro=True, fcl=False)
+    elif variant == "bimodal":
+        cfg.update(bimodal_contrastive=True, non_fusion_fcl=True)
+    elif variant == "nofcl":
+        cfg.update(fcl=False)
+    return cfg
+
+
+def tiny_batch(seed: int, drop: dict, b: int = 4):
+    """drop: {modality: [sample indices dropped]}.  Layouts follow the reference collators
+    (encoders.py:300-343): embedded_sequence -> tokens (b,pad,in) f32 zero-filled + bool mask (True = pad);
+    sequence -> values (b,n) with -10000 fill + int64 mask."""
+    g = torch.Generator().manual_seed(seed)
+    batch = {}
+    for name, n, width in (("seqA", 12, 10), ("seqB", 9, 7)):
+        toks = torch.zeros(b, n, width)
+        mask = torch.ones(b, n, dtype=torch.bool)
+        for i in range(b):
+            if i in drop.get(name, []):
+                continue
+            ln = int(torch.randint(1, n + 1, (1,), generator=g))
+            toks[i, :ln] = torch.randn(ln, width, generator=g)
+            mask[i, :ln] = False
+        batch[name] = {"tokens": toks, "attention_mask": mask}
+    vals = torch.randn(b, 11, generator=g)
+    vals[0, 3] = -1.0            # value-path padding sentinel (encoders.py:63,88)
+    vals[1, 5] = 250.0           # above max_value -> clamped
+    vals[2, 7] = -10000.0        # a missing entry inside a present sample
+    for i in drop.get("tab", []):
+        vals[i] = -10000.0
+    batch["tab"] = {"values": vals, "attention_mask": (vals == -10000).to(torch.long)}
+    return batch
+
+
+def perturb_(model, seed):
+    """make gammas/betas/biases non-trivial and give the embedding rows norms on both sides of max_norm."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("gamma") or (".token_encoder." in n and n.endswith("weight") and p.dim() == 1) \
+                    or n.endswith("norm.weight"):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+            elif n.endswith("bias"):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+            elif n.endswith("embedding.weight"):
+                p[::2].mul_(0.1)
+
+
+def run_case(refmodel, cfg, batch, seed, lr, clip, steps=2):
+    torch.manual_seed(seed)
+    torch.save_real = getattr(torch, "save_real", torch.save)
+    real_save = torch.save
+    torch.save = lambda *a, **k: None
+    try:
+        model = refmodel.MCA(**cfg)
+        perturb_(model, seed + 1)
+        init_sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model.train()
+        opt = torch.optim.AdamW(model.parameters(), lr=lr)
+        rec = {"config": cfg, "batch": batch, "init_state": init_sd, "lr": lr, "clip": clip}
+        for s in range(steps):
+            out = model(batch)
+            opt.zero_grad()
+            out["loss"].backward()
+            if s == 0:
+                rec["outputs"] = {
+                    "embeddings": {("|".join(map(str, sorted(k))) if isinstance(k, frozenset) else k): v.detach().clone()
+                                   for k, v in out.items()
+                                   if isinstance(v, torch.Tensor) and v.dim() == 2},
+                    "losses": {k: v.detach().clone() for k, v in out["losses"].items()},
+                    "loss": out["loss"].detach().clone(),
+                    "modality_sample_mask": {k: v.clone() for k, v in out["modality_sample_mask"].items()},
+                }
+                for extra in ("fcl_loss", "no-fcl_loss"):
+                    if extra in out:
+                        rec["outputs"][extra] = out[extra].detach().clone()
+                rec["grads"] = {n: (p.grad.detach().clone() if p.grad is not None else None)
+                                for n, p in model.named_parameters()}
+                rec["state_after_forward"] = {k: v.detach().clone() for k, v in model.state_dict().items()
+                                              if k.endswith("embedding.weight") or k.endswith("logit_scale")}
+            gn = torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+            if s == 0:
+                rec["grad_norm"] = gn.detach().clone()
+            opt.step()
+            rec[f"state_step{s + 1}"] = {k: v.detach().clone() for k, v in model.state_dict().items()
+                                         if k in dict(model.named_parameters())}
+        rec["attn_mask"] = model.attn_mask.clone()
+        rec["pool_mask"] = model.pool_mask.clone()
+        rec["token_types"] = model.token_types.clone()
+        rec["return_token_types"] = list(model.return_token_types)
+        rec["loss_names"] = list(out["losses"].keys())
+    finally:
+        torch.save = real_save
+    return rec
+
+
+TINY_CASES = {
+    # name: (variant, drop map, seed)
+    "mca_fcl": ("mca", {}, 11),
+    "mca_fcl_drop": ("mca", {"seqA": [1], "tab": [2]}, 12),
+    "mca_fcl_nan": ("mca", {"seqB": [0, 1, 2, 3]}, 13),
+    "zorro_drop": ("zorro", {"seqA": [0], "seqB": [0, 3]}, 14),
+    "bimodal_drop": ("bimodal", {"seqB": [2], "tab": [0, 2]}, 15),
+    "nofcl": ("nofcl", {"seqA": [3]}, 16),
+}
+
+
+def make_tiny(refmodel):
+    for name, (variant, drop, seed) in TINY_CASES.items():
+        cfg = tiny_model_config(variant)
+        batch = tiny_batch(seed, drop)
+        rec = run_case(refmodel, cfg, batch, seed, lr=1e-3, clip=2.0)
+        torch.save(rec, os.path.join(GOLD, f"tiny_{name}.pt"))
+        print(f"tiny_{name}: loss {float(rec['outputs']['loss']):.6f} terms {len(rec['outputs']['losses'])} "
+              f"nan {sum(int(torch.isnan(v)) for v in rec['outputs']['losses'].values())} gn {float(rec['grad_norm']):.4f}")
+
+
+def make_init_parity(refmodel):
+    """Same torch seed -> the reference's own initial weights for the CMU config; only per-tensor
+    checksums are stored (the weights are 70 MB)."""
+    import importlib
+    sys.path.insert(0, REPO)
+    pkg = importlib.import_module("mca-paper_amd")
+    cfg = pkg.config.cmu_model_config(batch_size=2)
+    torch.manual_seed(43)
+    real_save = torch.save
+    m = refmodel.MCA(**cfg)
+    sums = {k: (float(v.double().sum()), float(v.double().abs().sum()), tuple(v.shape))
+            for k, v in m.state_dict().items() if v.dtype.is_floating_point}
+    torch.save({"seed": 43, "checksums": sums, "keys": list(m.state_dict().keys())},
+               os.path.join(GOLD, "cmu_init_checksums.pt"))
+    print("cmu init checksums:", len(sums), "tensors")
+
+
+def make_cmu(refmodel):
+    """CMU-shaped runs at b=2: weights from the build's own initialiser, inputs from its synthetic
+    generator; store pooled embeddings, losses, grad norms and a few gradient slices."""
+    import importlib
+    sys.path.insert(0, REPO)
+    pkg = importlib.import_module("mca-paper_amd")
+    for case, (zorro, p_drop) in {"mca": (False, 0.0), "mma_d40": (True, 0.4)}.items():
+        cfg = pkg.config.cmu_model_config(batch_size=2, zorro=zorro)
+        torch.manual_seed(43)
+        real_save = torch.save
+        torch.save = lambda *a, **k: None
+        try:
+            model = refmodel.MCA(**cfg)
+            sd = pkg.params.init_state_dict(cfg, seed=43)
+            missing = model.load_state_dict(sd, strict=False)
+            assert not missing.unexpected_keys, missing
+            batch = pkg.data.synthetic_batch(cfg, batch_size=2, seed=1234, p_drop=p_drop, lengths="uniform")
+            out = model(batch)
+            out["loss"].backward()
+        finally:
+            torch.save = real_save
+        names = list(cfg["encoder_configs"].keys())
+        rec = {
+            "case": case, "seed": 43, "data_seed": 1234, "p_drop": p_drop,
+            "pooled": torch.stack([out[n] for n in names] +
+                                  ([out[k] for k in model.fusion_combos] if (cfg["fcl"] and not zorro) else [out["fusion"]]), 1).detach(),
+            "losses": {k: v.detach() for k, v in out["losses"].items()},
+            "loss": out["loss"].detach(),
+            "sample_mask": {k: v for k, v in out["modality_sample_mask"].items()},
+            "grad_norms": {n: float(p.grad.norm()) for n, p in model.named_parameters()},
+            "grad_slices": {n: p.grad.flatten()[:64].clone() for n, p in model.named_parameters()},
+        }
+        torch.save(rec, os.path.join(GOLD, f"cmu_{case}_b2.pt"))
+        print(f"cmu_{case}: loss {float(rec['loss']):.5f}")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cmu", action="store_true")
+    ap.add_argument("--init", action="store_true")
+    ap.add_argument("--tiny", action="store_true")
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    refmodel, refenc = import_reference()
+    if a.tiny or not (a.cmu or a.init):
+        make_tiny(refmodel)
+    if a.init:
+        make_init_parity(refmodel)
+    if a.cmu:
+        make_cmu(refmodel)
