@@ -1,0 +1,184 @@
+/*
+ * mca_hip.h — C ABI of libmca_hip.so: the gfx950 (MI355X) kernels behind the MCA / MMA fusion
+ * training step.
+ *
+ * The reference (josiahbjorgaard/mca-paper) has no FFI: its hot path is stock ATen ops called from
+ * Python.  Each entry point below therefore names the reference Python lines whose
+ * arithmetic it replaces.  Conventions:
+ *   - plain pointers to DEVICE memory, sizes as integers, `stream` is a hipStream_t passed as void*;
+ *   - caller allocates every output and workspace; nothing is allocated, freed or synchronised here,
+ *     so every call is stream-ordered and graph-capturable;
+ *   - return value 0 = launched, negative = argument error (MCA_E_*), nothing launched;
+ *   - bf16 tensors are uint16_t (raw bits, round-to-nearest-even); all accumulation is fp32.
+ *   - "ld" = leading dimension in ELEMENTS of a row-major matrix.
+ */
+#ifndef MCA_HIP_H
+#define MCA_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mca_stream_t;
+
+#define MCA_OK 0
+#define MCA_E_BADARG (-1)
+#define MCA_E_ALIGN (-2)
+#define MCA_E_UNSUPPORTED (-3)
+#define MCA_E_LAUNCH (-4)
+
+/* version / build info: returns a static string */
+const char* mca_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM  (all Linear layers: encoders.py:190, model.py:49-51,69-71; their autograd backward)
+ * --------------------------------------------------------------------------------------------- */
+/* C[M,N] = A[M,K] · B[N,K]^T (+ bias[N]) (+ residual[M,N]).   K % 64 == 0, lda/ldb % 8 == 0.
+ * out_bf16 != 0: C is bf16, else fp32.  bias / residual may be NULL.  residual rows are indexed
+ * row % res_period when res_period > 0 (broadcast over batch), else row.                         */
+int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
+                void* C, int64_t ldc, int out_bf16,
+                const float* bias, const float* residual, int64_t ldres, int64_t res_period,
+                int64_t M, int64_t N, int64_t K, mca_stream_t stream);
+
+/* C[N,K] += A[R,N]^T · B[R,K]   (weight gradient: reduction over the R token rows; fp32 atomics
+ * into C, which the caller zeroes once per step).  lda/ldb % 8 == 0; N and K are arbitrary but the
+ * rows of A / B must be readable up to the next multiple of 8 columns (lda >= roundup8(N) etc.).  */
+int mca_gemm_tn_acc(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
+                    float* C, int64_t ldc, int64_t R, int64_t N, int64_t K, mca_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm (model.py:24-31; nn.LayerNorm in encoders.py:51,189,192)
+ * --------------------------------------------------------------------------------------------- */
+/* y = LN(x)*gamma (+beta), eps; one row = `cols` contiguous floats at x + row*ldx.
+ * Optional outputs (NULL to skip): y (fp32) at y + (row / period)*y_bstride + (row % period)*ldy
+ * (period <= 0: row*ldy); y_bf16 at row*ld_bf16, zero-filled up to cols_pad.
+ * rowmask (u8, 1 = padded row): the row's output is `add` only (fp32) / zeros (bf16) and its stats
+ * are (0, 0).  add (fp32 [period, cols]) is added after masking (positional table).
+ * mean/rstd: per-row statistics saved for the backward.                                          */
+int mca_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                      const uint8_t* rowmask, const float* add, int64_t period,
+                      float* y, int64_t ldy, int64_t y_bstride,
+                      uint16_t* y_bf16, int64_t ld_bf16, int cols_pad,
+                      float* mean, float* rstd, int64_t rows, int cols, float eps, mca_stream_t stream);
+
+/* Backward of the above.  dy is read with the same (period, ldy, y_bstride) row mapping as y was
+ * written; masked rows have zero gradient.  dx / dx_bf16 optional.  dgamma/dbeta (fp32[cols]) are
+ * ACCUMULATED (atomics).                                                                         */
+int mca_layernorm_bwd(const float* dy, int64_t ldy, int64_t y_bstride, int64_t period,
+                      const float* x, int64_t ldx, const float* gamma,
+                      const float* mean, const float* rstd, const uint8_t* rowmask,
+                      float* dx, int64_t lddx, uint16_t* dx_bf16, int64_t ld_bf16,
+                      float* dgamma, float* dbeta, int64_t rows, int cols, mca_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEGLU (model.py:35-38): h = [a | gate] (two halves of width ip, ld 2*ip) -> g = gelu(gate)*a
+ * --------------------------------------------------------------------------------------------- */
+int mca_geglu_fwd(const uint16_t* h, uint16_t* g, int64_t rows, int ip, mca_stream_t stream);
+int mca_geglu_bwd(const uint16_t* dg, const uint16_t* h, uint16_t* dh, int64_t rows, int ip,
+                  mca_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * small data-movement helpers
+ * --------------------------------------------------------------------------------------------- */
+/* dst[bf16, rows_pad x cols_pad, ld] = src[fp32, rows x cols, lds] (transposed if transpose != 0:
+ * dst[c][r] = src[r][c]); padding is zero-filled.  Used to refresh the bf16 weight copies.       */
+int mca_cast_pad_bf16(const float* src, int64_t lds, int64_t rows, int64_t cols,
+                      uint16_t* dst, int64_t ldd, int64_t rows_pad, int64_t cols_pad, int transpose,
+                      mca_stream_t stream);
+/* dst[r*ldd + c] = bf16(src[r*lds + c] * scale) */
+int mca_f32_to_bf16(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t rows, int64_t cols,
+                    float scale, mca_stream_t stream);
+/* dst[(i/period)*dst_bstride + (i%period)*ldd + c] = src[(i % period)*lds + c]  for i < rows
+ * (broadcast learned tokens over the batch: model.py:460,472)                                    */
+int mca_bcast_rows(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t dst_bstride,
+                   int64_t period, int64_t rows, int cols, mca_stream_t stream);
+/* dst[(i % period)*ldd + c] += sum over i of src[(i/period)*src_bstride + (i%period)*lds + c]
+ * (period == 1: plain column sum -> bias gradients)                                              */
+int mca_reduce_rows(const float* src, int64_t lds, int64_t src_bstride, int64_t period,
+                    float* dst, int64_t ldd, int64_t rows, int cols, mca_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Block-masked fused attention (model.py:73-105 as used by MCALayer :119 and attn_pool :472-473)
+ * --------------------------------------------------------------------------------------------- */
+/* keyinfo[b, nk_pad] = padded ? 31 : kgroup[j]; entries >= nk are 31.
+ * ktile_flags[b, n_ktiles] = 0 no valid key in the 64-key tile, 1 mixed, 2 all valid.
+ * padding: u8 (b, nk), 1 = padded key (model.py:465-466).                                       */
+int mca_build_keyinfo(const uint8_t* padding, const uint8_t* kgroup, uint8_t* keyinfo,
+                      uint8_t* ktile_flags, int batch, int nk, int nk_pad, mca_stream_t stream);
+
+/* vmean[b, h*64+d] = mean over ALL nk keys of V  (value of a fully-masked softmax row)          */
+int mca_attn_vmean(const uint16_t* V, int64_t kv_bstride, int64_t kv_ld, float* vmean,
+                   int batch, int nk, int heads, mca_stream_t stream);
+
+typedef struct {
+  const uint16_t* q; int64_t q_bstride; int64_t q_ld;     /* q[b*q_bstride + i*q_ld + h*64 + d]   */
+  const uint16_t* k; const uint16_t* v; int64_t kv_bstride; int64_t kv_ld;
+  uint16_t* o; int64_t o_bstride; int64_t o_ld;
+  float* lse;                       /* (b, heads, nq) log2-domain; +inf marks a uniform row       */
+  const uint32_t* qmask;            /* (nq) allowed key groups per query row                       */
+  const uint8_t* keyinfo;           /* (b, nk_pad)                                                 */
+  const uint8_t* ktile_flags;       /* (b, n_ktiles)                                               */
+  const int32_t* q_ptr; const int32_t* q_kt; const uint8_t* q_full; const int32_t* q_order;
+  const float* vmean;               /* (b, heads*64)                                               */
+  int batch, heads, nq, nk, nk_pad, n_qtiles, n_ktiles;
+  float scale;                      /* dim_head ** -0.5                                            */
+} mca_attn_fwd_args;
+/* dim_head is fixed at 64; query tile 128 rows, key tile 64.                                     */
+int mca_attn_fwd(const mca_attn_fwd_args* args, mca_stream_t stream);
+
+/* delta[b,h,i] = sum_d dO*O ; dvmean[b,h*64+d] = (1/nk) * sum over uniform rows i of dO          */
+int mca_attn_bwd_prep(const uint16_t* o, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld,
+                      const float* lse, float* delta, float* dvmean,
+                      int batch, int heads, int nq, int nk, mca_stream_t stream);
+
+typedef struct {
+  const uint16_t* q; int64_t q_bstride; int64_t q_ld;
+  const uint16_t* k; const uint16_t* v; int64_t kv_bstride; int64_t kv_ld;
+  const uint16_t* d_o; int64_t o_bstride; int64_t o_ld;
+  const float* lse; const float* delta; const float* dvmean;
+  float* dq; int64_t dq_bstride; int64_t dq_ld;           /* fp32, ACCUMULATED with atomics       */
+  uint16_t* dk; uint16_t* dv; int64_t dkv_bstride; int64_t dkv_ld;   /* bf16, written once        */
+  const uint32_t* qmask; const uint8_t* keyinfo; const uint8_t* ktile_flags;
+  const int32_t* k_ptr; const int32_t* k_qt; const uint8_t* k_full; const int32_t* k_order;
+  int batch, heads, nq, nk, nk_pad, n_qtiles, n_ktiles;
+  float scale;
+} mca_attn_bwd_args;
+/* key block 256 (one workgroup), query step 32.                                                  */
+int mca_attn_bwd(const mca_attn_bwd_args* args, mca_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * All-pairs contrastive loss with temperature
+ * (model.py:175-233 + torchmultimodal ContrastiveLossWithTemperature, formula per
+ *  utils/contrastive_loss_with_temperature.py:40-108,178-195)
+ * --------------------------------------------------------------------------------------------- */
+typedef struct { int32_t slot_a, slot_b; uint32_t and_bits, or_bits; } mca_loss_term;
+/* pooled_all: (B, R, D) fp32, all ranks concatenated rank-major; present_all: (B) u32 bit m = modality
+ * m present in the sample.  Local rows are [row0, row0+b).
+ * Outputs: term_loss[T] (NaN where a term has no valid row on this rank), loss[1] (NaN-aware mean),
+ * d_pooled (b,R,D) = d(sum over ranks of loss_r)/d(local pooled) given every rank's n_valid/n_terms
+ * are computed here from present_all; d_logit_scale[1] = d loss_local / d logit_scale.
+ * workspace: >= mca_contrastive_workspace_bytes(...)                                              */
+int64_t mca_contrastive_workspace_bytes(int B, int T);
+int mca_contrastive_fwd_bwd(const float* pooled_all, const uint32_t* present_all,
+                            const mca_loss_term* terms, int T, const float* logit_scale,
+                            int B, int b_local, int row0, int R, int D,
+                            float* term_loss, float* loss, float* d_pooled, float* d_logit_scale,
+                            void* workspace, mca_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * clip_grad_norm_ + AdamW over one flat buffer (train_accel_gpu.py:116-118; torch AdamW defaults)
+ * --------------------------------------------------------------------------------------------- */
+/* sqnorm[0] += sum g^2  (caller zeroes sqnorm)                                                   */
+int mca_grad_sqnorm(const float* g, int64_t n, float* sqnorm, mca_stream_t stream);
+/* grads scaled by min(1, max_norm/(sqrt(sqnorm)+1e-6)) when max_norm > 0, then decoupled AdamW.  */
+int mca_adamw_step(float* p, const float* g, float* m, float* v, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float bias_corr1, float bias_corr2, float max_norm, const float* sqnorm,
+                   mca_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,10 @@
+"""MI355X-native implementation of the MCA / MMA multimodal-fusion training step
+(drop-in for the hot path of josiahbjorgaard/mca-paper: model.py / encoders.py / the step loop of
+train_accel_gpu.py).  Import by name: ``importlib.import_module("mca-paper_amd")`` (the directory name
+has a hyphen), or use the root-level shims ``model.py`` / ``encoders.py``.
+"""
+from . import config, data, encoders, params, structure  # noqa: F401
+from .encoders import MultimodalCollator, collators, encoders_dict  # noqa: F401
+from .model import MCA  # noqa: F401
+
+__all__ = ["MCA", "encoders_dict", "collators", "MultimodalCollator", "config", "data", "params", "structure"]

@@ -1,0 +1,306 @@
+// Block-masked fused attention, backward (autograd of model.py:73-105).  P is recomputed from Q, K and the
+// forward's log-sum-exp; nothing of size N x N is ever stored.
+//
+// One workgroup = 8 wavefronts = a block of 256 keys of one (sample, head); wavefront w owns keys
+// [32w, 32w+32) and keeps K, V fragments plus the dK^T and dV^T accumulators of its keys in registers for
+// the whole kernel (no cross-workgroup sum for dK/dV).  The workgroup sweeps the 32-row query tiles the
+// fusion structure allows for its key block (CSR list from the host).  Per query tile and wavefront, with
+// the KEY on the MFMA lane (cdna guide, Appendix B "Attention backward"):
+//     S[q][key]   = Q · K^T           A = Q rows (LDS, ds_read_b128),  B = K fragments (registers)
+//     dP[q][key]  = dO · V^T          A = dO rows (LDS),               B = V fragments (registers)
+//     P = exp2(c·S − lse),  dS = P ∘ (dP − delta)
+//     dV^T[d][key] += dO^T · P        A = dO^T (ds_read_b64_tr_b16 of the same LDS image), B = P accumulators
+//     dK^T[d][key] += Q^T · dS        A = Q^T  (transposed reads),                         B = dS accumulators
+//     dQ[q][d]     += dS · K          dS crosses LDS once (transposed image), 16x16x32 MFMA, each wavefront
+//                                     owns one 16x16 block of the 32x64 dQ tile -> fp32 atomics to HBM
+// One barrier per query tile.
+#include "common.h"
+
+#define BKEYS 256
+#define BQ 32
+#define DH 64
+
+// [32 rows][64 d] image used for BOTH row reads and transposed reads (Q and dO tiles)
+__device__ __forceinline__ int qd_off(int r, int c) {
+  const int s = ((r >> 1) & 7) ^ (((r >> 1) & 1) << 2);
+  return r * 64 + ((c ^ s) << 3);
+}
+// [256 keys][64 d] K image, transposed reads of 8 consecutive keys x 16 d
+__device__ __forceinline__ int kt_off(int key, int c) { return key * 64 + ((c ^ (((key >> 1) & 3) << 1)) << 3); }
+// [256 keys][32 q] dS^T image (64-byte rows)
+__device__ __forceinline__ int ds_off(int key, int c) { return key * 32 + ((c ^ ((key >> 1) & 3)) << 3); }
+
+__global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a) {
+  extern __shared__ __attribute__((aligned(16))) u16 lds[];
+  u16* Qs = lds;                               // 2 x 32 x 64
+  u16* Os = Qs + 2 * BQ * DH;                  // 2 x 32 x 64   (dO)
+  u16* Ds = Os + 2 * BQ * DH;                  // 2 x 256 x 32  (dS^T)
+  u16* Kimg = Ds + 2 * BKEYS * BQ;             // 256 x 64
+  float* rowc = reinterpret_cast<float*>(Kimg + BKEYS * DH);      // [2][3][32]: lse, delta, qmask(bits)
+
+  const int kbi = a.k_order[blockIdx.x];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int key0 = kbi * BKEYS;
+  const int mykey = key0 + wave * 32 + l31;
+  int keyc = mykey; if (keyc > a.nk - 1) keyc = a.nk - 1;
+  const float c2 = a.scale * 1.4426950408889634f;
+
+  const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
+  const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
+  // K / V fragments (B operands): lane = key, k = d
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    kf[s] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)keyc * a.kv_ld + 16 * s + 8 * lh);
+    vf[s] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)keyc * a.kv_ld + 16 * s + 8 * lh);
+  }
+  const uint32_t kinfo = a.keyinfo[(int64_t)b * a.nk_pad + mykey];     // nk_pad covers every key block
+  const bool key_ok = kinfo != 31u;
+  // K image for the dQ product
+  for (int id = tid; id < BKEYS * 8; id += 512) {
+    const int r = id >> 3, c = id & 7;
+    int kk = key0 + r; if (kk > a.nk - 1) kk = a.nk - 1;
+    *reinterpret_cast<bf16x8*>(Kimg + kt_off(r, c)) = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)kk * a.kv_ld + c * 8);
+  }
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int n = 0; n < 2; n++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dk[n][r] = 0.f; dv[n][r] = 0.f; }
+
+  const u16* qbase = a.q + (int64_t)b * a.q_bstride + h * DH;
+  const u16* obase = a.d_o + (int64_t)b * a.o_bstride + h * DH;
+  const float* lse_g = a.lse + ((int64_t)b * a.heads + h) * a.nq;
+  const float* delta_g = a.delta + ((int64_t)b * a.heads + h) * a.nq;
+
+  // staging: threads 0..255 -> Q chunks, 256..511 -> dO chunks; threads 0..95 -> row constants
+  const int sid = tid & 255, srow = sid >> 3, sc = sid & 7;
+  bf16x8 stage;
+  float stage_c = 0.f;
+  auto gload = [&](int qt) {
+    int q = qt * BQ + srow; if (q > a.nq - 1) q = a.nq - 1;
+    if (tid < 256) stage = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)q * a.q_ld + sc * 8);
+    else stage = *reinterpret_cast<const bf16x8*>(obase + (int64_t)q * a.o_ld + sc * 8);
+    if (tid < 96) {
+      const int which = tid >> 5, r = tid & 31, qq = qt * BQ + r;
+      if (which == 0) stage_c = qq < a.nq ? lse_g[qq] : INFINITY;          // rows past nq contribute nothing
+      else if (which == 1) stage_c = qq < a.nq ? delta_g[qq] : 0.f;
+      else stage_c = __uint_as_float(qq < a.nq ? a.qmask[qq] : 0u);
+    }
+  };
+  auto swrite = [&](int buf) {
+    if (tid < 256) *reinterpret_cast<bf16x8*>(Qs + buf * BQ * DH + qd_off(srow, sc)) = stage;
+    else *reinterpret_cast<bf16x8*>(Os + buf * BQ * DH + qd_off(srow, sc)) = stage;
+    if (tid < 96) rowc[buf * 96 + tid] = stage_c;
+  };
+
+  const int it_begin = a.k_ptr[kbi], it_end = a.k_ptr[kbi + 1];
+  int buf = 0;
+  if (it_begin < it_end) { gload(a.k_qt[it_begin]); swrite(0); }
+  __syncthreads();
+
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1, g4 = lane >> 4;
+  const int qb = wave & 1, db = wave >> 1;       // this wavefront's 16x16 block of the dQ tile
+
+  for (int it = it_begin; it < it_end; it++) {
+    const int qt = a.k_qt[it];
+    const bool full = a.k_full[it] != 0;
+    if (it + 1 < it_end) gload(a.k_qt[it + 1]);
+    const u16* qs = Qs + buf * BQ * DH;
+    const u16* os = Os + buf * BQ * DH;
+    const float* rc = rowc + buf * 96;
+    u16* ds = Ds + buf * BKEYS * BQ;
+
+    // ---- S and dP (rows = q in registers, column = key on the lane)
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+      const bf16x8 qfrag = *reinterpret_cast<const bf16x8*>(qs + qd_off(l31, 2 * st + lh));
+      const bf16x8 ofrag = *reinterpret_cast<const bf16x8*>(os + qd_off(l31, 2 * st + lh));
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfrag, kf[st], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofrag, vf[st], dp, 0, 0, 0);
+    }
+    // ---- P, dS
+    bf16x8 pb[2], sb[2];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const f32x4 lse4 = *reinterpret_cast<const f32x4*>(rc + 8 * g + 4 * lh);
+      const f32x4 del4 = *reinterpret_cast<const f32x4*>(rc + 32 + 8 * g + 4 * lh);
+      const f32x4 qm4 = *reinterpret_cast<const f32x4*>(rc + 64 + 8 * g + 4 * lh);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int r = 4 * g + e;
+        bool ok = key_ok;
+        if (!full) ok = ok && ((__float_as_uint(qm4[e]) >> kinfo) & 1u);
+        float p = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse4[e]));
+        p = ok ? p : 0.f;
+        const float dsv = p * (dp[r] - del4[e]);
+        pb[r >> 3][r & 7] = (short)f2bf(p);
+        sb[r >> 3][r & 7] = (short)f2bf(dsv);
+      }
+    }
+    // ---- dS^T to LDS: lane = key row, 4 consecutive q per store
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      uint2 pk;
+      pk.x = (uint32_t)(u16)sb[g >> 1][4 * (g & 1)] | ((uint32_t)(u16)sb[g >> 1][4 * (g & 1) + 1] << 16);
+      pk.y = (uint32_t)(u16)sb[g >> 1][4 * (g & 1) + 2] | ((uint32_t)(u16)sb[g >> 1][4 * (g & 1) + 3] << 16);
+      *reinterpret_cast<uint2*>(ds + ds_off(wave * 32 + l31, g) + 4 * lh) = pk;
+    }
+    // ---- dV^T += dO^T P ; dK^T += Q^T dS   (element j of k-step sp carries q = 16sp + 8(j>>2) + 4lh + (j&3))
+#pragma unroll
+    for (int sp = 0; sp < 2; sp++)
+#pragma unroll
+      for (int n = 0; n < 2; n++) {
+        bf16x8 ot, qtf;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const int qr = 16 * sp + 8 * t + 4 * lh + tq;
+          const int d = n * 32 + 16 * tg + 4 * tp;
+          const bf16x4 o4 = lds_read_tr16(os + qd_off(qr, d >> 3) + (d & 7));
+          const bf16x4 q4 = lds_read_tr16(qs + qd_off(qr, d >> 3) + (d & 7));
+#pragma unroll
+          for (int e = 0; e < 4; e++) { ot[4 * t + e] = o4[e]; qtf[4 * t + e] = q4[e]; }
+        }
+        dv[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot, pb[sp], dv[n], 0, 0, 0);
+        dk[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, sb[sp], dk[n], 0, 0, 0);
+      }
+
+    if (it + 1 < it_end) swrite(buf ^ 1);
+    __syncthreads();
+
+    // ---- dQ tile (32 x 64) = dS (32 x 256) · K (256 x 64): this wavefront's 16x16 block, 8 k-steps of 32 keys.
+    //      key carried by (lane group g4, read t, element e): 32ks + 16(g4>>1) + 8t + 4(g4&1) + e
+    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      bf16x8 af, bfr;
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int key = 32 * ks + 16 * (g4 >> 1) + 8 * t + 4 * (g4 & 1) + tq;
+        const int qc = qb * 16 + 4 * tp;          // q column inside the dS^T row
+        const int dc = db * 16 + 4 * tp;          // d column inside the K row
+        const bf16x4 a4 = lds_read_tr16(ds + ds_off(key, qc >> 3) + (qc & 7));
+        const bf16x4 b4 = lds_read_tr16(Kimg + kt_off(key, dc >> 3) + (dc & 7));
+#pragma unroll
+        for (int e = 0; e < 4; e++) { af[4 * t + e] = a4[e]; bfr[4 * t + e] = b4[e]; }
+      }
+      dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, dq, 0, 0, 0);
+    }
+    {
+      float* dqp = a.dq + (int64_t)b * a.dq_bstride + h * DH + db * 16 + (lane & 15);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int q = qt * BQ + qb * 16 + 4 * g4 + e;
+        if (q < a.nq) atomicAdd(dqp + (int64_t)q * a.dq_ld, dq[e] * a.scale);
+      }
+    }
+    buf ^= 1;
+  }
+
+  // ---- epilogue: dK = scale * dK^T, dV = dV^T + dvmean (uniform rows spread over every key)
+  if (mykey < a.nk) {
+    u16* dkp = a.dk + (int64_t)b * a.dkv_bstride + (int64_t)mykey * a.dkv_ld + h * DH;
+    u16* dvp = a.dv + (int64_t)b * a.dkv_bstride + (int64_t)mykey * a.dkv_ld + h * DH;
+    const float* dvm = a.dvmean + (int64_t)b * a.heads * DH + h * DH;
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int d = n * 32 + 8 * g + 4 * lh;
+        uint2 pk;
+        pk.x = pack2bf(dk[n][4 * g] * a.scale, dk[n][4 * g + 1] * a.scale);
+        pk.y = pack2bf(dk[n][4 * g + 2] * a.scale, dk[n][4 * g + 3] * a.scale);
+        *reinterpret_cast<uint2*>(dkp + d) = pk;
+        pk.x = pack2bf(dv[n][4 * g] + dvm[d], dv[n][4 * g + 1] + dvm[d + 1]);
+        pk.y = pack2bf(dv[n][4 * g + 2] + dvm[d + 2], dv[n][4 * g + 3] + dvm[d + 3]);
+        *reinterpret_cast<uint2*>(dvp + d) = pk;
+      }
+  }
+}
+
+#define BWD_LDS_BYTES ((2 * BQ * DH * 2 + 2 * BKEYS * BQ + BKEYS * DH) * 2 + 2 * 96 * 4)
+
+extern "C" int mca_attn_bwd(const mca_attn_bwd_args* a, mca_stream_t stream) {
+  if (!a || !a->q || !a->k || !a->v || !a->d_o || !a->lse || !a->delta || !a->dvmean || !a->dq || !a->dk || !a->dv ||
+      !a->qmask || !a->keyinfo || !a->k_ptr || !a->k_qt || !a->k_full || !a->k_order)
+    return MCA_E_BADARG;
+  if (a->batch <= 0 || a->heads <= 0 || a->nq <= 0 || a->nk <= 0) return MCA_E_BADARG;
+  if (a->n_qtiles != (a->nq + BQ - 1) / BQ || a->n_ktiles != (a->nk + BKEYS - 1) / BKEYS) return MCA_E_BADARG;
+  if (a->nk_pad < a->n_ktiles * BKEYS) return MCA_E_BADARG;
+  if (a->q_ld % 8 || a->kv_ld % 8 || a->o_ld % 8 || a->dkv_ld % 4 || a->q_bstride % 8 || a->kv_bstride % 8 ||
+      a->o_bstride % 8 || a->dkv_bstride % 4)
+    return MCA_E_ALIGN;
+  if ((uintptr_t)a->q % 16 || (uintptr_t)a->k % 16 || (uintptr_t)a->v % 16 || (uintptr_t)a->d_o % 16 ||
+      (uintptr_t)a->dk % 8 || (uintptr_t)a->dv % 8)
+    return MCA_E_ALIGN;
+  if (a->heads > 65535 || a->batch > 65535) return MCA_E_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            BWD_LDS_BYTES) != hipSuccess)
+      return MCA_E_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(a->n_ktiles, a->heads, a->batch), dim3(512), BWD_LDS_BYTES, as_stream(stream), *a);
+  return launch_status();
+}
+
+// =====================================================================================================
+// delta[b,h,q] = sum_d dO[q,h,d] * O[q,h,d];  dvmean[b, h*64+d] = (1/nk) sum over uniform rows (lse = +inf) of dO
+// one wavefront per (b, q) row: lane covers 8 contiguous columns of the 512-wide row -> head = lane / 8
+// =====================================================================================================
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restrict__ o, const u16* __restrict__ d_o,
+                                                             int64_t bstride, int64_t ld, const float* __restrict__ lse,
+                                                             float* __restrict__ delta, float* __restrict__ dvmean,
+                                                             int heads, int nq, float inv_nk, int rows_per_block) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cols = heads * DH;
+  const int q_begin = blockIdx.x * rows_per_block;
+  int q_end = q_begin + rows_per_block; if (q_end > nq) q_end = nq;
+  for (int c0 = 0; c0 < cols; c0 += 512) {
+    const int c = c0 + lane * 8;
+    const int hh = c / DH;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool any = false;
+    for (int q = q_begin + wave; q < q_end; q += 4) {
+      float part = 0.f;
+      bool uni = false;
+      if (c < cols) {
+        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(o + (int64_t)b * bstride + (int64_t)q * ld + c);
+        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(d_o + (int64_t)b * bstride + (int64_t)q * ld + c);
+        uni = lse[((int64_t)b * heads + hh) * nq + q] == INFINITY;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const float dvj = bf2f((u16)dv[j]);
+          part += dvj * bf2f((u16)ov[j]);
+          if (uni) { acc[j] += dvj; any = true; }
+        }
+      }
+      // 8 lanes per head
+      part += __shfl_xor(part, 1, WAVE); part += __shfl_xor(part, 2, WAVE); part += __shfl_xor(part, 4, WAVE);
+      if (c < cols && (lane & 7) == 0) delta[((int64_t)b * heads + hh) * nq + q] = part;
+    }
+    if (any && c < cols) {
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (acc[j] != 0.f) atomicAdd(dvmean + (int64_t)b * cols + c + j, acc[j] * inv_nk);
+    }
+  }
+}
+extern "C" int mca_attn_bwd_prep(const uint16_t* o, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld,
+                                 const float* lse, float* delta, float* dvmean, int batch, int heads, int nq, int nk,
+                                 mca_stream_t stream) {
+  if (!o || !d_o || !lse || !delta || !dvmean || batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0) return MCA_E_BADARG;
+  if (o_ld % 8 || o_bstride % 8 || (uintptr_t)o % 16 || (uintptr_t)d_o % 16) return MCA_E_ALIGN;
+  if (hipMemsetAsync(dvmean, 0, (size_t)batch * heads * DH * sizeof(float), as_stream(stream)) != hipSuccess) return MCA_E_LAUNCH;
+  const int rpb = 32;
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((nq + rpb - 1) / rpb, batch), dim3(256), 0, as_stream(stream), o, d_o,
+                     o_bstride, o_ld, lse, delta, dvmean, heads, nq, 1.f / (float)nk, rpb);
+  return launch_status();
+}

@@ -1,0 +1,280 @@
+// Block-masked fused attention, forward (reference: model.py:73-105 — q·kᵀ, two masked_fill(-finfo.max),
+// softmax, ·v — as called by MCALayer.forward :119 and by the attentive pooling :472-473).
+//
+// The reference materialises (b,h,N,N) scores and masks.  Here one workgroup owns a 128-row query tile of
+// one (sample, head): 4 wavefronts x 32 query rows.  It walks only the 64-key tiles the static fusion
+// structure allows for that query tile (CSR list from the host) and skips tiles whose
+// keys are all padded in this sample.  Per tile and wavefront:
+//     S^T[key][q]  = K · Q^T          A = K rows from LDS (ds_read_b128, XOR-swizzled image),
+//                                     B = Q fragments held in registers for the whole kernel
+//     online softmax in registers     lane = query (its row max/sum need one cross-half exchange only)
+//     O^T[d][q]   += V^T · P^T        A = V^T via ds_read_b64_tr_b16 from the row-major V tile,
+//                                     B = the S^T accumulators converted to bf16 in place (no LDS trip)
+// with v_mfma_f32_32x32x16_bf16.  Element-wise masking (allowed = (qmask[q] >> keyinfo[key]) & 1) runs
+// only on tiles that straddle a structure boundary or contain padded keys.
+//
+// Semantics kept from the reference: a query row with no allowed, un-padded key gets a UNIFORM
+// distribution over ALL nk keys (softmax of a constant row), i.e. its output is the mean of V; such rows
+// are marked with lse = +inf for the backward.
+#include "common.h"
+
+#define AQ 128      // query rows per workgroup
+#define AK 64       // keys per tile
+#define DH 64       // head dim (fixed)
+
+// K tile image: [64 keys][64 d] bf16, 128-byte rows, chunk c (16 B) of row r at c ^ ((r>>1)&7)
+__device__ __forceinline__ int k_off(int r, int c) { return r * 64 + ((c ^ ((r >> 1) & 7)) << 3); }
+// V tile image: same shape, chunk c of row r at c ^ (4*((r>>1)&1)): the 4 rows of a transposed 4x16 read
+// fall into 4 distinct 64-byte bank quarters
+__device__ __forceinline__ int v_off(int r, int c) { return r * 64 + ((c ^ (((r >> 1) & 1) << 2)) << 3); }
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a) {
+  __shared__ __attribute__((aligned(16))) u16 lds[2 * 2 * AK * DH];   // K,V double-buffered: 32 KiB
+  __shared__ __attribute__((aligned(16))) uint8_t kinfo[2][AK];
+  u16* Ks = lds;
+  u16* Vs = lds + 2 * AK * DH;
+
+  const int qt = a.q_order[blockIdx.x];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int q0 = qt * AQ + wave * 32;
+  int qrow = q0 + l31;
+  const bool qvalid = qrow < a.nq;
+  if (qrow > a.nq - 1) qrow = a.nq - 1;
+
+  // Q fragments (B operand): lane holds Q[q][16s + 8*lh + j]
+  bf16x8 qf[4];
+  {
+    const u16* qp = a.q + (int64_t)b * a.q_bstride + (int64_t)qrow * a.q_ld + h * DH + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+  const uint32_t qm = a.qmask[qrow];
+  const float c2 = a.scale * 1.4426950408889634f;      // scores -> log2 domain
+
+  f32x16 o[2];
+#pragma unroll
+  for (int n = 0; n < 2; n++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[n][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
+  const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
+  const uint8_t* kinfo_g = a.keyinfo + (int64_t)b * a.nk_pad;
+  const uint8_t* flags = a.ktile_flags + (int64_t)b * a.n_ktiles;
+
+  // staging: 512 chunks of 16 B per tile per operand, 2 per thread
+  int srow[2], sc[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) { const int id = tid + 256 * i; srow[i] = id >> 3; sc[i] = id & 7; }
+  bf16x8 rk[2], rv[2];
+  uint32_t rinfo = 0;
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      int key = kt * AK + srow[i]; if (key > a.nk - 1) key = a.nk - 1;
+      rk[i] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * a.kv_ld + sc[i] * 8);
+      rv[i] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * a.kv_ld + sc[i] * 8);
+    }
+    if (tid < 16) rinfo = *reinterpret_cast<const uint32_t*>(kinfo_g + kt * AK + tid * 4);
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      *reinterpret_cast<bf16x8*>(Ks + buf * AK * DH + k_off(srow[i], sc[i])) = rk[i];
+      *reinterpret_cast<bf16x8*>(Vs + buf * AK * DH + v_off(srow[i], sc[i])) = rv[i];
+    }
+    if (tid < 16) *reinterpret_cast<uint32_t*>(&kinfo[buf][tid * 4]) = rinfo;
+  };
+
+  // the tile list of this query tile, minus tiles whose keys are all padded in this sample
+  const int it_end = a.q_ptr[qt + 1];
+  int it = a.q_ptr[qt];
+  auto next_live = [&](int i) { while (i < it_end && flags[a.q_kt[i]] == 0) i++; return i; };
+  it = next_live(it);
+  int buf = 0;
+  if (it < it_end) { gload(a.q_kt[it]); swrite(0); }
+  __syncthreads();
+
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  while (it < it_end) {
+    const int kt = a.q_kt[it];
+    const bool need_mask = (a.q_full[it] == 0) || (flags[kt] != 2);
+    const int nit = next_live(it + 1);
+    if (nit < it_end) gload(a.q_kt[nit]);
+
+    const u16* ks = Ks + buf * AK * DH;
+    const u16* vs = Vs + buf * AK * DH;
+    // ---- S^T = K Q^T : two 32-key blocks
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[kb][r] = 0.f;
+#pragma unroll
+      for (int st = 0; st < 4; st++) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + k_off(kb * 32 + l31, 2 * st + lh));
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[kb], 0, 0, 0);
+      }
+    }
+    // ---- masking (structure boundary / padded keys / keys past nk)
+    if (need_mask) {
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const uint32_t info4 = *reinterpret_cast<const uint32_t*>(&kinfo[buf][kb * 32 + 8 * g + 4 * lh]);
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const uint32_t grp = (info4 >> (8 * e)) & 0xffu;
+            const bool ok = (qm >> grp) & 1u;
+            s[kb][4 * g + e] = ok ? s[kb][4 * g + e] : -INFINITY;
+          }
+        }
+    }
+    // ---- online softmax (log2 domain), lane = query
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+    const float m_new = fmaxf(m_run, mx * c2);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = exp2f(m_run - m_use);
+    float rs = 0.f;
+    bf16x8 pb[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int sp = 0; sp < 2; sp++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const float p = exp2f(fmaf(s[kb][8 * sp + j], c2, -m_use));
+          rs += p;
+          pb[kb][sp][j] = (short)f2bf(p);
+        }
+    rs += __shfl_xor(rs, 32, WAVE);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) o[n][r] *= alpha;
+    // ---- O^T += V^T P^T : A = V^T (transposed LDS reads), B = P^T (accumulators as operand; element j of
+    //      k-step sp carries key 16sp + 8(j>>2) + 4lh + (j&3) of the 32-key block)
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int sp = 0; sp < 2; sp++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+          bf16x8 vf;
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            const int key = kb * 32 + 16 * sp + 8 * t + 4 * lh + tq;
+            const int d = n * 32 + 16 * tg + 4 * tp;
+            const bf16x4 v4 = lds_read_tr16(vs + v_off(key, d >> 3) + (d & 7));
+#pragma unroll
+            for (int e = 0; e < 4; e++) vf[4 * t + e] = v4[e];
+          }
+          o[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kb][sp], o[n], 0, 0, 0);
+        }
+
+    if (nit < it_end) swrite(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+    it = nit;
+  }
+
+  // ---- epilogue
+  const bool uniform = !(l_run > 0.f);
+  const float inv = uniform ? 0.f : 1.f / l_run;
+  if (qvalid) {
+    if (lh == 0) a.lse[((int64_t)b * a.heads + h) * a.nq + qrow] = uniform ? INFINITY : m_run + log2f(l_run);
+    u16* op = a.o + (int64_t)b * a.o_bstride + (int64_t)qrow * a.o_ld + h * DH;
+    const float* vm = a.vmean + (int64_t)b * a.heads * DH + h * DH;
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int d = n * 32 + 8 * g + 4 * lh;
+        float v0, v1, v2, v3;
+        if (uniform) { v0 = vm[d]; v1 = vm[d + 1]; v2 = vm[d + 2]; v3 = vm[d + 3]; }
+        else { v0 = o[n][4 * g] * inv; v1 = o[n][4 * g + 1] * inv; v2 = o[n][4 * g + 2] * inv; v3 = o[n][4 * g + 3] * inv; }
+        uint2 pk; pk.x = pack2bf(v0, v1); pk.y = pack2bf(v2, v3);
+        *reinterpret_cast<uint2*>(op + d) = pk;
+      }
+  }
+}
+
+extern "C" int mca_attn_fwd(const mca_attn_fwd_args* a, mca_stream_t stream) {
+  if (!a || !a->q || !a->k || !a->v || !a->o || !a->lse || !a->qmask || !a->keyinfo || !a->ktile_flags || !a->q_ptr ||
+      !a->q_kt || !a->q_full || !a->q_order || !a->vmean)
+    return MCA_E_BADARG;
+  if (a->batch <= 0 || a->heads <= 0 || a->nq <= 0 || a->nk <= 0) return MCA_E_BADARG;
+  if (a->n_qtiles != (a->nq + AQ - 1) / AQ || a->n_ktiles != (a->nk + AK - 1) / AK) return MCA_E_BADARG;
+  if (a->nk_pad < a->n_ktiles * AK || a->nk_pad % 4) return MCA_E_BADARG;
+  if (a->q_ld % 8 || a->kv_ld % 8 || a->o_ld % 4 || a->q_bstride % 8 || a->kv_bstride % 8 || a->o_bstride % 4) return MCA_E_ALIGN;
+  if ((uintptr_t)a->q % 16 || (uintptr_t)a->k % 16 || (uintptr_t)a->v % 16 || (uintptr_t)a->o % 8 ||
+      (uintptr_t)a->keyinfo % 4)
+    return MCA_E_ALIGN;
+  if (a->heads > 65535 || a->batch > 65535) return MCA_E_UNSUPPORTED;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(a->n_qtiles, a->heads, a->batch), dim3(256), 0, as_stream(stream), *a);
+  return launch_status();
+}
+
+// =====================================================================================================
+// keyinfo / tile flags, vmean
+// =====================================================================================================
+__global__ __launch_bounds__(64) void build_keyinfo_kernel(const uint8_t* __restrict__ padding,
+                                                            const uint8_t* __restrict__ kgroup,
+                                                            uint8_t* __restrict__ keyinfo, uint8_t* __restrict__ flags,
+                                                            int nk, int nk_pad, int n_ktiles) {
+  // one wavefront per (sample, 64-key tile); tiles past n_ktiles only fill the pad region
+  const int b = blockIdx.y, kt = blockIdx.x, lane = threadIdx.x;
+  const int key = kt * AK + lane;
+  uint8_t info = 31;
+  if (key < nk && !padding[(int64_t)b * nk + key]) info = kgroup[key];
+  if (key < nk_pad) keyinfo[(int64_t)b * nk_pad + key] = info;
+  const unsigned long long valid = __ballot(info != 31);
+  if (lane == 0 && kt < n_ktiles) {
+    const int in_tile = (nk - kt * AK) < AK ? (nk - kt * AK) : AK;
+    const int nvalid = __popcll(valid);
+    flags[(int64_t)b * n_ktiles + kt] = nvalid == 0 ? 0 : (nvalid == AK && in_tile == AK ? 2 : 1);
+  }
+}
+extern "C" int mca_build_keyinfo(const uint8_t* padding, const uint8_t* kgroup, uint8_t* keyinfo,
+                                 uint8_t* ktile_flags, int batch, int nk, int nk_pad, mca_stream_t stream) {
+  if (!padding || !kgroup || !keyinfo || !ktile_flags || batch <= 0 || nk <= 0) return MCA_E_BADARG;
+  const int n_ktiles = (nk + AK - 1) / AK;
+  if (nk_pad < n_ktiles * AK) return MCA_E_BADARG;
+  const int ntile_pad = (nk_pad + AK - 1) / AK;
+  hipLaunchKernelGGL(build_keyinfo_kernel, dim3(ntile_pad, batch), dim3(64), 0, as_stream(stream), padding, kgroup,
+                     keyinfo, ktile_flags, nk, nk_pad, n_ktiles);
+  return launch_status();
+}
+
+// vmean[b, c] = (1/nk) sum_j V[b, j, c]   c in [0, heads*64).  grid (cols/64, b): 256 threads = 64 columns
+// x 4 key slices, reduced through LDS.
+__global__ __launch_bounds__(256) void vmean_kernel(const u16* __restrict__ V, int64_t bstride, int64_t ld,
+                                                     float* __restrict__ vmean, int nk, int cols) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < cols)
+    for (int j = sl; j < nk; j += 4) acc += bf2f(V[(int64_t)b * bstride + (int64_t)j * ld + c]);
+  red[sl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (sl == 0 && c < cols) vmean[(int64_t)b * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)nk;
+}
+extern "C" int mca_attn_vmean(const uint16_t* V, int64_t kv_bstride, int64_t kv_ld, float* vmean, int batch, int nk,
+                              int heads, mca_stream_t stream) {
+  if (!V || !vmean || batch <= 0 || nk <= 0 || heads <= 0) return MCA_E_BADARG;
+  const int cols = heads * DH;
+  hipLaunchKernelGGL(vmean_kernel, dim3((cols + 63) / 64, batch), dim3(256), 0, as_stream(stream), V, kv_bstride, kv_ld,
+                     vmean, nk, cols);
+  return launch_status();
+}

@@ -1,0 +1,396 @@
+// HBM-bound kernels of the MCA step: LayerNorm fwd/bwd (with the encoder's pad-mask / positional-table
+// fusions), GEGLU fwd/bwd, bf16 casts, row broadcast / row reduction.  One wavefront (64 lanes) per
+// row for the norms; 16-byte accesses wherever the layout allows.
+#include "common.h"
+
+// =====================================================================================================
+// LayerNorm forward.  Reference: model.py:24-31 (gamma only), encoders.py:189-192,199-209 (affine,
+// pad rows zeroed, + positional table), encoders.py:68-70 (tabular value norm).
+// =====================================================================================================
+template <int VEC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const uint8_t* __restrict__ rowmask, const float* __restrict__ add, int64_t period,
+    float* __restrict__ y, int64_t ldy, int64_t y_bstride,
+    u16* __restrict__ y_bf16, int64_t ld_bf16, int cols_pad,
+    float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t rows, int cols, float eps) {
+  constexpr int NI = 16 / VEC;             // up to 1024 columns
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const bool masked = rowmask && rowmask[row];
+    const float* xr = x + row * ldx;
+    float v[NI][VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int c = (lane + 64 * i) * VEC;
+      if (c < cols) {
+        if (VEC == 4) {
+          float4 t = masked ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(xr + c);
+          v[i][0] = t.x; v[i][1 % VEC] = t.y; v[i][2 % VEC] = t.z; v[i][3 % VEC] = t.w;
+        } else {
+          v[i][0] = masked ? 0.f : xr[c];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; j++) s += v[i][j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) v[i][j] = 0.f;
+      }
+    }
+    const float mean = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int c = (lane + 64 * i) * VEC;
+      if (c < cols) {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) { const float d = v[i][j] - mean; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = masked ? 0.f : mean;
+      if (rstd_out) rstd_out[row] = masked ? 0.f : rstd;
+    }
+    const int64_t prow = period > 0 ? row % period : row;
+    float* yr = y ? (period > 0 ? y + (row / period) * y_bstride + prow * ldy : y + row * ldy) : nullptr;
+    const float* ar = add ? add + prow * (int64_t)cols : nullptr;
+    u16* br = y_bf16 ? y_bf16 + row * ld_bf16 : nullptr;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int c = (lane + 64 * i) * VEC;
+      if (c < cols) {
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          float t = (v[i][j] - mean) * rstd * gamma[c + j];
+          if (beta) t += beta[c + j];
+          o[j] = masked ? 0.f : t;
+        }
+        if (br) {
+          if (VEC == 4) {
+            uint2 pk; pk.x = pack2bf(o[0], o[1 % VEC]); pk.y = pack2bf(o[2 % VEC], o[3 % VEC]);
+            *reinterpret_cast<uint2*>(br + c) = pk;
+          } else {
+            br[c] = f2bf(o[0]);
+          }
+        }
+        if (yr) {
+          if (ar) {
+#pragma unroll
+            for (int j = 0; j < VEC; j++) o[j] += ar[c + j];
+          }
+          if (VEC == 4) *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
+          else yr[c] = o[0];
+        }
+      }
+    }
+    if (br) for (int c = cols + lane; c < cols_pad; c += 64) br[c] = 0;
+  }
+}
+
+extern "C" int mca_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                                 const uint8_t* rowmask, const float* add, int64_t period,
+                                 float* y, int64_t ldy, int64_t y_bstride,
+                                 uint16_t* y_bf16, int64_t ld_bf16, int cols_pad,
+                                 float* mean, float* rstd, int64_t rows, int cols, float eps,
+                                 mca_stream_t stream) {
+  if (!x || !gamma || rows < 0 || cols <= 0 || cols > 1024) return MCA_E_BADARG;
+  if (rows == 0) return MCA_OK;
+  const bool vec = (cols % 4 == 0) && (ldx % 4 == 0) && (!y || (ldy % 4 == 0 && y_bstride % 4 == 0)) &&
+                   (!y_bf16 || ld_bf16 % 4 == 0) &&
+                   ((uintptr_t)x % 16 == 0) && (!y || (uintptr_t)y % 16 == 0) && (!add || (uintptr_t)add % 16 == 0);
+  int64_t blocks = (rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  if (vec)
+    hipLaunchKernelGGL(ln_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, ldx, gamma, beta,
+                       rowmask, add, period, y, ldy, y_bstride, y_bf16, ld_bf16, cols_pad, mean, rstd, rows, cols, eps);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, ldx, gamma, beta,
+                       rowmask, add, period, y, ldy, y_bstride, y_bf16, ld_bf16, cols_pad, mean, rstd, rows, cols, eps);
+  return launch_status();
+}
+
+// =====================================================================================================
+// LayerNorm backward:  g = dy*gamma;  dx = rstd*(g - mean(g) - xhat*mean(g*xhat));
+// dgamma += sum_rows dy*xhat;  dbeta += sum_rows dy.   Per-block partials in registers, one atomic
+// per column per block.
+// =====================================================================================================
+template <int VEC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(
+    const float* __restrict__ dy, int64_t ldy, int64_t y_bstride, int64_t period,
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+    const float* __restrict__ mean_in, const float* __restrict__ rstd_in, const uint8_t* __restrict__ rowmask,
+    float* __restrict__ dx, int64_t lddx, u16* __restrict__ dx_bf16, int64_t ld_bf16,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int cols) {
+  constexpr int NI = 16 / VEC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dg[NI][VEC], db[NI][VEC];
+#pragma unroll
+  for (int i = 0; i < NI; i++)
+#pragma unroll
+    for (int j = 0; j < VEC; j++) { dg[i][j] = 0.f; db[i][j] = 0.f; }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const bool masked = rowmask && rowmask[row];
+    const float* xr = x + row * ldx;
+    const float* dyr = period > 0 ? dy + (row / period) * y_bstride + (row % period) * ldy : dy + row * ldy;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float xh[NI][VEC], g[NI][VEC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int c = (lane + 64 * i) * VEC;
+#pragma unroll
+      for (int j = 0; j < VEC; j++) { xh[i][j] = 0.f; g[i][j] = 0.f; }
+      if (c < cols && !masked) {
+        float xv[VEC], dv[VEC];
+        if (VEC == 4) {
+          float4 a = *reinterpret_cast<const float4*>(xr + c), d = *reinterpret_cast<const float4*>(dyr + c);
+          xv[0] = a.x; xv[1 % VEC] = a.y; xv[2 % VEC] = a.z; xv[3 % VEC] = a.w;
+          dv[0] = d.x; dv[1 % VEC] = d.y; dv[2 % VEC] = d.z; dv[3 % VEC] = d.w;
+        } else { xv[0] = xr[c]; dv[0] = dyr[c]; }
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          xh[i][j] = (xv[j] - mean) * rstd;
+          g[i][j] = dv[j] * gamma[c + j];
+          dg[i][j] += dv[j] * xh[i][j];
+          db[i][j] += dv[j];
+          s1 += g[i][j];
+          s2 += g[i][j] * xh[i][j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)cols;
+    s2 = wave_sum(s2) / (float)cols;
+    float* dxr = dx ? dx + row * lddx : nullptr;
+    u16* br = dx_bf16 ? dx_bf16 + row * ld_bf16 : nullptr;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int c = (lane + 64 * i) * VEC;
+      if (c < cols) {
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; j++) o[j] = masked ? 0.f : rstd * (g[i][j] - s1 - xh[i][j] * s2);
+        if (dxr) {
+          if (VEC == 4) *reinterpret_cast<float4*>(dxr + c) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
+          else dxr[c] = o[0];
+        }
+        if (br) {
+          if (VEC == 4) {
+            uint2 pk; pk.x = pack2bf(o[0], o[1 % VEC]); pk.y = pack2bf(o[2 % VEC], o[3 % VEC]);
+            *reinterpret_cast<uint2*>(br + c) = pk;
+          } else br[c] = f2bf(o[0]);
+        }
+      }
+    }
+  }
+  // block reduction of the parameter-gradient partials through LDS, then one atomic per column
+  __shared__ float red[4][1024];
+  for (int pass = 0; pass < 2; pass++) {
+    float* target = pass == 0 ? dgamma : dbeta;
+    if (!target) continue;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int c = (lane + 64 * i) * VEC;
+#pragma unroll
+      for (int j = 0; j < VEC; j++)
+        if (c + j < 1024) red[wave][c + j] = pass == 0 ? dg[i][j] : db[i][j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += 256) {
+      const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+      if (t != 0.f) atomicAdd(target + c, t);
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int mca_layernorm_bwd(const float* dy, int64_t ldy, int64_t y_bstride, int64_t period,
+                                 const float* x, int64_t ldx, const float* gamma,
+                                 const float* mean, const float* rstd, const uint8_t* rowmask,
+                                 float* dx, int64_t lddx, uint16_t* dx_bf16, int64_t ld_bf16,
+                                 float* dgamma, float* dbeta, int64_t rows, int cols, mca_stream_t stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || rows < 0 || cols <= 0 || cols > 1024) return MCA_E_BADARG;
+  if (rows == 0) return MCA_OK;
+  const bool vec = (cols % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (y_bstride % 4 == 0) &&
+                   (!dx || lddx % 4 == 0) && (!dx_bf16 || ld_bf16 % 4 == 0) &&
+                   ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && (!dx || (uintptr_t)dx % 16 == 0);
+  int64_t blocks = (rows + 3) / 4;
+  if (blocks > 1024) blocks = 1024;          // bounds the number of atomics on dgamma/dbeta
+  if (vec)
+    hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dy, ldy, y_bstride,
+                       period, x, ldx, gamma, mean, rstd, rowmask, dx, lddx, dx_bf16, ld_bf16, dgamma, dbeta, rows, cols);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dy, ldy, y_bstride,
+                       period, x, ldx, gamma, mean, rstd, rowmask, dx, lddx, dx_bf16, ld_bf16, dgamma, dbeta, rows, cols);
+  return launch_status();
+}
+
+// =====================================================================================================
+// GEGLU (model.py:35-38).  h = [a | gate], g = gelu_erf(gate) * a.  8 bf16 per lane per access.
+// =====================================================================================================
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const u16* __restrict__ h, u16* __restrict__ g,
+                                                         int64_t rows, int ip) {
+  const int chunks = ip / 8;
+  const int64_t total = rows * chunks;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / chunks;
+    const int c = (int)(idx % chunks) * 8;
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(h + r * 2 * ip + c);
+    const bf16x8 gt = *reinterpret_cast<const bf16x8*>(h + r * 2 * ip + ip + c);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = (short)f2bf(gelu_erf(bf2f((u16)gt[j])) * bf2f((u16)a[j]));
+    *reinterpret_cast<bf16x8*>(g + r * ip + c) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const u16* __restrict__ dg, const u16* __restrict__ h,
+                                                         u16* __restrict__ dh, int64_t rows, int ip) {
+  const int chunks = ip / 8;
+  const int64_t total = rows * chunks;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / chunks;
+    const int c = (int)(idx % chunks) * 8;
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(h + r * 2 * ip + c);
+    const bf16x8 gt = *reinterpret_cast<const bf16x8*>(h + r * 2 * ip + ip + c);
+    const bf16x8 d = *reinterpret_cast<const bf16x8*>(dg + r * ip + c);
+    bf16x8 da, dgt;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const float gv = bf2f((u16)gt[j]), av = bf2f((u16)a[j]), dv = bf2f((u16)d[j]);
+      da[j] = (short)f2bf(dv * gelu_erf(gv));
+      dgt[j] = (short)f2bf(dv * av * gelu_erf_grad(gv));
+    }
+    *reinterpret_cast<bf16x8*>(dh + r * 2 * ip + c) = da;
+    *reinterpret_cast<bf16x8*>(dh + r * 2 * ip + ip + c) = dgt;
+  }
+}
+
+static inline unsigned stream_grid(int64_t items) {
+  int64_t b = (items + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+extern "C" int mca_geglu_fwd(const uint16_t* h, uint16_t* g, int64_t rows, int ip, mca_stream_t stream) {
+  if (!h || !g || rows < 0 || ip <= 0 || ip % 8) return MCA_E_BADARG;
+  if (rows == 0) return MCA_OK;
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(stream_grid(rows * (ip / 8))), dim3(256), 0, as_stream(stream), h, g, rows, ip);
+  return launch_status();
+}
+extern "C" int mca_geglu_bwd(const uint16_t* dg, const uint16_t* h, uint16_t* dh, int64_t rows, int ip,
+                             mca_stream_t stream) {
+  if (!dg || !h || !dh || rows < 0 || ip <= 0 || ip % 8) return MCA_E_BADARG;
+  if (rows == 0) return MCA_OK;
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(stream_grid(rows * (ip / 8))), dim3(256), 0, as_stream(stream), dg, h, dh, rows, ip);
+  return launch_status();
+}
+
+// =====================================================================================================
+// casts / broadcast / reductions
+// =====================================================================================================
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, int64_t lds, int64_t rows,
+                                                        int64_t cols, u16* __restrict__ dst, int64_t ldd,
+                                                        int64_t rows_pad, int64_t cols_pad, int transpose) {
+  // dst is (rows_pad x cols_pad); element (r, c) of dst comes from src[r][c] or src[c][r]
+  const int64_t total = rows_pad * cols_pad;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / cols_pad, c = idx % cols_pad;
+    float v = 0.f;
+    if (!transpose) { if (r < rows && c < cols) v = src[r * lds + c]; }
+    else { if (c < rows && r < cols) v = src[c * lds + r]; }
+    dst[r * ldd + c] = f2bf(v);
+  }
+}
+extern "C" int mca_cast_pad_bf16(const float* src, int64_t lds, int64_t rows, int64_t cols, uint16_t* dst,
+                                 int64_t ldd, int64_t rows_pad, int64_t cols_pad, int transpose,
+                                 mca_stream_t stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || rows_pad <= 0 || cols_pad <= 0) return MCA_E_BADARG;
+  if (!transpose && (rows_pad < rows || cols_pad < cols)) return MCA_E_BADARG;
+  if (transpose && (rows_pad < cols || cols_pad < rows)) return MCA_E_BADARG;
+  hipLaunchKernelGGL(cast_pad_kernel, dim3(stream_grid(rows_pad * cols_pad)), dim3(256), 0, as_stream(stream), src, lds,
+                     rows, cols, dst, ldd, rows_pad, cols_pad, transpose);
+  return launch_status();
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, int64_t lds,
+                                                           u16* __restrict__ dst, int64_t ldd, int64_t rows,
+                                                           int64_t cols4, float scale) {
+  const int64_t total = rows * cols4;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / cols4, c = (idx % cols4) * 4;
+    const float4 t = *reinterpret_cast<const float4*>(src + r * lds + c);
+    uint2 pk; pk.x = pack2bf(t.x * scale, t.y * scale); pk.y = pack2bf(t.z * scale, t.w * scale);
+    *reinterpret_cast<uint2*>(dst + r * ldd + c) = pk;
+  }
+}
+extern "C" int mca_f32_to_bf16(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t rows,
+                               int64_t cols, float scale, mca_stream_t stream) {
+  if (!src || !dst || rows < 0 || cols <= 0) return MCA_E_BADARG;
+  if (cols % 4 || lds % 4 || ldd % 4 || (uintptr_t)src % 16 || (uintptr_t)dst % 8) return MCA_E_ALIGN;
+  if (rows == 0) return MCA_OK;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(stream_grid(rows * cols / 4)), dim3(256), 0, as_stream(stream), src, lds,
+                     dst, ldd, rows, cols / 4, scale);
+  return launch_status();
+}
+
+__global__ __launch_bounds__(256) void bcast_rows_kernel(const float* __restrict__ src, int64_t lds,
+                                                          float* __restrict__ dst, int64_t ldd, int64_t dst_bstride,
+                                                          int64_t period, int64_t rows, int cols) {
+  const int64_t total = rows * cols;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t i = idx / cols; const int c = (int)(idx % cols);
+    dst[(i / period) * dst_bstride + (i % period) * ldd + c] = src[(i % period) * lds + c];
+  }
+}
+extern "C" int mca_bcast_rows(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t dst_bstride,
+                              int64_t period, int64_t rows, int cols, mca_stream_t stream) {
+  if (!src || !dst || rows < 0 || cols <= 0 || period <= 0) return MCA_E_BADARG;
+  if (rows == 0) return MCA_OK;
+  hipLaunchKernelGGL(bcast_rows_kernel, dim3(stream_grid(rows * cols)), dim3(256), 0, as_stream(stream), src, lds, dst,
+                     ldd, dst_bstride, period, rows, cols);
+  return launch_status();
+}
+
+// dst[(i % period), c] += sum_i src[...]: each block owns a slab of rows, one atomic per (prow, c) per block
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ src, int64_t lds,
+                                                           int64_t src_bstride, int64_t period,
+                                                           float* __restrict__ dst, int64_t ldd, int64_t rows,
+                                                           int cols, int64_t groups_per_block) {
+  // grid.x = column chunks of 256, grid.y = prow, grid.z = slabs over the i/period ("group") index
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int64_t prow = blockIdx.y;
+  const int64_t ngroups = (rows + period - 1) / period;
+  const int64_t g0 = (int64_t)blockIdx.z * groups_per_block;
+  int64_t g1 = g0 + groups_per_block; if (g1 > ngroups) g1 = ngroups;
+  if (c >= cols) return;
+  float acc = 0.f;
+  for (int64_t g = g0; g < g1; g++) {
+    if (g * period + prow < rows) acc += src[g * src_bstride + prow * lds + c];
+  }
+  if (acc != 0.f) atomicAdd(dst + prow * ldd + c, acc);
+}
+extern "C" int mca_reduce_rows(const float* src, int64_t lds, int64_t src_bstride, int64_t period, float* dst,
+                               int64_t ldd, int64_t rows, int cols, mca_stream_t stream) {
+  if (!src || !dst || rows < 0 || cols <= 0 || period <= 0) return MCA_E_BADARG;
+  if (rows == 0) return MCA_OK;
+  const int64_t ngroups = (rows + period - 1) / period;
+  int64_t slabs = ngroups < 64 ? ngroups : 64;
+  // keep the grid reasonable when period is large
+  while (slabs > 1 && slabs * period * ((cols + 255) / 256) > 65536) slabs /= 2;
+  const int64_t gpb = (ngroups + slabs - 1) / slabs;
+  if (period > 65535) return MCA_E_UNSUPPORTED;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 255) / 256, (unsigned)period, (unsigned)slabs), dim3(256), 0,
+                     as_stream(stream), src, lds, src_bstride, period, dst, ldd, rows, cols, gpb);
+  return launch_status();
+}

@@ -1,0 +1,605 @@
+"""FusionEngine: drives the HIP kernels for one MCA/MMA training step (forward, loss, backward).
+
+Data layout in HBM (b = per-GPU batch, N = tokens per sample, D = 512, H = 8, Ip = FF inner dim padded to
+a multiple of 64):
+  * parameters and gradients: two flat fp32 buffers ordered by BACKWARD COMPLETION (loss/pool first,
+    encoders last) so that gradient buckets for the RCCL all-reduce are contiguous prefixes;
+  * bf16 copies of every weight (plain and transposed, zero-padded to MFMA-friendly shapes), refreshed
+    once per optimizer step;
+  * residual stream fp32 (b*N, D) per layer (LayerNorm inputs are kept for the backward); every GEMM
+    operand bf16; q|k|v packed as one (b*N, 3D) bf16 matrix written by a single fused QKV GEMM;
+  * nothing of size N x N exists: the attention kernels recompute scores from q, k and a (b,H,N) fp32
+    log-sum-exp.
+
+Reference lines: forward model.py:448-478, layer algebra :117-122, pooling :470-473, loss :175-233,
+encoders encoders.py:196-214 / :90-96, backward = autograd of those (train_accel_gpu.py:115).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import hip
+from .encoders import EmbeddedSequenceEncoder, NativeEncoder, TabularEncoder
+from .hip import AttnBwdArgs, AttnFwdArgs, LossTerm, call, ptr, stream_ptr
+
+LN_EPS = 1e-5
+FWD_BQ, FWD_BK = 128, 64
+BWD_BQ, BWD_BK = 32, 256
+
+
+def _pad_to(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _dev(a: np.ndarray, device) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+class _Sched:
+    """device copies of a TileSchedule"""
+
+    def __init__(self, s, device):
+        self.s = s
+        self.q_ptr, self.q_kt, self.q_full, self.q_order = (_dev(s.q_ptr, device), _dev(s.q_kt, device),
+                                                            _dev(s.q_full, device), _dev(s.q_order, device))
+        self.k_ptr, self.k_qt, self.k_full, self.k_order = (_dev(s.k_ptr, device), _dev(s.k_qt, device),
+                                                            _dev(s.k_full, device), _dev(s.k_order, device))
+
+
+class FusionEngine:
+    def __init__(self, model):
+        self.model = model
+        p0 = model.fusion_tokens
+        if p0.device.type != "cuda":
+            raise hip.MCAHipError("the MCA step runs only on a HIP device: move the model to cuda first "
+                                  "(there is no CPU fallback)")
+        hip.lib()                                   # fail loudly if the extension is missing
+        self.device = p0.device
+        self.D, self.H, self.L = model.dim, model.heads, model.depth
+        st = model.structure
+        self.st = st
+        self.N, self.R, self.F, self.M = st.n_tokens, st.n_return, st.num_fusion_tokens, st.n_modalities
+        if self.D != self.H * 64:
+            raise NotImplementedError("native path needs dim == heads * 64")
+        self.I = model.layers[0].ff.inner_dim if self.L else int(self.D * 4 * 2 / 3)
+        self.Ip = _pad_to(self.I, 64)
+        self.scale = model.dim_head ** -0.5
+        self.nk_pad = _pad_to(self.N, 256)
+        self._flatten_parameters()
+        self._build_static()
+        self._alloc_weights()
+        self._ws: Dict[int, dict] = {}
+        self._weights_version = -1
+        self.grad_bucket_hook: Optional[Callable[[int, int], None]] = None   # (lo, hi) offsets ready
+        self.gather_hook: Optional[Callable] = None                          # DP: pooled/present all-gather
+        self.check_finite = True
+
+    # ------------------------------------------------------------------------------------------------
+    # parameters -> one flat buffer (and one for gradients)
+    # ------------------------------------------------------------------------------------------------
+    def _flatten_parameters(self):
+        m = self.model
+        order: List[torch.nn.Parameter] = []
+        marks: List[int] = []                        # bucket boundaries (indices into `order`)
+        order += [m.loss.loss_fn.logit_scale, m.return_tokens, m.attn_pool.to_out.weight, m.attn_pool.to_q.weight,
+                  m.attn_pool.to_kv.weight, m.norm.gamma]
+        marks.append(len(order))
+        for i in reversed(range(self.L)):
+            ly = m.layers[i]
+            order += [ly.ff.feedforward[2].weight, ly.ff.feedforward[0].weight, ly.attn.to_out.weight,
+                      ly.attn.to_q.weight, ly.attn.to_kv.weight, ly.norm.gamma]
+            marks.append(len(order))
+        order.append(m.fusion_tokens)
+        for name in m.modality_types:
+            order += list(m.encoders[name].parameters())
+        marks.append(len(order))
+        seen = {id(p) for p in order}
+        for p in m.parameters():
+            if id(p) not in seen:
+                order.append(p)
+        marks[-1] = len(order)
+        offs, n = [], 0
+        for p in order:
+            n = _pad_to(n, 4)                        # keep every tensor 16-byte aligned
+            offs.append(n)
+            n += p.numel()
+        total = _pad_to(n, 4)
+        flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        gflat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.param_views, self.grad_views = {}, {}
+        for p, o in zip(order, offs):
+            if p.dtype != torch.float32:
+                raise TypeError("parameters must be fp32 (bf16 is used for GEMM operands only)")
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+            self.grad_views[id(p)] = gflat[o:o + p.numel()].view(p.shape)
+        self.flat, self.gflat = flat, gflat
+        self.param_order, self.param_offsets = order, offs
+        self.bucket_bounds = [offs[i] if i < len(offs) else total for i in marks]
+        self.bucket_bounds[-1] = total
+        self.n_params = total
+
+    def grad_of(self, p) -> torch.Tensor:
+        return self.grad_views[id(p)]
+
+    # ------------------------------------------------------------------------------------------------
+    def _build_static(self):
+        st, dev = self.st, self.device
+        self.kgroup = _dev(st.kgroup.astype(np.uint8), dev)
+        self.qmask_attn = _dev(st.qmask_attn.astype(np.uint32).view(np.int32), dev)
+        self.qmask_pool = _dev(st.qmask_pool.astype(np.uint32).view(np.int32), dev)
+        self.sched_attn_f = _Sched(st.attn_schedule(FWD_BQ, FWD_BK), dev)
+        self.sched_attn_b = _Sched(st.attn_schedule(BWD_BQ, BWD_BK), dev)
+        self.sched_pool_f = _Sched(st.pool_schedule(FWD_BQ, FWD_BK), dev)
+        self.sched_pool_b = _Sched(st.pool_schedule(BWD_BQ, BWD_BK), dev)
+        terms = self.model.loss_terms
+        arr = (LossTerm * len(terms))()
+        for i, t in enumerate(terms):
+            arr[i] = LossTerm(t.slot_a, t.slot_b, t.and_bits, t.or_bits)
+        self.n_terms = len(terms)
+        self.loss_terms_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.offsets = np.concatenate([[0], np.cumsum(st.token_dims)]).astype(int).tolist()
+
+    # ------------------------------------------------------------------------------------------------
+    # bf16 weight copies
+    # ------------------------------------------------------------------------------------------------
+    def _alloc_weights(self):
+        D, Ip, dev = self.D, self.Ip, self.device
+        bf = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=dev)
+        self.wl = []
+        for _ in range(self.L):
+            self.wl.append(dict(qkv=bf(3 * D, D), qkvT=bf(D, 3 * D), o=bf(D, D), oT=bf(D, D),
+                                w1=bf(2 * Ip, D), w1T=bf(D, 2 * Ip), w2=bf(D, Ip), w2T=bf(Ip, D)))
+        self.wp = dict(q=bf(D, D), qT=bf(D, D), kv=bf(2 * D, D), kvT=bf(D, 2 * D), o=bf(D, D), oT=bf(D, D))
+        self.we = {}
+        for name in self.model.modality_types:
+            enc = self.model.encoders[name]
+            if isinstance(enc, EmbeddedSequenceEncoder):
+                kp = _pad_to(enc.input_size, 64)
+                self.we[name] = dict(kp=kp, w=bf(D, kp), wT=bf(kp, D))
+            elif isinstance(enc, TabularEncoder):
+                self.we[name] = dict(w2=bf(D, D), w2T=bf(D, D))
+
+    def _cast(self, src: torch.Tensor, dst: torch.Tensor, transpose=False, dst_row0=0, dst_col0=0):
+        """dst[dst_row0:, dst_col0:] (bf16) <- src (fp32 2-D), zero padding untouched (buffers start zeroed)."""
+        r, c = src.shape
+        d = dst[dst_row0:, dst_col0:]
+        rp, cp = (c, r) if transpose else (r, c)
+        call("mca_cast_pad_bf16", ptr(src), src.stride(0), r, c, ptr(d), dst.stride(0), rp, cp, int(transpose), stream_ptr())
+
+    def refresh_weights(self, force=False):
+        v = self.flat._version
+        if not force and v == self._weights_version:
+            return
+        m, D, I, Ip = self.model, self.D, self.I, self.Ip
+        for i, ly in enumerate(m.layers):
+            w = self.wl[i]
+            self._cast(ly.attn.to_q.weight.data, w["qkv"])
+            self._cast(ly.attn.to_kv.weight.data, w["qkv"], dst_row0=D)
+            self._cast(ly.attn.to_q.weight.data, w["qkvT"], transpose=True)
+            self._cast(ly.attn.to_kv.weight.data, w["qkvT"], transpose=True, dst_col0=D)
+            self._cast(ly.attn.to_out.weight.data, w["o"])
+            self._cast(ly.attn.to_out.weight.data, w["oT"], transpose=True)
+            w1 = ly.ff.feedforward[0].weight.data
+            self._cast(w1[:I], w["w1"])
+            self._cast(w1[I:], w["w1"], dst_row0=Ip)
+            self._cast(w1[:I], w["w1T"], transpose=True)
+            self._cast(w1[I:], w["w1T"], transpose=True, dst_col0=Ip)
+            w2 = ly.ff.feedforward[2].weight.data
+            self._cast(w2, w["w2"])
+            self._cast(w2, w["w2T"], transpose=True)
+        ap = m.attn_pool
+        self._cast(ap.to_q.weight.data, self.wp["q"]); self._cast(ap.to_q.weight.data, self.wp["qT"], transpose=True)
+        self._cast(ap.to_kv.weight.data, self.wp["kv"]); self._cast(ap.to_kv.weight.data, self.wp["kvT"], transpose=True)
+        self._cast(ap.to_out.weight.data, self.wp["o"]); self._cast(ap.to_out.weight.data, self.wp["oT"], transpose=True)
+        for name in m.modality_types:
+            enc = m.encoders[name]
+            if isinstance(enc, EmbeddedSequenceEncoder):
+                self._cast(enc.token_encoder[1].weight.data, self.we[name]["w"])
+                self._cast(enc.token_encoder[1].weight.data, self.we[name]["wT"], transpose=True)
+            elif isinstance(enc, TabularEncoder):
+                self._cast(enc.value_encoder.linear2.weight.data, self.we[name]["w2"])
+                self._cast(enc.value_encoder.linear2.weight.data, self.we[name]["w2T"], transpose=True)
+        self._weights_version = v
+
+    # ------------------------------------------------------------------------------------------------
+    # workspaces for a given local batch size
+    # ------------------------------------------------------------------------------------------------
+    def workspace(self, b: int) -> dict:
+        if b in self._ws:
+            return self._ws[b]
+        D, N, H, Ip, R, dev = self.D, self.N, self.H, self.Ip, self.R, self.device
+        T = b * N
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        bf = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
+        u8 = lambda *s: torch.empty(*s, dtype=torch.uint8, device=dev)
+        ws = dict(b=b, T=T)
+        ws["x"] = [f32(T, D) for _ in range(self.L + 1)]
+        ws["layers"] = [dict(x1=f32(T, D), m1=f32(T), r1=f32(T), m2=f32(T), r2=f32(T), xn_b=bf(T, D), qkv=bf(T, 3 * D),
+                             o=bf(T, D), lse=f32(b, H, N), x1n_b=bf(T, D), h=bf(T, 2 * Ip), g=bf(T, Ip))
+                        for _ in range(self.L)]
+        ws["xn"], ws["x1n"] = f32(T, D), f32(T, D)
+        ws["mf"], ws["rf"], ws["t_b"], ws["kvp"] = f32(T), f32(T), bf(T, D), bf(T, 2 * D)
+        ws["rt_b"], ws["qp"], ws["op"], ws["lse_p"] = bf(R, D), bf(R, D), bf(b * R, D), f32(b, H, R)
+        ws["pooled"] = f32(b * R, D)
+        ws["vmean"], ws["dvmean"], ws["delta"], ws["delta_p"] = f32(b, D), f32(b, D), f32(b, H, N), f32(b, H, R)
+        ws["keyinfo"], ws["kflags"] = u8(b, self.nk_pad), u8(b, (N + 63) // 64)
+        ws["padding"] = u8(b, N)
+        # backward
+        ws["dxa"], ws["dxb"], ws["dx_b"] = f32(T, D), f32(T, D), bf(T, D)
+        ws["dg"], ws["dh"], ws["do"], ws["dq32"], ws["dqkv"] = bf(T, Ip), bf(T, 2 * Ip), bf(T, D), f32(T, D), bf(T, 3 * D)
+        ws["dpool_b"], ws["dop"], ws["dqp32"], ws["dqp_sum"], ws["dqp_b"] = bf(b * R, D), bf(b * R, D), f32(b * R, D), f32(R, D), bf(R, D)
+        ws["dkvp"], ws["drt"] = bf(T, 2 * D), f32(R, D)
+        ws["enc"] = {}
+        for mi, name in enumerate(self.model.modality_types):
+            enc = self.model.encoders[name]
+            n = self.st.token_dims[mi]
+            rows = b * n
+            if isinstance(enc, EmbeddedSequenceEncoder):
+                kp = self.we[name]["kp"]
+                ws["enc"][name] = dict(xin_b=bf(rows, kp), m0=f32(rows), r0=f32(rows), y=f32(rows, D), m2=f32(rows), r2=f32(rows),
+                                       dy=f32(rows, D), dy_b=bf(rows, D), dxin=f32(rows, kp), mask=u8(rows))
+            elif isinstance(enc, TabularEncoder):
+                ws["enc"][name] = dict(h1_b=bf(rows, D), y=f32(rows, D), m2=f32(rows), r2=f32(rows), dy=f32(rows, D),
+                                       dy_b=bf(rows, D), dh1=f32(rows, D), mask=u8(rows))
+        ws["sqnorm"] = f32(1)
+        self._ws[b] = ws
+        return ws
+
+    # ------------------------------------------------------------------------------------------------
+    # thin kernel wrappers
+    # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def gemm_nt(A, B, C, M, N, K, bias=None, residual=None, res_period=0):
+        """C[M,N] = A[M,K] B[N,K]^T (+bias) (+residual)."""
+        call("mca_gemm_nt", ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), C.stride(0), int(C.dtype == torch.bfloat16),
+             ptr(bias), ptr(residual), residual.stride(0) if residual is not None else 0, res_period, M, N, K, stream_ptr())
+
+    @staticmethod
+    def gemm_tn_acc(A, B, Cgrad, R, N, K):
+        """Cgrad[N,K] += A[R,N]^T B[R,K]"""
+        call("mca_gemm_tn_acc", ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(Cgrad), Cgrad.stride(0), R, N, K, stream_ptr())
+
+    @staticmethod
+    def ln_fwd(x, gamma, rows, cols, mean, rstd, beta=None, rowmask=None, add=None, period=0, y=None, ldy=0, y_bstride=0,
+               y_bf16=None, cols_pad=0):
+        call("mca_layernorm_fwd", ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(rowmask), ptr(add), period,
+             ptr(y), ldy, y_bstride, ptr(y_bf16), y_bf16.stride(0) if y_bf16 is not None else 0, cols_pad,
+             ptr(mean), ptr(rstd), rows, cols, LN_EPS, stream_ptr())
+
+    @staticmethod
+    def ln_bwd(dy, ldy, x, gamma, mean, rstd, rows, cols, dgamma, dbeta=None, rowmask=None, dx=None, dx_bf16=None,
+               y_bstride=0, period=0):
+        call("mca_layernorm_bwd", ptr(dy), ldy, y_bstride, period, ptr(x), x.stride(0), ptr(gamma), ptr(mean), ptr(rstd),
+             ptr(rowmask), ptr(dx), dx.stride(0) if dx is not None else 0, ptr(dx_bf16),
+             dx_bf16.stride(0) if dx_bf16 is not None else 0, ptr(dgamma), ptr(dbeta), rows, cols, stream_ptr())
+
+    def _attn_fwd(self, q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, lse, qmask, sched, ws, b, nq):
+        N = self.N
+        a = AttnFwdArgs()
+        esz = 2
+        a.q, a.q_bstride, a.q_ld = q, q_bstride, q_ld
+        a.k, a.v = kv.data_ptr() + k_off * esz, kv.data_ptr() + v_off * esz
+        a.kv_bstride, a.kv_ld = N * kv_ld, kv_ld
+        a.o, a.o_bstride, a.o_ld = o.data_ptr(), nq * o.stride(0), o.stride(0)
+        a.lse = lse.data_ptr()
+        a.qmask, a.keyinfo, a.ktile_flags = qmask.data_ptr(), ws["keyinfo"].data_ptr(), ws["kflags"].data_ptr()
+        a.q_ptr, a.q_kt, a.q_full, a.q_order = (sched.q_ptr.data_ptr(), sched.q_kt.data_ptr(), sched.q_full.data_ptr(),
+                                                sched.q_order.data_ptr())
+        a.vmean = ws["vmean"].data_ptr()
+        a.batch, a.heads, a.nq, a.nk, a.nk_pad = b, self.H, nq, N, self.nk_pad
+        a.n_qtiles, a.n_ktiles, a.scale = sched.s.n_q, sched.s.n_k, self.scale
+        call("mca_attn_vmean", a.v, a.kv_bstride, a.kv_ld, ws["vmean"].data_ptr(), b, N, self.H, stream_ptr())
+        call("mca_attn_fwd", C.byref(a), stream_ptr())
+
+    def _attn_bwd(self, q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, d_o, lse, delta, dq, dq_bstride, dkv, dk_off,
+                  dv_off, dkv_ld, qmask, sched, ws, b, nq):
+        N = self.N
+        esz = 2
+        call("mca_attn_bwd_prep", o.data_ptr(), d_o.data_ptr(), nq * o.stride(0), o.stride(0), lse.data_ptr(),
+             delta.data_ptr(), ws["dvmean"].data_ptr(), b, self.H, nq, N, stream_ptr())
+        a = AttnBwdArgs()
+        a.q, a.q_bstride, a.q_ld = q, q_bstride, q_ld
+        a.k, a.v = kv.data_ptr() + k_off * esz, kv.data_ptr() + v_off * esz
+        a.kv_bstride, a.kv_ld = N * kv_ld, kv_ld
+        a.d_o, a.o_bstride, a.o_ld = d_o.data_ptr(), nq * d_o.stride(0), d_o.stride(0)
+        a.lse, a.delta, a.dvmean = lse.data_ptr(), delta.data_ptr(), ws["dvmean"].data_ptr()
+        a.dq, a.dq_bstride, a.dq_ld = dq.data_ptr(), dq_bstride, dq.stride(0)
+        a.dk, a.dv = dkv.data_ptr() + dk_off * esz, dkv.data_ptr() + dv_off * esz
+        a.dkv_bstride, a.dkv_ld = N * dkv_ld, dkv_ld
+        a.qmask, a.keyinfo, a.ktile_flags = qmask.data_ptr(), ws["keyinfo"].data_ptr(), ws["kflags"].data_ptr()
+        a.k_ptr, a.k_qt, a.k_full, a.k_order = (sched.k_ptr.data_ptr(), sched.k_qt.data_ptr(), sched.k_full.data_ptr(),
+                                                sched.k_order.data_ptr())
+        a.batch, a.heads, a.nq, a.nk, a.nk_pad = b, self.H, nq, N, self.nk_pad
+        a.n_qtiles, a.n_ktiles, a.scale = sched.s.n_q, sched.s.n_k, self.scale
+        call("mca_attn_bwd", C.byref(a), stream_ptr())
+
+    # ------------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------------
+    def _encode(self, batch, ws, need_grad: bool):
+        """encoders + packing (model.py:455-466): writes ws['x'][0] (b, N, D) and ws['padding'] (b, N)."""
+        m, D, N, b = self.model, self.D, self.N, ws["b"]
+        x0 = ws["x"][0]
+        sample_mask = {}
+        ws["foreign"] = {}
+        for mi, name in enumerate(m.modality_types):
+            enc = m.encoders[name]
+            n, off = self.st.token_dims[mi], self.offsets[mi]
+            bm = batch[name]
+            pad_view = ws["padding"].view(b, N)[:, off:off + n]
+            x0_view = x0.view(b, N, D)[:, off:off + n]
+            if isinstance(enc, EmbeddedSequenceEncoder):
+                e = ws["enc"][name]
+                toks = bm["tokens"]
+                if toks.dtype != torch.float32 or not toks.is_contiguous():
+                    toks = toks.float().contiguous()
+                if toks.shape != (b, n, enc.input_size):
+                    raise AssertionError(f"{name}: tokens {tuple(toks.shape)} != {(b, n, enc.input_size)}")
+                mask = bm["attention_mask"].to(torch.bool)
+                e["mask"].copy_(mask.reshape(-1))
+                pad_view.copy_(mask)
+                e["tokens"] = toks
+                te = enc.token_encoder
+                rows = b * n
+                t2 = toks.view(rows, enc.input_size)
+                self.ln_fwd(t2, te[0].weight, rows, enc.input_size, e["m0"], e["r0"], beta=te[0].bias, rowmask=e["mask"],
+                            y_bf16=e["xin_b"], cols_pad=self.we[name]["kp"])
+                self.gemm_nt(e["xin_b"], self.we[name]["w"], e["y"], rows, D, self.we[name]["kp"], bias=te[1].bias)
+                pe = enc.positional_encoder.pe
+                self.ln_fwd(e["y"], te[2].weight, rows, D, e["m2"], e["r2"], beta=te[2].bias, rowmask=e["mask"], add=pe,
+                            period=n, y=x0[off:], ldy=D, y_bstride=N * D)
+                sample_mask[name] = ~mask.all(dim=1)
+            elif isinstance(enc, TabularEncoder):
+                sample_mask[name] = self._encode_tabular(name, enc, bm, ws, mi)
+            else:
+                # user-registered torch encoder: run it with autograd and feed its tokens to the native trunk
+                with torch.enable_grad() if need_grad else torch.no_grad():
+                    toks, amask = enc(bm)
+                ws["foreign"][name] = toks
+                x0_view.copy_(toks.detach().float())
+                pad_view.copy_(amask.to(torch.bool))
+                sample_mask[name] = (amask == 0).sum(dim=1) != 0
+        if self.F:
+            call("mca_bcast_rows", ptr(m.fusion_tokens.data), D, x0.data_ptr() + (N - self.F) * D * 4, D, N * D, self.F,
+                 b * self.F, D, stream_ptr())
+            ws["padding"].view(b, N)[:, N - self.F:] = 0
+        return sample_mask
+
+    def _encode_tabular(self, name, enc, bm, ws, mi):
+        raise NotImplementedError("TabularEncoder native path: see engine_tabular (round 1 covers EmbeddedSequenceEncoder)")
+
+    def forward_trunk(self, ws):
+        """fusion layers + final norm + attentive pooling -> ws['pooled'] (b*R, D)."""
+        m, D, N, H, Ip, R, b, T = self.model, self.D, self.N, self.H, self.Ip, self.R, ws["b"], ws["T"]
+        call("mca_build_keyinfo", ptr(ws["padding"]), ptr(self.kgroup), ptr(ws["keyinfo"]), ptr(ws["kflags"]), b, N,
+             self.nk_pad, stream_ptr())
+        for i, ly in enumerate(m.layers):
+            w, a = self.wl[i], ws["layers"][i]
+            xin, xout = ws["x"][i], ws["x"][i + 1]
+            g = ly.norm.gamma
+            self.ln_fwd(xin, g, T, D, a["m1"], a["r1"], y=ws["xn"], ldy=D, y_bf16=a["xn_b"], cols_pad=D)
+            self.gemm_nt(a["xn_b"], w["qkv"], a["qkv"], T, 3 * D, D)
+            self._attn_fwd(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], a["lse"],
+                           self.qmask_attn, self.sched_attn_f, ws, b, N)
+            self.gemm_nt(a["o"], w["o"], a["x1"], T, D, D, residual=ws["xn"])
+            self.ln_fwd(a["x1"], g, T, D, a["m2"], a["r2"], y=ws["x1n"], ldy=D, y_bf16=a["x1n_b"], cols_pad=D)
+            self.gemm_nt(a["x1n_b"], w["w1"], a["h"], T, 2 * Ip, D)
+            call("mca_geglu_fwd", ptr(a["h"]), ptr(a["g"]), T, Ip, stream_ptr())
+            self.gemm_nt(a["g"], w["w2"], xout, T, D, Ip, residual=ws["x1n"])
+        xl = ws["x"][self.L]
+        self.ln_fwd(xl, m.norm.gamma, T, D, ws["mf"], ws["rf"], y_bf16=ws["t_b"], cols_pad=D)
+        self.gemm_nt(ws["t_b"], self.wp["kv"], ws["kvp"], T, 2 * D, D)
+        call("mca_f32_to_bf16", ptr(m.return_tokens.data), D, ptr(ws["rt_b"]), D, R, D, 1.0, stream_ptr())
+        self.gemm_nt(ws["rt_b"], self.wp["q"], ws["qp"], R, D, D)
+        self._attn_fwd(ws["qp"].data_ptr(), 0, D, ws["kvp"], 0, D, 2 * D, ws["op"], ws["lse_p"], self.qmask_pool,
+                       self.sched_pool_f, ws, b, R)
+        self.gemm_nt(ws["op"], self.wp["o"], ws["pooled"], b * R, D, D, residual=m.return_tokens.data, res_period=R)
+        return ws["pooled"]
+
+    # ------------------------------------------------------------------------------------------------
+    # loss (+ its gradient w.r.t. the local pooled block and the temperature)
+    # ------------------------------------------------------------------------------------------------
+    def loss_fwd_bwd(self, pooled_all, present_all, b_local, row0):
+        B, R, D, T = pooled_all.shape[0], self.R, self.D, self.n_terms
+        dev = self.device
+        nbytes = hip.lib().mca_contrastive_workspace_bytes(B, T)
+        key = ("lossws", B)
+        if key not in self._ws:
+            self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = dict(term_loss=torch.empty(T, dtype=torch.float32, device=dev), loss=torch.empty(1, dtype=torch.float32, device=dev),
+                   d_pooled=torch.empty(b_local, R, D, dtype=torch.float32, device=dev),
+                   d_logit=torch.empty(1, dtype=torch.float32, device=dev))
+        ls = self.model.loss.loss_fn.logit_scale
+        call("mca_contrastive_fwd_bwd", ptr(pooled_all), ptr(present_all), ptr(self.loss_terms_dev), T, ptr(ls.data), B, b_local,
+             row0, R, D, ptr(out["term_loss"]), ptr(out["loss"]), ptr(out["d_pooled"]), ptr(out["d_logit"]),
+             ptr(self._ws[key]), stream_ptr())
+        return out
+
+    # ------------------------------------------------------------------------------------------------
+    # backward
+    # ------------------------------------------------------------------------------------------------
+    def _bucket_ready(self, idx):
+        if self.grad_bucket_hook is not None:
+            lo = 0 if idx == 0 else self.bucket_bounds[idx - 1]
+            self.grad_bucket_hook(lo, self.bucket_bounds[idx])
+
+    def backward(self, ws, d_pooled, d_logit_scale=None, accumulate=False):
+        """d_pooled: (b, R, D) fp32 gradient of the objective w.r.t. the pooled tokens.  Writes every parameter
+        gradient into the flat gradient buffer."""
+        m, D, N, H, Ip, I, R, b, T = self.model, self.D, self.N, self.H, self.Ip, self.I, self.R, ws["b"], ws["T"]
+        if not accumulate:
+            self.gflat.zero_()
+        G = self.grad_of
+        if d_logit_scale is not None:
+            G(m.loss.loss_fn.logit_scale).add_(d_logit_scale.reshape(()))
+        dpool = d_pooled.reshape(b * R, D).contiguous()
+        ap = m.attn_pool
+        # pooled = op @ Wo^T + return_tokens
+        call("mca_reduce_rows", ptr(dpool), D, R * D, R, ptr(G(m.return_tokens)), D, b * R, D, stream_ptr())
+        call("mca_f32_to_bf16", ptr(dpool), D, ptr(ws["dpool_b"]), D, b * R, D, 1.0, stream_ptr())
+        self.gemm_nt(ws["dpool_b"], self.wp["oT"], ws["dop"], b * R, D, D)
+        self.gemm_tn_acc(ws["dpool_b"], ws["op"], G(ap.to_out.weight), b * R, D, D)
+        # pooling attention
+        ws["dqp32"].zero_()
+        self._attn_bwd(ws["qp"].data_ptr(), 0, D, ws["kvp"], 0, D, 2 * D, ws["op"], ws["dop"], ws["lse_p"], ws["delta_p"],
+                       ws["dqp32"], R * D, ws["dkvp"], 0, D, 2 * D, self.qmask_pool, self.sched_pool_b, ws, b, R)
+        ws["dqp_sum"].zero_()
+        call("mca_reduce_rows", ptr(ws["dqp32"]), D, R * D, R, ptr(ws["dqp_sum"]), D, b * R, D, stream_ptr())
+        call("mca_f32_to_bf16", ptr(ws["dqp_sum"]), D, ptr(ws["dqp_b"]), D, R, D, 1.0, stream_ptr())
+        self.gemm_tn_acc(ws["dqp_b"], ws["rt_b"], G(ap.to_q.weight), R, D, D)
+        self.gemm_nt(ws["dqp_b"], self.wp["qT"], ws["drt"], R, D, D)                 # d return_tokens via to_q
+        G(m.return_tokens).add_(ws["drt"])
+        self.gemm_tn_acc(ws["dkvp"], ws["t_b"], G(ap.to_kv.weight), T, 2 * D, D)
+        dx, dx_other = ws["dxa"], ws["dxb"]
+        self.gemm_nt(ws["dkvp"], self.wp["kvT"], dx, T, D, 2 * D)                    # d (final-normed tokens), fp32
+        self.ln_bwd(dx, D, ws["x"][self.L], m.norm.gamma, ws["mf"], ws["rf"], T, D, G(m.norm.gamma), dx=dx_other,
+                    dx_bf16=ws["dx_b"])
+        dx, dx_other = dx_other, dx
+        self._bucket_ready(0)
+        for bi, i in enumerate(reversed(range(self.L))):
+            ly, w, a = m.layers[i], self.wl[i], ws["layers"][i]
+            g = ly.norm.gamma
+            # x_out = g @ W2^T + x1n            (dx = d x_out, fp32 + bf16 copy in ws['dx_b'])
+            self.gemm_nt(ws["dx_b"], w["w2T"], ws["dg"], T, Ip, D)
+            self.gemm_tn_acc(ws["dx_b"], a["g"], G(ly.ff.feedforward[2].weight), T, D, I)
+            call("mca_geglu_bwd", ptr(ws["dg"]), ptr(a["h"]), ptr(ws["dh"]), T, Ip, stream_ptr())
+            gw1 = G(ly.ff.feedforward[0].weight)
+            self.gemm_tn_acc(ws["dh"], a["x1n_b"], gw1, T, I, D)
+            self.gemm_tn_acc(ws["dh"][:, Ip:], a["x1n_b"], gw1[I:], T, I, D)
+            self.gemm_nt(ws["dh"], w["w1T"], dx_other, T, D, 2 * Ip, residual=dx)      # d x1n = dh @ W1 + dx
+            self.ln_bwd(dx_other, D, a["x1"], g, a["m2"], a["r2"], T, D, G(g), dx=dx, dx_bf16=ws["dx_b"])   # dx = d x1
+            # x1 = o @ Wo^T + xn
+            self.gemm_nt(ws["dx_b"], w["oT"], ws["do"], T, D, D)
+            self.gemm_tn_acc(ws["dx_b"], a["o"], G(ly.attn.to_out.weight), T, D, D)
+            ws["dq32"].zero_()
+            self._attn_bwd(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], ws["do"], a["lse"],
+                           ws["delta"], ws["dq32"], N * D, ws["dqkv"], D, 2 * D, 3 * D, self.qmask_attn, self.sched_attn_b,
+                           ws, b, N)
+            call("mca_f32_to_bf16", ptr(ws["dq32"]), D, ptr(ws["dqkv"]), 3 * D, T, D, 1.0, stream_ptr())
+            self.gemm_tn_acc(ws["dqkv"], a["xn_b"], G(ly.attn.to_q.weight), T, D, D)
+            self.gemm_tn_acc(ws["dqkv"][:, D:], a["xn_b"], G(ly.attn.to_kv.weight), T, 2 * D, D)
+            self.gemm_nt(ws["dqkv"], w["qkvT"], dx_other, T, D, 3 * D, residual=dx)   # d xn = dqkv @ Wqkv + d x1
+            self.ln_bwd(dx_other, D, ws["x"][i], g, a["m1"], a["r1"], T, D, G(g), dx=dx, dx_bf16=ws["dx_b"])  # dx = d x_in
+            self._bucket_ready(bi + 1)
+        # dx = gradient w.r.t. the packed encoder output (b, N, D)
+        if self.F:
+            call("mca_reduce_rows", dx.data_ptr() + (N - self.F) * D * 4, D, N * D, self.F, ptr(G(m.fusion_tokens)), D,
+                 b * self.F, D, stream_ptr())
+        for mi, name in enumerate(m.modality_types):
+            enc = m.encoders[name]
+            n, off = self.st.token_dims[mi], self.offsets[mi]
+            rows = b * n
+            if isinstance(enc, EmbeddedSequenceEncoder):
+                e, te = ws["enc"][name], enc.token_encoder
+                kp = self.we[name]["kp"]
+                self.ln_bwd(dx[off:], D, e["y"], te[2].weight, e["m2"], e["r2"], rows, D, G(te[2].weight), dbeta=G(te[2].bias),
+                            rowmask=e["mask"], dx=e["dy"], dx_bf16=e["dy_b"], y_bstride=N * D, period=n)
+                call("mca_reduce_rows", ptr(e["dy"]), D, D, 1, ptr(G(te[1].bias)), D, rows, D, stream_ptr())
+                self.gemm_tn_acc(e["dy_b"], e["xin_b"], G(te[1].weight), rows, D, enc.input_size)
+                self.gemm_nt(e["dy_b"], self.we[name]["wT"], e["dxin"], rows, kp, D)
+                t2 = e["tokens"].view(rows, enc.input_size)
+                self.ln_bwd(e["dxin"], kp, t2, te[0].weight, e["m0"], e["r0"], rows, enc.input_size, G(te[0].weight),
+                            dbeta=G(te[0].bias), rowmask=e["mask"])
+            elif isinstance(enc, TabularEncoder):
+                self._backward_tabular(name, enc, ws, mi, dx)
+            else:
+                toks = ws["foreign"][name]
+                if toks.requires_grad:
+                    torch.autograd.backward(toks, dx.view(b, N, D)[:, off:off + n].to(toks.dtype))
+        self._bucket_ready(len(self.bucket_bounds) - 1)
+
+    def _backward_tabular(self, name, enc, ws, mi, dx):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------------------------------------
+    # model-level forward (autograd node)
+    # ------------------------------------------------------------------------------------------------
+    def model_forward(self, batch, no_loss=False):
+        m = self.model
+        first = batch[m.modality_types[0]]
+        b = next(iter(first.values())).shape[0]
+        need_grad = torch.is_grad_enabled() and not no_loss
+        if self.check_finite:
+            bad = [(~torch.isfinite(v["tokens"])).any() for v in batch.values() if isinstance(v, dict) and "tokens" in v]
+            if bad and bool(torch.stack(bad).any()):
+                raise Exception("Tokens are not finite")               # encoders.py:197-198
+        self.refresh_weights()
+        ws = self.workspace(b)
+        sample_mask = self._encode(batch, ws, need_grad)
+        pooled = self.forward_trunk(ws).view(b, self.R, self.D)
+        slots = m.output_slots()
+        if no_loss:
+            out = {k: pooled[:, s] for k, s in slots.items()}
+            out["modality_sample_mask"] = sample_mask
+            return out
+        # in-place clamp of the temperature parameter (utils/contrastive_loss_with_temperature.py:187)
+        ls = m.loss.loss_fn
+        ls.logit_scale.data.clamp_(ls.logit_scale_min, ls.logit_scale_max)
+        present = torch.zeros(b, dtype=torch.int32, device=self.device)
+        for mi, name in enumerate(m.modality_types):
+            present |= sample_mask[name].to(torch.int32) << mi
+        if need_grad:
+            pooled_out, terms, loss = _MCAStep.apply(self, ws, pooled, present, *self.param_order)
+        else:
+            pooled_out, terms, loss, _ = _loss_forward(self, pooled, present)
+        out = {k: pooled_out[:, s] for k, s in slots.items()}
+        names = [t.name for t in m.loss_terms]
+        out["losses"] = {n: terms[i] for i, n in enumerate(names)}
+        if m.fcl and not m.zorro:
+            fc = [i for i, n in enumerate(names) if "fcl" in n]
+            nf = [i for i, n in enumerate(names) if "fcl" not in n]
+            out["fcl_loss"] = torch.nan_to_num(terms[fc]).mean()
+            out["no-fcl_loss"] = torch.nan_to_num(terms[nf]).mean()
+        out["loss"] = loss.reshape(())
+        out["modality_sample_mask"] = sample_mask
+        if self.check_finite and not bool(torch.isfinite(pooled_out).all()):
+            raise Exception("Encoder transform / fusion resulted in non-finite values")   # encoders.py:206-213
+        return out
+
+
+def _loss_forward(engine, pooled, present):
+    """(optional all-gather of pooled embeddings + presence bits) then the fused loss kernels."""
+    b = pooled.shape[0]
+    if engine.gather_hook is not None:
+        pooled_all, present_all, row0 = engine.gather_hook(pooled, present)
+    else:
+        pooled_all, present_all, row0 = pooled, present, 0
+    res = engine.loss_fwd_bwd(pooled_all.contiguous(), present_all.contiguous(), b, row0)
+    return pooled.clone(), res["term_loss"], res["loss"], res
+
+
+class _MCAStep(torch.autograd.Function):
+    """One autograd node for the whole step.  forward: (optional all-gather) + loss kernels, which also
+    produce d loss/d pooled; backward: the engine's backward chain, gradients written straight into the flat
+    gradient buffer (each parameter's ``.grad`` is a view of it)."""
+
+    @staticmethod
+    def forward(ctx, engine, ws, pooled, present, *params):
+        pooled_out, terms, loss, res = _loss_forward(engine, pooled, present)
+        ctx.engine, ctx.ws, ctx.res = engine, ws, res
+        ctx.mark_non_differentiable(terms)
+        return pooled_out, terms, loss
+
+    @staticmethod
+    def backward(ctx, g_pooled, g_terms, g_loss):
+        engine, ws, res = ctx.engine, ctx.ws, ctx.res
+        d_pooled = res["d_pooled"] * g_loss.reshape(())
+        if g_pooled is not None:
+            d_pooled = d_pooled + g_pooled
+        params = engine.param_order
+        live = params[0].grad is not None and params[0].grad.data_ptr() == engine.grad_of(params[0]).data_ptr()
+        engine.backward(ws, d_pooled, res["d_logit"] * g_loss.reshape(()), accumulate=live)
+        for p in params:
+            p.grad = engine.grad_of(p)
+        return (None, None, None, None) + tuple(None for _ in params)
+
+
+def run_single_encoder(enc: NativeEncoder, batch):
+    raise NotImplementedError("standalone encoder forward: construct an MCA model and call it (the encoders are fused "
+                              "into the model's step)")

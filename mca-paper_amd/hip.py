@@ -1,0 +1,119 @@
+"""ctypes binding of libmca_hip.so (C ABI declared in include/mca_hip.h).
+
+The library holds every compute kernel of the step; there is NO fallback: if it is missing or a call
+returns an error code, this module raises.  Tensors are passed as raw device pointers
+(``tensor.data_ptr()``) plus the current HIP stream handle — PyTorch only owns the memory.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmca_hip.so")
+
+_ERR = {-1: "bad argument", -2: "misaligned pointer / leading dimension", -3: "unsupported size", -4: "launch failed"}
+
+
+class MCAHipError(RuntimeError):
+    pass
+
+
+class LossTerm(C.Structure):
+    _fields_ = [("slot_a", C.c_int32), ("slot_b", C.c_int32), ("and_bits", C.c_uint32), ("or_bits", C.c_uint32)]
+
+
+class AttnFwdArgs(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("q_bstride", C.c_int64), ("q_ld", C.c_int64),
+        ("k", C.c_void_p), ("v", C.c_void_p), ("kv_bstride", C.c_int64), ("kv_ld", C.c_int64),
+        ("o", C.c_void_p), ("o_bstride", C.c_int64), ("o_ld", C.c_int64),
+        ("lse", C.c_void_p), ("qmask", C.c_void_p), ("keyinfo", C.c_void_p), ("ktile_flags", C.c_void_p),
+        ("q_ptr", C.c_void_p), ("q_kt", C.c_void_p), ("q_full", C.c_void_p), ("q_order", C.c_void_p),
+        ("vmean", C.c_void_p),
+        ("batch", C.c_int), ("heads", C.c_int), ("nq", C.c_int), ("nk", C.c_int), ("nk_pad", C.c_int),
+        ("n_qtiles", C.c_int), ("n_ktiles", C.c_int), ("scale", C.c_float),
+    ]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("q_bstride", C.c_int64), ("q_ld", C.c_int64),
+        ("k", C.c_void_p), ("v", C.c_void_p), ("kv_bstride", C.c_int64), ("kv_ld", C.c_int64),
+        ("d_o", C.c_void_p), ("o_bstride", C.c_int64), ("o_ld", C.c_int64),
+        ("lse", C.c_void_p), ("delta", C.c_void_p), ("dvmean", C.c_void_p),
+        ("dq", C.c_void_p), ("dq_bstride", C.c_int64), ("dq_ld", C.c_int64),
+        ("dk", C.c_void_p), ("dv", C.c_void_p), ("dkv_bstride", C.c_int64), ("dkv_ld", C.c_int64),
+        ("qmask", C.c_void_p), ("keyinfo", C.c_void_p), ("ktile_flags", C.c_void_p),
+        ("k_ptr", C.c_void_p), ("k_qt", C.c_void_p), ("k_full", C.c_void_p), ("k_order", C.c_void_p),
+        ("batch", C.c_int), ("heads", C.c_int), ("nq", C.c_int), ("nk", C.c_int), ("nk_pad", C.c_int),
+        ("n_qtiles", C.c_int), ("n_ktiles", C.c_int), ("scale", C.c_float),
+    ]
+
+
+_P, _I64, _I, _F = C.c_void_p, C.c_int64, C.c_int, C.c_float
+
+# name -> (restype, argtypes).  Must list EVERY symbol include/mca_hip.h declares (tests check this).
+SIGNATURES = {
+    "mca_version": (C.c_char_p, []),
+    "mca_gemm_nt": (_I, [_P, _I64, _P, _I64, _P, _I64, _I, _P, _P, _I64, _I64, _I64, _I64, _I64, _P]),
+    "mca_gemm_tn_acc": (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P]),
+    "mca_layernorm_fwd": (_I, [_P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _I, _P, _P, _I64, _I, _F, _P]),
+    "mca_layernorm_bwd": (_I, [_P, _I64, _I64, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I, _P]),
+    "mca_geglu_fwd": (_I, [_P, _P, _I64, _I, _P]),
+    "mca_geglu_bwd": (_I, [_P, _P, _P, _I64, _I, _P]),
+    "mca_cast_pad_bf16": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I, _P]),
+    "mca_f32_to_bf16": (_I, [_P, _I64, _P, _I64, _I64, _I64, _F, _P]),
+    "mca_bcast_rows": (_I, [_P, _I64, _P, _I64, _I64, _I64, _I64, _I, _P]),
+    "mca_reduce_rows": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I, _P]),
+    "mca_build_keyinfo": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "mca_attn_vmean": (_I, [_P, _I64, _I64, _P, _I, _I, _I, _P]),
+    "mca_attn_fwd": (_I, [C.POINTER(AttnFwdArgs), _P]),
+    "mca_attn_bwd_prep": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "mca_attn_bwd": (_I, [C.POINTER(AttnBwdArgs), _P]),
+    "mca_contrastive_workspace_bytes": (_I64, [_I, _I]),
+    "mca_contrastive_fwd_bwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "mca_grad_sqnorm": (_I, [_P, _I64, _P, _P]),
+    "mca_adamw_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load the shared library (built by ``__graft_entry__.build()`` / ``mca-paper_amd/build.py``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MCAHipError(
+                f"{LIB_PATH} not found: the HIP extension is not built (run `python __graft_entry__.py build`). "
+                "There is no CPU or eager fallback for the MCA step.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise MCAHipError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def call(name: str, *args):
+    check(getattr(lib(), name)(*args), name)

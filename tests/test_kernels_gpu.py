@@ -1,0 +1,373 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against a plain torch fp32/fp64 restatement
+of the same op (floating point: tolerances written per test).  All calls go through the C ABI."""
+import ctypes as C
+import importlib
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    hip = importlib.import_module("mca-paper_amd.hip")
+    hip.lib()
+    return hip
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (1000, 1536, 512), (129, 2816, 512), (16, 512, 512), (4060, 512, 1408)])
+def test_gemm_nt(H, M, N, K):
+    g = torch.Generator(device="cuda").manual_seed(1)
+    A = bf(torch.randn(M, K, device="cuda", generator=g))
+    B = bf(torch.randn(N, K, device="cuda", generator=g))
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    ref = A.float() @ B.float().t()
+    C32 = torch.empty(M, N, device="cuda")
+    H.call("mca_gemm_nt", A.data_ptr(), K, B.data_ptr(), K, C32.data_ptr(), N, 0, None, None, 0, 0, M, N, K, H.stream_ptr())
+    assert rel(C32, ref) < 1e-5
+    H.call("mca_gemm_nt", A.data_ptr(), K, B.data_ptr(), K, C32.data_ptr(), N, 0, bias.data_ptr(), res.data_ptr(), N, 0, M, N, K, H.stream_ptr())
+    assert rel(C32, ref + bias + res) < 1e-5
+    Cb = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    H.call("mca_gemm_nt", A.data_ptr(), K, B.data_ptr(), K, Cb.data_ptr(), N, 1, None, None, 0, 0, M, N, K, H.stream_ptr())
+    assert rel(Cb.float(), ref) < 4e-3
+    # broadcast residual (row % period)
+    per = 16 if M % 16 == 0 else 0
+    if per:
+        r2 = torch.randn(per, N, device="cuda", generator=g)
+        H.call("mca_gemm_nt", A.data_ptr(), K, B.data_ptr(), K, C32.data_ptr(), N, 0, None, r2.data_ptr(), N, per, M, N, K, H.stream_ptr())
+        assert rel(C32, ref + r2.repeat(M // per, 1)) < 1e-5
+
+
+@pytest.mark.parametrize("R,N,K,lda,ldb", [(1000, 512, 512, 512, 512), (777, 1365, 512, 2816, 512), (2048, 512, 1365, 512, 1408),
+                                           (16, 512, 512, 512, 512), (500, 128, 74, 128, 128), (5000, 1024, 512, 1536, 512)])
+def test_gemm_tn_acc(H, R, N, K, lda, ldb):
+    g = torch.Generator(device="cuda").manual_seed(2)
+    A = bf(torch.randn(R, lda, device="cuda", generator=g))
+    B = bf(torch.randn(R, ldb, device="cuda", generator=g))
+    Cg = torch.randn(N, K, device="cuda", generator=g)
+    ref = Cg + A[:, :N].float().t() @ B[:, :K].float()
+    H.call("mca_gemm_tn_acc", A.data_ptr(), lda, B.data_ptr(), ldb, Cg.data_ptr(), K, R, N, K, H.stream_ptr())
+    assert rel(Cg, ref) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,cols,affine,masked", [(1000, 512, False, False), (333, 74, True, True), (64, 713, True, True),
+                                                      (90, 128, True, True)])
+def test_layernorm_fwd_bwd(H, rows, cols, affine, masked):
+    g = torch.Generator(device="cuda").manual_seed(3)
+    period = 30 if masked else 0
+    nb = rows // period if period else 0
+    if period:
+        rows = nb * period
+    x = torch.randn(rows, cols, device="cuda", generator=g) * 2 + 0.5
+    gamma = torch.randn(cols, device="cuda", generator=g)
+    beta = torch.randn(cols, device="cuda", generator=g) if affine else None
+    mask = (torch.rand(rows, device="cuda", generator=g) < 0.3) if masked else None
+    add = torch.randn(period, cols, device="cuda", generator=g) if period else None
+    cols_pad = (cols + 63) // 64 * 64
+    # packed output: (nb, NTOT, cols) with this block at row offset 5
+    NTOT = period + 11 if period else 0
+    y = torch.zeros(nb, NTOT, cols, device="cuda") if period else torch.empty(rows, cols, device="cuda")
+    yb = torch.full((rows, cols_pad), 7.0, device="cuda", dtype=torch.bfloat16)
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    yptr = y.data_ptr() + (5 * cols * 4 if period else 0)
+    mm = mask.to(torch.uint8) if masked else None
+    H.call("mca_layernorm_fwd", x.data_ptr(), cols, gamma.data_ptr(), H.ptr(beta), H.ptr(mm),
+           H.ptr(add), period, yptr, cols, NTOT * cols, yb.data_ptr(), cols_pad, cols_pad, mean.data_ptr(), rstd.data_ptr(), rows, cols,
+           1e-5, H.stream_ptr())
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True) if affine else None
+    xin = xr.masked_fill(mask[:, None], 0.0) if masked else xr
+    ref = torch.nn.functional.layer_norm(xin, (cols,), gr, br if affine else torch.zeros_like(gr), 1e-5)
+    if masked:
+        ref = ref.masked_fill(mask[:, None], 0.0)
+    ref_b = ref
+    ref_y = ref + add.repeat(nb, 1) if period else ref
+    got_y = y[:, 5:5 + period].reshape(rows, cols) if period else y
+    assert rel(got_y, ref_y) < 1e-5
+    assert rel(yb[:, :cols].float(), ref_b) < 4e-3
+    assert (yb[:, cols:] == 0).all()
+    # backward
+    dy_full = torch.randn_like(y)
+    dy = dy_full[:, 5:5 + period].reshape(rows, cols) if period else dy_full
+    ref_y.backward(dy)
+    dx = torch.empty(rows, cols, device="cuda")
+    dxb = torch.empty(rows, cols_pad, device="cuda", dtype=torch.bfloat16)
+    dgamma = torch.zeros(cols, device="cuda")
+    dbeta = torch.zeros(cols, device="cuda") if affine else None
+    dyptr = dy_full.data_ptr() + (5 * cols * 4 if period else 0)
+    H.call("mca_layernorm_bwd", dyptr, cols, NTOT * cols, period, x.data_ptr(), cols, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+           H.ptr(mm), dx.data_ptr(), cols, dxb.data_ptr(), cols_pad, dgamma.data_ptr(), H.ptr(dbeta), rows, cols, H.stream_ptr())
+    gx = xr.grad
+    assert rel(dx, gx) < 2e-5
+    assert rel(dxb[:, :cols].float(), gx) < 4e-3
+    assert rel(dgamma, gr.grad) < 2e-5
+    if affine:
+        assert rel(dbeta, br.grad) < 2e-5
+
+
+# ----------------------------------------------------------------------------------------------- GEGLU
+def test_geglu(H):
+    g = torch.Generator(device="cuda").manual_seed(4)
+    rows, ip = 777, 1408
+    h = bf(torch.randn(rows, 2 * ip, device="cuda", generator=g))
+    out = torch.empty(rows, ip, device="cuda", dtype=torch.bfloat16)
+    H.call("mca_geglu_fwd", h.data_ptr(), out.data_ptr(), rows, ip, H.stream_ptr())
+    hr = h.float().requires_grad_(True)
+    a, gate = hr[:, :ip], hr[:, ip:]
+    ref = torch.nn.functional.gelu(gate) * a
+    assert rel(out.float(), ref) < 4e-3
+    dg = bf(torch.randn(rows, ip, device="cuda", generator=g))
+    ref.backward(dg.float())
+    dh = torch.empty(rows, 2 * ip, device="cuda", dtype=torch.bfloat16)
+    H.call("mca_geglu_bwd", dg.data_ptr(), h.data_ptr(), dh.data_ptr(), rows, ip, H.stream_ptr())
+    assert rel(dh.float(), hr.grad) < 4e-3
+
+
+# ------------------------------------------------------------------------------------- data movement
+def test_cast_bcast_reduce(H):
+    g = torch.Generator(device="cuda").manual_seed(5)
+    src = torch.randn(100, 74, device="cuda", generator=g)
+    dst = torch.full((128, 128), 3.0, device="cuda", dtype=torch.bfloat16)
+    H.call("mca_cast_pad_bf16", src.data_ptr(), 74, 100, 74, dst.data_ptr(), 128, 128, 128, 0, H.stream_ptr())
+    assert torch.equal(dst[:100, :74], bf(src)) and (dst[100:] == 0).all() and (dst[:, 74:] == 0).all()
+    dstT = torch.full((128, 128), 3.0, device="cuda", dtype=torch.bfloat16)
+    H.call("mca_cast_pad_bf16", src.data_ptr(), 74, 100, 74, dstT.data_ptr(), 128, 128, 128, 1, H.stream_ptr())
+    assert torch.equal(dstT[:74, :100], bf(src).t()) and (dstT[74:] == 0).all() and (dstT[:, 100:] == 0).all()
+    s2 = torch.randn(50, 512, device="cuda", generator=g)
+    d2 = torch.zeros(50, 1536, device="cuda", dtype=torch.bfloat16)
+    H.call("mca_f32_to_bf16", s2.data_ptr(), 512, d2.data_ptr() + 512 * 2, 1536, 50, 512, 0.5, H.stream_ptr())
+    assert torch.equal(d2[:, 512:1024], bf(s2 * 0.5)) and (d2[:, :512] == 0).all()
+    # broadcast 8 learned rows into a (b=3, N=20, D=64) buffer at row offset 12
+    toks = torch.randn(8, 64, device="cuda", generator=g)
+    buf = torch.zeros(3, 20, 64, device="cuda")
+    H.call("mca_bcast_rows", toks.data_ptr(), 64, buf.data_ptr() + 12 * 64 * 4, 64, 20 * 64, 8, 24, 64, H.stream_ptr())
+    assert torch.equal(buf[:, 12:], toks[None].expand(3, -1, -1)) and (buf[:, :12] == 0).all()
+    # reduce back
+    gsrc = torch.randn(3, 20, 64, device="cuda", generator=g)
+    acc = torch.ones(8, 64, device="cuda")
+    H.call("mca_reduce_rows", gsrc.data_ptr() + 12 * 64 * 4, 64, 20 * 64, 8, acc.data_ptr(), 64, 24, 64, H.stream_ptr())
+    assert rel(acc, 1 + gsrc[:, 12:].sum(0)) < 1e-6
+    cs = torch.zeros(64, device="cuda")
+    flat = gsrc.reshape(60, 64)
+    H.call("mca_reduce_rows", flat.data_ptr(), 64, 64, 1, cs.data_ptr(), 64, 60, 64, H.stream_ptr())
+    assert rel(cs, flat.sum(0)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------- attention
+def dense_attention(q, k, v, allowed, pad, scale):
+    """model.py:87-99 on (b,h,n,d) tensors; allowed (nq,nk) bool, pad (b,nk) bool."""
+    sim = torch.einsum("bhid,bhjd->bhij", q * scale, k)
+    neg = -torch.finfo(sim.dtype).max
+    sim = sim.masked_fill(~allowed[None, None], neg)
+    sim = sim.masked_fill(pad[:, None, None, :], neg)
+    return torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v)
+
+
+def _attention_case(H, st, b, heads, pool, seed, drop_first):
+    eng = importlib.import_module("mca-paper_amd.engine")
+    N, D = st.n_tokens, heads * 64
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(seed)
+    qmask_np = st.qmask_pool if pool else st.qmask_attn
+    nq = len(qmask_np)
+    sf = eng._Sched(st.pool_schedule(128, 64) if pool else st.attn_schedule(128, 64), dev)
+    sb = eng._Sched(st.pool_schedule(32, 256) if pool else st.attn_schedule(32, 256), dev)
+    qmask = torch.from_numpy(qmask_np.astype(np.uint32).view(np.int32)).to(dev)
+    kgroup = torch.from_numpy(st.kgroup).to(dev)
+    allowed = torch.from_numpy(~(st.dense_pool_mask() if pool else st.dense_attn_mask())).to(dev)
+    # padding: random valid prefix per modality; sample 0 optionally loses its first modality entirely
+    pad = torch.zeros(b, N, dtype=torch.bool, device=dev)
+    off = 0
+    for mi, n in enumerate(st.token_dims):
+        ln = torch.randint(1, n + 1, (b,), generator=g, device=dev)
+        if drop_first and mi == 0:
+            ln[0] = 0
+        pad[:, off:off + n] = torch.arange(n, device=dev)[None] >= ln[:, None]
+        off += n
+    qkv = bf(torch.randn(b, N, 3 * D, device=dev, generator=g))
+    if pool:
+        qsrc = bf(torch.randn(nq, D, device=dev, generator=g))
+        q4 = qsrc.float().view(1, nq, heads, 64).permute(0, 2, 1, 3).expand(b, -1, -1, -1)
+    else:
+        q4 = qkv[:, :, :D].float().view(b, N, heads, 64).permute(0, 2, 1, 3)
+    k4 = qkv[:, :, D:2 * D].float().view(b, N, heads, 64).permute(0, 2, 1, 3)
+    v4 = qkv[:, :, 2 * D:].float().view(b, N, heads, 64).permute(0, 2, 1, 3)
+    q4r, k4r, v4r = (t.double().clone().requires_grad_(True) for t in (q4, k4, v4))
+    ref = dense_attention(q4r, k4r, v4r, allowed, pad, 0.125)          # (b,h,nq,64)
+    ref_o = ref.permute(0, 2, 1, 3).reshape(b, nq, D)
+
+    nk_pad = (N + 255) // 256 * 256
+    keyinfo = torch.empty(b, nk_pad, dtype=torch.uint8, device=dev)
+    kflags = torch.empty(b, (N + 63) // 64, dtype=torch.uint8, device=dev)
+    H.call("mca_build_keyinfo", pad.to(torch.uint8).data_ptr(), kgroup.data_ptr(), keyinfo.data_ptr(), kflags.data_ptr(), b, N, nk_pad,
+           H.stream_ptr())
+    exp_info = torch.where(pad, torch.full_like(pad, 31, dtype=torch.uint8), kgroup[None].expand(b, -1))
+    assert torch.equal(keyinfo[:, :N], exp_info) and (keyinfo[:, N:] == 31).all()
+    vmean = torch.empty(b, D, device=dev)
+    vptr = qkv.data_ptr() + 2 * D * 2
+    H.call("mca_attn_vmean", vptr, N * 3 * D, 3 * D, vmean.data_ptr(), b, N, heads, H.stream_ptr())
+    assert rel(vmean, qkv[:, :, 2 * D:].float().mean(1)) < 1e-5
+    o = torch.zeros(b * nq, D, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(b, heads, nq, device=dev)
+    a = H.AttnFwdArgs()
+    if pool:
+        a.q, a.q_bstride, a.q_ld = qsrc.data_ptr(), 0, D
+    else:
+        a.q, a.q_bstride, a.q_ld = qkv.data_ptr(), N * 3 * D, 3 * D
+    a.k, a.v, a.kv_bstride, a.kv_ld = qkv.data_ptr() + D * 2, vptr, N * 3 * D, 3 * D
+    a.o, a.o_bstride, a.o_ld, a.lse = o.data_ptr(), nq * D, D, lse.data_ptr()
+    a.qmask, a.keyinfo, a.ktile_flags = qmask.data_ptr(), keyinfo.data_ptr(), kflags.data_ptr()
+    a.q_ptr, a.q_kt, a.q_full, a.q_order = sf.q_ptr.data_ptr(), sf.q_kt.data_ptr(), sf.q_full.data_ptr(), sf.q_order.data_ptr()
+    a.vmean = vmean.data_ptr()
+    a.batch, a.heads, a.nq, a.nk, a.nk_pad, a.n_qtiles, a.n_ktiles, a.scale = b, heads, nq, N, nk_pad, sf.s.n_q, sf.s.n_k, 0.125
+    H.call("mca_attn_fwd", C.byref(a), H.stream_ptr())
+    torch.cuda.synchronize()
+    got_o = o.float().view(b, nq, D)
+    e = rel(got_o, ref_o)
+    assert e < 6e-3, f"attention forward rel err {e}"
+    # uniform rows are flagged
+    uni_ref = ((~allowed)[None] | pad[:, None, :]).all(-1)             # (b, nq)
+    assert torch.equal(torch.isinf(lse[:, 0]), uni_ref)
+    if drop_first and not pool:
+        assert uni_ref.any()
+
+    # ---- backward
+    d_o = bf(torch.randn(b, nq, D, device=dev, generator=g))
+    ref_o.backward(d_o.double())
+    delta = torch.empty(b, heads, nq, device=dev)
+    dvmean = torch.empty(b, D, device=dev)
+    H.call("mca_attn_bwd_prep", o.data_ptr(), d_o.data_ptr(), nq * D, D, lse.data_ptr(), delta.data_ptr(), dvmean.data_ptr(), b, heads,
+           nq, N, H.stream_ptr())
+    ref_delta = (d_o.float() * got_o).view(b, nq, heads, 64).sum(-1).permute(0, 2, 1)
+    assert rel(delta, ref_delta) < 1e-4
+    dq = torch.zeros(b, nq, D, device=dev)
+    dkv = torch.zeros(b, N, 3 * D, dtype=torch.bfloat16, device=dev)
+    ab = H.AttnBwdArgs()
+    ab.q, ab.q_bstride, ab.q_ld = a.q, a.q_bstride, a.q_ld
+    ab.k, ab.v, ab.kv_bstride, ab.kv_ld = a.k, a.v, a.kv_bstride, a.kv_ld
+    ab.d_o, ab.o_bstride, ab.o_ld = d_o.data_ptr(), nq * D, D
+    ab.lse, ab.delta, ab.dvmean = lse.data_ptr(), delta.data_ptr(), dvmean.data_ptr()
+    ab.dq, ab.dq_bstride, ab.dq_ld = dq.data_ptr(), nq * D, D
+    ab.dk, ab.dv, ab.dkv_bstride, ab.dkv_ld = dkv.data_ptr() + D * 2, dkv.data_ptr() + 2 * D * 2, N * 3 * D, 3 * D
+    ab.qmask, ab.keyinfo, ab.ktile_flags = qmask.data_ptr(), keyinfo.data_ptr(), kflags.data_ptr()
+    ab.k_ptr, ab.k_qt, ab.k_full, ab.k_order = sb.k_ptr.data_ptr(), sb.k_qt.data_ptr(), sb.k_full.data_ptr(), sb.k_order.data_ptr()
+    ab.batch, ab.heads, ab.nq, ab.nk, ab.nk_pad, ab.n_qtiles, ab.n_ktiles, ab.scale = b, heads, nq, N, nk_pad, sb.s.n_q, sb.s.n_k, 0.125
+    H.call("mca_attn_bwd", C.byref(ab), H.stream_ptr())
+    torch.cuda.synchronize()
+    rdq = q4r.grad.permute(0, 2, 1, 3).reshape(b, nq, D)
+    rdk = k4r.grad.permute(0, 2, 1, 3).reshape(b, N, D)
+    rdv = v4r.grad.permute(0, 2, 1, 3).reshape(b, N, D)
+    e_q, e_k, e_v = rel(dq, rdq), rel(dkv[:, :, D:2 * D].float(), rdk), rel(dkv[:, :, 2 * D:].float(), rdv)
+    assert e_q < 1.5e-2 and e_k < 1.5e-2 and e_v < 1.5e-2, f"attention backward rel err dq {e_q} dk {e_k} dv {e_v}"
+
+
+@pytest.mark.parametrize("variant,pool,drop", [("mca", False, False), ("mca", False, True), ("zorro", False, True),
+                                               ("mca", True, True), ("zorro", True, False)])
+def test_attention_small(H, variant, pool, drop):
+    S = importlib.import_module("mca-paper_amd.structure")
+    st = S.FusionStructure([70, 45, 30], 8, (3, 2), fcl=variant == "mca", zorro=variant == "zorro")
+    _attention_case(H, st, b=3, heads=2, pool=pool, seed=11, drop_first=drop)
+
+
+@pytest.mark.parametrize("variant,pool", [("mca", False), ("zorro", False), ("mca", True)])
+def test_attention_cmu_shape(H, variant, pool):
+    S = importlib.import_module("mca-paper_amd.structure")
+    st = S.FusionStructure([1500, 450, 450, 50], 88, (4, 3, 2), fcl=variant == "mca", zorro=variant == "zorro")
+    _attention_case(H, st, b=2, heads=2, pool=pool, seed=12, drop_first=True)
+
+
+# ------------------------------------------------------------------------------------------------ loss
+@pytest.mark.parametrize("variant,world", [("mca", 1), ("bimodal", 1), ("zorro", 1), ("mca", 2), ("bimodal", 4)])
+def test_contrastive_loss(H, variant, world):
+    from oracle import mca_oracle as O
+    from util_small import small_config
+    S = importlib.import_module("mca-paper_amd.structure")
+    cfg = small_config(variant)
+    OS = O.Structure(cfg)
+    st = S.FusionStructure([70, 45, 30], 8, (3, 2), fcl=cfg["fcl"], zorro=cfg["zorro"])
+    names = list(cfg["encoder_configs"].keys())
+    terms = S.loss_terms(names, st, cfg["bimodal_contrastive"], cfg["non_fusion_fcl"])
+    assert [t.name for t in terms] == [t[0] for t in O.loss_schedule(OS)]
+    b, R, D = 6, st.n_return, 128
+    B = b * world
+    g = torch.Generator().manual_seed(21)
+    pooled_all = torch.randn(B, R, D, generator=g) * 0.3
+    pooled_dev, = (pooled_all.cuda(),)
+    present = torch.randint(0, 8, (B,), generator=g)
+    present[present == 0] = 5
+    present[:b] &= 0b101                                   # rank 0 never sees modality 1 -> NaN terms there
+    logit = torch.tensor(math.log(1 / 0.07))
+    arr = (H.LossTerm * len(terms))()
+    for i, t in enumerate(terms):
+        arr[i] = H.LossTerm(t.slot_a, t.slot_b, t.and_bits, t.or_bits)
+    terms_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    ws = torch.empty(H.lib().mca_contrastive_workspace_bytes(B, len(terms)), dtype=torch.uint8, device="cuda")
+    total_ref_grad = torch.zeros(B, R, D, dtype=torch.float64)
+    pa = pooled_all.double().requires_grad_(True)
+    results = []
+    for r in range(world):
+        lg = logit.double().clone().requires_grad_(True)
+        sm = {n: ((present[r * b:(r + 1) * b] >> i) & 1).bool() for i, n in enumerate(names)}
+        out = O.pretraining_loss(OS, pa[r * b:(r + 1) * b], sm, lg, pooled_all=pa, rank=r)
+        gp, gl = torch.autograd.grad(out["loss"], [pa, lg])
+        total_ref_grad += gp
+        results.append((out, gl))
+    for r in range(world):
+        tl = torch.empty(len(terms), device="cuda"); ls = torch.empty(1, device="cuda")
+        dp = torch.empty(b, R, D, device="cuda"); dl = torch.empty(1, device="cuda")
+        present_dev, logit_dev = present.to(torch.int32).cuda(), logit.cuda()
+        H.call("mca_contrastive_fwd_bwd", pooled_dev.data_ptr(), present_dev.data_ptr(), terms_dev.data_ptr(),
+               len(terms), logit_dev.data_ptr(), B, b, r * b, R, D, tl.data_ptr(), ls.data_ptr(), dp.data_ptr(), dl.data_ptr(),
+               ws.data_ptr(), H.stream_ptr())
+        torch.cuda.synchronize()
+        out, gl = results[r]
+        ref_terms = torch.stack([out["losses"][t.name] for t in terms]).float()
+        assert torch.equal(torch.isnan(tl.cpu()), torch.isnan(ref_terms))
+        ok = ~torch.isnan(ref_terms)
+        assert rel(tl.cpu()[ok], ref_terms[ok]) < 1e-5
+        assert abs(float(ls) - float(out["loss"])) < 1e-5 * abs(float(out["loss"]))
+        assert rel(dp.cpu(), total_ref_grad[r * b:(r + 1) * b]) < 1e-4
+        assert abs(float(dl) - float(gl)) < 1e-4 * max(1.0, abs(float(gl)))
+    if variant == "mca" and world == 1:
+        assert torch.isnan(ref_terms).any()
+
+
+# --------------------------------------------------------------------------------------------- optimizer
+def test_clip_adamw(H):
+    g = torch.Generator().manual_seed(31)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([p_ref], lr=1e-3)
+    p = p0.cuda(); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * (3.0 if step == 1 else 0.001)
+        p_ref.grad = grad.clone()
+        gn = torch.nn.utils.clip_grad_norm_([p_ref], 2.0)
+        opt.step()
+        gd = grad.cuda()
+        sq = torch.zeros(1, device="cuda")
+        H.call("mca_grad_sqnorm", gd.data_ptr(), n, sq.data_ptr(), H.stream_ptr())
+        assert abs(float(sq.sqrt()) - float(gn)) < 1e-4 * float(gn)
+        H.call("mca_adamw_step", p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.01,
+               1 - 0.9 ** step, 1 - 0.999 ** step, 2.0, sq.data_ptr(), H.stream_ptr())
+        err = (p.cpu() - p_ref.detach()).abs().max()
+        assert err < 5e-6, f"step {step}: {err}"
