@@ -1,0 +1,153 @@
+"""bench.py — training samples/sec of the native MCA step (fwd + bwd + clip + AdamW) on synthetic CMU-shaped
+batches (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     : the dominant kernel of the step, timed live with HIP events on its launch stream; achieved =
+                 algorithmic flops per launch / average launch duration (DESIGN.md section "Measurement").
+  cpu_baseline : the oracle (CPU restatement of the reference, oracle/mca_oracle.py) timed on this host on a
+                 bounded sample of the same workload (N=1, rank 0 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic GFLOP per sample per step, mask-aware, 2 flop/MAC, bwd = 2 x fwd
+STEP_GFLOP = {"cmu_mca": 334.8, "cmu_mma": 337.4}
+
+
+def cpu_baseline(P, cfg, threads: int, b: int = 2):
+    from oracle import mca_oracle as O
+    torch.set_num_threads(threads)
+    S = O.Structure(cfg)
+    sd = P.params.init_state_dict(cfg, seed=43)
+    batch = P.data.synthetic_batch(cfg, b, seed=1234, lengths="uniform")
+    opt = None
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        _, _, _, opt = O.train_step(S, sd, batch, "fp32", lr=1e-4, clip=2.0, opt_state=opt)
+        times.append(time.perf_counter() - t0)
+    return {"value": round(b / times[-1], 4), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"CMU 4-modality MCA fp32 full step (fwd+bwd+clip+AdamW) at batch {b}, 1 timed step after 1 warm-up step "
+                      f"({times[-1]:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE config: 32 on 1 GPU)")
+    ap.add_argument("--variant", default="mca", choices=["mca", "mma"])
+    ap.add_argument("--lengths", default="full", choices=["full", "uniform"])
+    ap.add_argument("--p-drop", type=float, default=0.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    P = importlib.import_module("mca-paper_amd")
+    hip = importlib.import_module("mca-paper_amd.hip")
+    optim = importlib.import_module("mca-paper_amd.optim")
+    dpmod = importlib.import_module("mca-paper_amd.dp")
+    b = args.batch
+    cfg = P.config.cmu_model_config(batch_size=b, zorro=args.variant == "mma")
+    torch.manual_seed(43)
+    model = P.MCA(**cfg).to(dev)
+    model.engine.check_finite = False          # no host syncs inside the timed region (checked once after it)
+    opt = optim.FusedAdamW(model, lr=1e-4)
+    dp = dpmod.DataParallelMCA(model) if world > 1 else None
+    batch = P.data.synthetic_batch(cfg, b, seed=1234 + rank, p_drop=args.p_drop, lengths=args.lengths, device=dev)
+
+    def step():
+        out = model(batch)
+        opt.zero_grad()
+        out["loss"].backward()
+        if dp is not None:
+            dp.finish_backward()
+        optim.clip_grad_norm_(model, 2.0)
+        opt.step()
+        return out["loss"]
+
+    for _ in range(args.warmup):
+        step()
+    timed = ("mca_attn_fwd", "mca_attn_bwd", "mca_gemm_nt", "mca_gemm_tn_acc")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_kernel_timing:
+        hip.profile_start(timed)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = hip.profile_stop() if not args.no_kernel_timing else {}
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    assert bool(torch.isfinite(loss)), "non-finite loss in the timed region"
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = world * b * args.steps / dt
+        wl = f"cmu_{args.variant}"
+        line = {
+            "metric": "training samples/sec (fwd+bwd+opt), CMU 4-modality MCA", "value": round(value, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"synthetic CMU 4-modality ({'MCA fcl' if args.variant == 'mca' else 'MMA/zorro'}), N=2538 D=512 L=5 H=8 F=88, "
+                                   f"lengths={args.lengths}, p_drop={args.p_drop}", "per_gpu_batch": b, "global_batch": b * world,
+                       "parallelism": f"dp{world}"},
+            "step_tflops": round(value * STEP_GFLOP[wl] / 1e3, 1),
+            "step_frac_of_mfma_peak": round(value * STEP_GFLOP[wl] / 1e3 / (MFMA_BF16_PEAK_TFLOPS * world), 4),
+        }
+        if prof:
+            kern = {}
+            for key, (n, ms, fl) in prof.items():
+                kern[key] = {"launches_per_step": n / args.steps, "ms_per_step": round(ms / args.steps, 3),
+                             "avg_us": round(ms / n * 1e3, 1), "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None}
+            dom = max(prof.items(), key=lambda kv: kv[1][1])
+            n, ms, fl = dom[1]
+            ach = fl / (ms * 1e-3) / 1e12
+            line["roofline"] = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                                "avg_launch_us": round(ms / n * 1e3, 1), "alg_flops_per_launch": fl / n}
+            line["kernels"] = kern
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(16, os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(P, P.config.cmu_model_config(batch_size=2, zorro=args.variant == "mma"), threads)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

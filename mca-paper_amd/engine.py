@@ -258,12 +258,14 @@ class FusionEngine:
     def gemm_nt(A, B, C, M, N, K, bias=None, residual=None, res_period=0):
         """C[M,N] = A[M,K] B[N,K]^T (+bias) (+residual)."""
         call("mca_gemm_nt", ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), C.stride(0), int(C.dtype == torch.bfloat16),
-             ptr(bias), ptr(residual), residual.stride(0) if residual is not None else 0, res_period, M, N, K, stream_ptr())
+             ptr(bias), ptr(residual), residual.stride(0) if residual is not None else 0, res_period, M, N, K, stream_ptr(),
+             flops=2.0 * M * N * K)
 
     @staticmethod
     def gemm_tn_acc(A, B, Cgrad, R, N, K):
         """Cgrad[N,K] += A[R,N]^T B[R,K]"""
-        call("mca_gemm_tn_acc", ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(Cgrad), Cgrad.stride(0), R, N, K, stream_ptr())
+        call("mca_gemm_tn_acc", ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(Cgrad), Cgrad.stride(0), R, N, K, stream_ptr(),
+             flops=2.0 * R * N * K)
 
     @staticmethod
     def ln_fwd(x, gamma, rows, cols, mean, rstd, beta=None, rowmask=None, add=None, period=0, y=None, ldy=0, y_bstride=0,
@@ -295,7 +297,9 @@ class FusionEngine:
         a.batch, a.heads, a.nq, a.nk, a.nk_pad = b, self.H, nq, N, self.nk_pad
         a.n_qtiles, a.n_ktiles, a.scale = sched.s.n_q, sched.s.n_k, self.scale
         call("mca_attn_vmean", a.v, a.kv_bstride, a.kv_ld, ws["vmean"].data_ptr(), b, N, self.H, stream_ptr())
-        call("mca_attn_fwd", C.byref(a), stream_ptr())
+        hip.set_tag("pool" if nq != N else "layer")
+        call("mca_attn_fwd", C.byref(a), stream_ptr(), flops=4.0 * 64 * sched.s.allowed_pairs * self.H * b)
+        hip.set_tag("")
 
     def _attn_bwd(self, q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, d_o, lse, delta, dq, dq_bstride, dkv, dk_off,
                   dv_off, dkv_ld, qmask, sched, ws, b, nq):
@@ -317,7 +321,9 @@ class FusionEngine:
                                                 sched.k_order.data_ptr())
         a.batch, a.heads, a.nq, a.nk, a.nk_pad = b, self.H, nq, N, self.nk_pad
         a.n_qtiles, a.n_ktiles, a.scale = sched.s.n_q, sched.s.n_k, self.scale
-        call("mca_attn_bwd", C.byref(a), stream_ptr())
+        hip.set_tag("pool" if nq != N else "layer")
+        call("mca_attn_bwd", C.byref(a), stream_ptr(), flops=8.0 * 64 * sched.s.allowed_pairs * self.H * b)
+        hip.set_tag("")
 
     # ------------------------------------------------------------------------------------------------
     # forward

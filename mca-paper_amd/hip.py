@@ -115,5 +115,39 @@ def check(rc: int, what: str):
         raise MCAHipError(f"{what} failed: {_ERR.get(rc, rc)}")
 
 
-def call(name: str, *args):
+# ---- optional live kernel timing (bench.py): HIP events recorded on the launch stream around selected entry points
+PROFILE = None          # None or {"names": set, "records": {key: [(start, end, flops)]}}
+_TAG = ""
+
+
+def set_tag(tag: str):
+    global _TAG
+    _TAG = tag
+
+
+def profile_start(names):
+    global PROFILE
+    PROFILE = {"names": set(names), "records": {}}
+
+
+def profile_stop():
+    """-> {key: (launches, total_ms, total_flops)} (synchronises)."""
+    global PROFILE
+    prof, PROFILE = PROFILE, None
+    torch.cuda.synchronize()
+    out = {}
+    for key, recs in prof["records"].items():
+        ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+        out[key] = (len(recs), ms, sum(f for _, _, f in recs))
+    return out
+
+
+def call(name: str, *args, flops: float = 0.0):
+    if PROFILE is not None and name in PROFILE["names"]:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        check(getattr(lib(), name)(*args), name)
+        e.record()
+        PROFILE["records"].setdefault(name + ("/" + _TAG if _TAG else ""), []).append((s, e, flops))
+        return
     check(getattr(lib(), name)(*args), name)

@@ -52,7 +52,10 @@ def run_native_step(pkg, cfg, sd, batch, lr=1e-3, clip=2.0, steps=1, device="cud
     torch.cuda.synchronize()
     slots = model.output_slots()
     R = model.max_return_tokens
-    pooled = torch.stack([first[k] for k, _ in sorted(((k, s) for k, s in slots.items() if k != "fusion"), key=lambda t: t[1])], 1)
+    by_slot = {}
+    for k, sl in slots.items():
+        by_slot.setdefault(sl, k)
+    pooled = torch.stack([first[by_slot[sl]] for sl in sorted(by_slot)], 1)
     return dict(pooled=pooled.detach().cpu(), loss=float(first["loss"]),
                 losses={k: float(v) for k, v in first["losses"].items()}, grads=grads, grad_norm=gn0,
                 state={n: p.detach().clone().cpu() for n, p in model.named_parameters()}, model=model)
@@ -68,8 +71,8 @@ def run_oracle_step(O, cfg, sd, batch, mode="fp32", lr=1e-3, clip=2.0, steps=1):
         if s == 0:
             first, g0, gn0 = out, grads, float(gn)
     names = S.modalities
-    keys = list(names) + (list(S.combos) if S.do_fcl else [])
-    pooled = first["pooled"][:, :len(keys)] if S.do_fcl else first["pooled"][:, :len(names)]
+    nslots = len(names) + (len(S.combos) if S.do_fcl else (0 if S.no_fusion else 1))
+    pooled = first["pooled"][:, :nslots]
     return dict(pooled=pooled.detach(), pooled_full=first["pooled"].detach(), loss=float(first["loss"]),
                 losses={k: float(v) for k, v in first["losses"].items()}, grads=g0, grad_norm=gn0,
                 state={k: v.detach().clone() for k, v in sd.items() if O.is_param(k)})
