@@ -30,6 +30,8 @@ typedef void* mca_stream_t;
 
 /* version / build info: returns a static string */
 const char* mca_version(void);
+/* tuning knobs for A/B measurements (key 1: GEMM register prefetch depth 1|2); returns 0 */
+int mca_debug_set(int key, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM  (all Linear layers: encoders.py:190, model.py:49-51,69-71; their autograd backward)

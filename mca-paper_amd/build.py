@@ -11,6 +11,9 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmca_hip.so")
 SOURCES = ["elementwise.hip", "gemm.hip", "attention_fwd.hip", "attention_bwd.hip", "loss.hip", "optim.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
+# per-file extras: keep the attention accumulators in VGPRs (the softmax VALU works on them in place; the default
+# AGPR form costs 256 v_accvgpr moves per key tile)
+EXTRA = {"attention_fwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def needs_build() -> bool:
@@ -31,7 +34,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for src, p in procs:
         out, _ = p.communicate()

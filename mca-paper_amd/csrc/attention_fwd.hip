@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a) {
     mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
     const float m_new = fmaxf(m_run, mx * c2);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f(m_run - m_use);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
     float rs = 0.f;
     bf16x8 pb[2][2];
 #pragma unroll
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a) {
       for (int sp = 0; sp < 2; sp++)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          const float p = exp2f(fmaf(s[kb][8 * sp + j], c2, -m_use));
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][8 * sp + j], c2, -m_use));
           rs += p;
           pb[kb][sp][j] = (short)f2bf(p);
         }
@@ -257,24 +257,40 @@ extern "C" int mca_build_keyinfo(const uint8_t* padding, const uint8_t* kgroup, 
   return launch_status();
 }
 
-// vmean[b, c] = (1/nk) sum_j V[b, j, c]   c in [0, heads*64).  grid (cols/64, b): 256 threads = 64 columns
-// x 4 key slices, reduced through LDS.
+// vmean[b, c] = (1/nk) sum_j V[b, j, c]   c in [0, heads*64).  grid (key slabs, b): each wavefront sums whole
+// 16-byte pieces of rows (8 columns per lane), partial sums go out as one atomic per column per workgroup.
 __global__ __launch_bounds__(256) void vmean_kernel(const u16* __restrict__ V, int64_t bstride, int64_t ld,
-                                                     float* __restrict__ vmean, int nk, int cols) {
-  __shared__ float red[4][64];
-  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
-  float acc = 0.f;
-  if (c < cols)
-    for (int j = sl; j < nk; j += 4) acc += bf2f(V[(int64_t)b * bstride + (int64_t)j * ld + c]);
-  red[sl][threadIdx.x & 63] = acc;
-  __syncthreads();
-  if (sl == 0 && c < cols) vmean[(int64_t)b * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)nk;
+                                                     float* __restrict__ vmean, int nk, int cols, int keys_per_block) {
+  __shared__ float red[4][512];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k0 = blockIdx.x * keys_per_block;
+  int k1 = k0 + keys_per_block; if (k1 > nk) k1 = nk;
+  const float inv = 1.f / (float)nk;
+  for (int c0 = 0; c0 < cols; c0 += 512) {
+    const int c = c0 + lane * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < cols)
+      for (int j = k0 + wave; j < k1; j += 4) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(V + (int64_t)b * bstride + (int64_t)j * ld + c);
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] += bf2f((u16)v[e]);
+      }
+#pragma unroll
+    for (int e = 0; e < 8; e++) red[wave][lane * 8 + e] = acc[e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512 && c0 + i < cols; i += 256)
+      atomicAdd(vmean + (int64_t)b * cols + c0 + i, (red[0][i] + red[1][i] + red[2][i] + red[3][i]) * inv);
+    __syncthreads();
+  }
 }
 extern "C" int mca_attn_vmean(const uint16_t* V, int64_t kv_bstride, int64_t kv_ld, float* vmean, int batch, int nk,
                               int heads, mca_stream_t stream) {
   if (!V || !vmean || batch <= 0 || nk <= 0 || heads <= 0) return MCA_E_BADARG;
   const int cols = heads * DH;
-  hipLaunchKernelGGL(vmean_kernel, dim3((cols + 63) / 64, batch), dim3(256), 0, as_stream(stream), V, kv_bstride, kv_ld,
-                     vmean, nk, cols);
+  if (kv_ld % 8 || kv_bstride % 8 || (uintptr_t)V % 16) return MCA_E_ALIGN;
+  if (hipMemsetAsync(vmean, 0, (size_t)batch * cols * sizeof(float), as_stream(stream)) != hipSuccess) return MCA_E_LAUNCH;
+  const int kpb = 64;
+  hipLaunchKernelGGL(vmean_kernel, dim3((nk + kpb - 1) / kpb, batch), dim3(256), 0, as_stream(stream), V, kv_bstride, kv_ld,
+                     vmean, nk, cols, kpb);
   return launch_status();
 }

@@ -8,10 +8,12 @@
 //                                                     gfx950 transposed read ds_read_b64_tr_b16
 //
 // Tile 128x128x64, 256 threads = 4 wavefronts (2x2), each wavefront a 64x64 sub-tile as 2x2
-// v_mfma_f32_32x32x16_bf16 accumulators.  Operand tiles are staged global -> registers -> LDS
-// (issue-early / write-late, double-buffered LDS) with an XOR swizzle that makes the 16-byte fragment
-// reads bank-conflict free (cdna guide §5.5 T2/T14).  Workgroup ids are remapped so that the blocks that
-// share an XCD (ids congruent mod 8) walk neighbouring tiles and reuse the A panel from that XCD's L2.
+// v_mfma_f32_32x32x16_bf16 accumulators.  NT: operand tiles go global -> LDS directly
+// (global_load_lds_dwordx4, double-buffered) with the XOR swizzle on the source address and on the fragment
+// reads (16-byte reads bank-conflict free); the C tile leaves through LDS as whole 16-byte row pieces with
+// bias / residual fused.  TN: register-staged tiles, transposed LDS reads, fp32 atomics.  Workgroup ids are
+// remapped so that the blocks sharing an XCD (ids congruent mod 8) walk neighbouring tiles and reuse the
+// A panel from that XCD's L2.
 #include "common.h"
 
 #define BM 128
@@ -30,15 +32,99 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // all 64 banks exactly once.
 __device__ __forceinline__ int nt_off(int r, int c) { return r * 64 + ((c ^ ((r >> 1) & 7)) << 3); }
 
-template <bool OUT_BF16>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(
+// Epilogue through LDS (BK = 64 kernels: the 64 KiB of operand buffers hold exactly one 128x128 fp32 tile).  The
+// accumulators are written lane = column / register = row, then every thread reads whole 16-byte pieces of rows,
+// adds bias / residual with 16-byte loads and stores 16 bytes: 4x (fp32) or 8x (bf16) fewer store instructions,
+// every global access a full 128-byte-line segment of a row.
+template <bool OUT_BF16, int RES>
+__device__ __forceinline__ void nt_epilogue_lds(f32x16 (&acc)[2][2], float* __restrict__ cs, void* __restrict__ Cv, int64_t ldc,
+                                                const float* __restrict__ bias, const float* __restrict__ residual,
+                                                int64_t ldres, int64_t res_period, int M, int N, int m0, int n0, int wm, int wn,
+                                                int l31, int lh, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        cs[row * 128 + wn * 64 + j * 32 + l31] = acc[i][j][r];
+      }
+  __syncthreads();
+  constexpr int EPT = OUT_BF16 ? 8 : 4;          // elements per thread per piece
+  constexpr int PPR = 128 / EPT;                 // pieces per row
+#pragma unroll 4
+  for (int it = 0; it < (128 * PPR) / 256; it++) {
+    const int id = tid + 256 * it;
+    const int row = id / PPR, c0 = (id % PPR) * EPT;
+    const int m = m0 + row, n = n0 + c0;
+    if (m >= M || n >= N) continue;
+    float v[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e += 4) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(cs + row * 128 + c0 + e);
+      v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
+    }
+    const bool full = n + EPT <= N;
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < EPT; e++) if (full || n + e < N) v[e] += bias[n + e];
+    }
+    if (RES != 0) {
+      const int64_t rr = RES == 2 ? (int64_t)(m % (int)res_period) : (int64_t)m;
+      const float* rp = residual + rr * ldres + n;
+      if (full && (((uintptr_t)rp) & 15) == 0) {
+#pragma unroll
+        for (int e = 0; e < EPT; e += 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(rp + e);
+          v[e] += t[0]; v[e + 1] += t[1]; v[e + 2] += t[2]; v[e + 3] += t[3];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPT; e++) if (n + e < N) v[e] += rp[e];
+      }
+    }
+    if (OUT_BF16) {
+      u16* cp = reinterpret_cast<u16*>(Cv) + (int64_t)m * ldc + n;
+      if (full && (((uintptr_t)cp) & 15) == 0) {
+        uint4 pk;
+        pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4 % EPT], v[5 % EPT]); pk.w = pack2bf(v[6 % EPT], v[7 % EPT]);
+        *reinterpret_cast<uint4*>(cp) = pk;
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPT; e++) if (n + e < N) cp[e] = f2bf(v[e]);
+      }
+    } else {
+      float* cp = reinterpret_cast<float*>(Cv) + (int64_t)m * ldc + n;
+      if (full && (((uintptr_t)cp) & 15) == 0) {
+        *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPT; e++) if (n + e < N) cp[e] = v[e];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// NT kernel with direct global->LDS staging (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.
+// The LDS destination of one wave-instruction is linear (wave base + lane*16 B), so the XOR swizzle is applied
+// to the per-lane SOURCE address and again on the fragment reads (cdna guide, rule 21).
+// ---------------------------------------------------------------------------------------------------------
+template <int BKT> __device__ __forceinline__ int gl_sw(int r) { return BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
+template <int BKT> __device__ __forceinline__ int gl_off(int r, int c) { return r * BKT + ((c ^ gl_sw<BKT>(r)) << 3); }
+
+template <bool OUT_BF16, int RES, int BKT>
+__global__ __launch_bounds__(256) void gemm_nt_glds_kernel(
     const u16* __restrict__ A, int64_t lda, const u16* __restrict__ B, int64_t ldb, void* __restrict__ Cv,
     int64_t ldc, const float* __restrict__ bias, const float* __restrict__ residual, int64_t ldres,
     int64_t res_period, int M, int N, int K, int tiles_n, int nwg) {
-  __shared__ __attribute__((aligned(16))) u16 lds[2 * (BM + BN) * BK];   // 64 KiB
+  constexpr int CH = BKT / 8;                 // 16-byte chunks per tile row
+  constexpr int TILE = 128 * BKT;             // elements per operand tile
+  constexpr int NI = CH / 2;                  // wave-instructions per operand tile per wave
+  __shared__ __attribute__((aligned(16))) u16 lds[4 * TILE];
   u16* As = lds;
-  u16* Bs = lds + 2 * BM * BK;
-
+  u16* Bs = lds + 2 * TILE;
   const int tile = xcd_remap(blockIdx.x, nwg);
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -46,35 +132,29 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  // staging assignment: 1024 16-byte chunks per operand tile, 4 per thread
-  const u16* ga[4];
-  const u16* gb[4];
-  int soff[4];
+  const u16* ga[NI];
+  const u16* gb[NI];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int id = tid + 256 * i, r = id >> 3, c = id & 7;
+  for (int i = 0; i < NI; i++) {
+    const int p = (i * 4 + wave) * 64 + lane;           // linear chunk position inside the tile image
+    const int r = p / CH, cp = p % CH;
+    const int c = cp ^ gl_sw<BKT>(r);                   // logical chunk stored at this position
     int ra = m0 + r; if (ra > M - 1) ra = M - 1;
     int rb = n0 + r; if (rb > N - 1) rb = N - 1;
     ga[i] = A + (int64_t)ra * lda + c * 8;
     gb[i] = B + (int64_t)rb * ldb + c * 8;
-    soff[i] = nt_off(r, c);
   }
-  bf16x8 ra_[4], rb_[4];
-  auto gload = [&](int k0) {
+  auto stage = [&](int k0, int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      ra_[i] = *reinterpret_cast<const bf16x8*>(ga[i] + k0);
-      rb_[i] = *reinterpret_cast<const bf16x8*>(gb[i] + k0);
+    for (int i = 0; i < NI; i++) {
+      u16* da = As + buf * TILE + (i * 4 + wave) * 512;
+      u16* db = Bs + buf * TILE + (i * 4 + wave) * 512;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + k0),
+                                       (__attribute__((address_space(3))) void*)da, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + k0),
+                                       (__attribute__((address_space(3))) void*)db, 16, 0, 0);
     }
   };
-  auto swrite = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      *reinterpret_cast<bf16x8*>(As + buf * BM * BK + soff[i]) = ra_[i];
-      *reinterpret_cast<bf16x8*>(Bs + buf * BN * BK + soff[i]) = rb_[i];
-    }
-  };
-
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -83,22 +163,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  const int nkt = K / BK;
-  gload(0);
-  swrite(0);
+  const int nkt = K / BKT;
+  stage(0, 0);
   __syncthreads();
   for (int kt = 0; kt < nkt; kt++) {
     const int cur = kt & 1;
-    if (kt + 1 < nkt) gload((kt + 1) * BK);
-    const u16* as = As + cur * BM * BK;
-    const u16* bs = Bs + cur * BN * BK;
+    if (kt + 1 < nkt) stage((kt + 1) * BKT, cur ^ 1);
+    const u16* as = As + cur * TILE;
+    const u16* bs = Bs + cur * TILE;
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
+    for (int ks = 0; ks < BKT / 16; ks++) {
       bf16x8 af[2], bfr[2];
 #pragma unroll
       for (int i = 0; i < 2; i++) {
-        af[i] = *reinterpret_cast<const bf16x8*>(as + nt_off(wm * 64 + i * 32 + l31, 2 * ks + lh));
-        bfr[i] = *reinterpret_cast<const bf16x8*>(bs + nt_off(wn * 64 + i * 32 + l31, 2 * ks + lh));
+        af[i] = *reinterpret_cast<const bf16x8*>(as + gl_off<BKT>(wm * 64 + i * 32 + l31, 2 * ks + lh));
+        bfr[i] = *reinterpret_cast<const bf16x8*>(bs + gl_off<BKT>(wn * 64 + i * 32 + l31, 2 * ks + lh));
       }
 #pragma unroll
       for (int i = 0; i < 2; i++)
@@ -106,50 +185,32 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
         for (int j = 0; j < 2; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nkt) swrite(cur ^ 1);
-    __syncthreads();
+    __syncthreads();          // waits for this wave's LDS-DMA (vmcnt(0)) and for every wave's reads of `cur`
   }
-
-  // epilogue: C row = m (registers), col = n (lane): 32 consecutive columns per row per instruction
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int n = n0 + wn * 64 + j * 32 + l31;
-    const bool nok = n < N;
-    const float bv = (bias && nok) ? bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (nok && m < M) {
-          float v = acc[i][j][r] + bv;
-          if (residual) {
-            const int64_t rr = res_period > 0 ? (int64_t)m % res_period : (int64_t)m;
-            v += residual[rr * ldres + n];
-          }
-          if (OUT_BF16) reinterpret_cast<u16*>(Cv)[(int64_t)m * ldc + n] = f2bf(v);
-          else reinterpret_cast<float*>(Cv)[(int64_t)m * ldc + n] = v;
-        }
-      }
-    }
-  }
+  static_assert(BKT == 64, "the LDS epilogue needs the 64 KiB of operand buffers");
+  nt_epilogue_lds<OUT_BF16, RES>(acc, reinterpret_cast<float*>(lds), Cv, ldc, bias, residual, ldres, res_period, M, N, m0, n0,
+                                 wm, wn, l31, lh, tid);
 }
+
+static int g_knob[8];
+extern "C" int mca_debug_set(int key, int value) { if (key >= 0 && key < 8) g_knob[key] = value; return 0; }
 
 extern "C" int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
                            int out_bf16, const float* bias, const float* residual, int64_t ldres,
                            int64_t res_period, int64_t M, int64_t N, int64_t K, mca_stream_t stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MCA_E_BADARG;
-  if (K % BK || lda % 8 || ldb % 8 || (uintptr_t)A % 16 || (uintptr_t)B % 16) return MCA_E_ALIGN;
+  if (K % 64 || lda % 8 || ldb % 8 || (uintptr_t)A % 16 || (uintptr_t)B % 16) return MCA_E_ALIGN;
   if (lda < K || ldb < K || ldc < N) return MCA_E_BADARG;
   if (M > (1LL << 30) || N > (1LL << 30)) return MCA_E_UNSUPPORTED;
   const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
   const int nwg = tiles_m * tiles_n;
-  if (out_bf16)
-    hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3(nwg), dim3(256), 0, as_stream(stream), A, lda, B, ldb, C, ldc, bias,
-                       residual, ldres, res_period, (int)M, (int)N, (int)K, tiles_n, nwg);
-  else
-    hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3(nwg), dim3(256), 0, as_stream(stream), A, lda, B, ldb, C, ldc, bias,
-                       residual, ldres, res_period, (int)M, (int)N, (int)K, tiles_n, nwg);
+  const int res = !residual ? 0 : (res_period > 0 ? 2 : 1);
+#define NT_LAUNCH_G(OB, RS)                                                                                              \
+  hipLaunchKernelGGL((gemm_nt_glds_kernel<OB, RS, 64>), dim3(nwg), dim3(256), 0, as_stream(stream), A, lda, B, ldb, C,   \
+                     ldc, bias, residual, ldres, res_period, (int)M, (int)N, (int)K, tiles_n, nwg)
+#define NT_PICK_PF(OB, RS) NT_LAUNCH_G(OB, RS)
+  if (out_bf16) { if (res == 0) NT_PICK_PF(true, 0); else if (res == 1) NT_PICK_PF(true, 1); else NT_PICK_PF(true, 2); }
+  else { if (res == 0) NT_PICK_PF(false, 0); else if (res == 1) NT_PICK_PF(false, 1); else NT_PICK_PF(false, 2); }
   return launch_status();
 }
 
