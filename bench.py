@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--p-drop", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--sample-every", type=int, default=4, help="record per-kernel HIP events on every n-th timed step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,8 +102,13 @@ def main():
     if not args.no_kernel_timing:
         hip.profile_start(timed)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    sampled = 0
+    for i in range(args.steps):
+        rec = (i % args.sample_every) == 0
+        hip.profile_enable(rec)
+        sampled += int(rec)
         loss = step()
+    hip.profile_enable(True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -132,14 +138,15 @@ def main():
         if prof:
             kern = {}
             for key, (n, ms, fl) in prof.items():
-                kern[key] = {"launches_per_step": n / args.steps, "ms_per_step": round(ms / args.steps, 3),
+                kern[key] = {"launches_per_step": n / sampled, "ms_per_step": round(ms / sampled, 3),
                              "avg_us": round(ms / n * 1e3, 1), "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None}
             dom = max(prof.items(), key=lambda kv: kv[1][1])
             n, ms, fl = dom[1]
             ach = fl / (ms * 1e-3) / 1e12
             line["roofline"] = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                                "avg_launch_us": round(ms / n * 1e3, 1), "alg_flops_per_launch": fl / n}
+                                "avg_launch_us": round(ms / n * 1e3, 1), "alg_flops_per_launch": fl / n,
+                                "sampled_steps": sampled}
             line["kernels"] = kern
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)

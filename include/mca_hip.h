@@ -102,6 +102,18 @@ int mca_reduce_rows(const float* src, int64_t lds, int64_t src_bstride, int64_t 
                     float* dst, int64_t ldd, int64_t rows, int cols, mca_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * TabularEncoder (encoders.py:17-96): nn.Embedding(max_norm=1) in-place row renormalisation;
+ * ContinuousValueEncoder front end Linear(1,D)+ReLU on min(x, max_value), and its backward.
+ * --------------------------------------------------------------------------------------------- */
+int mca_embedding_renorm(float* weight, int64_t rows, int cols, float max_norm, mca_stream_t stream);
+/* h1[r, :] = relu(min(x[r], max_value) * w1 + b1) as bf16 (rows x cols); padmask[r] = (x[r] == padding_value) */
+int mca_tab_value_fwd(const float* x, const float* w1, const float* b1, uint16_t* h1, uint8_t* padmask,
+                      int64_t rows, int cols, float max_value, float padding_value, mca_stream_t stream);
+/* dw1 += sum_r dh1*[h1>0]*min(x,max_value);  db1 += sum_r dh1*[h1>0]   (dh1 fp32, ld in elements)            */
+int mca_tab_value_bwd(const float* dh1, int64_t ld, const uint16_t* h1, const float* x, float* dw1, float* db1,
+                      int64_t rows, int cols, float max_value, mca_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Block-masked fused attention (model.py:73-105 as used by MCALayer :119 and attn_pool :472-473)
  * --------------------------------------------------------------------------------------------- */
 /* keyinfo[b, nk_pad] = padded ? 31 : kgroup[j]; entries >= nk are 31.

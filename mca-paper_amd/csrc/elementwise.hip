@@ -394,3 +394,83 @@ extern "C" int mca_reduce_rows(const float* src, int64_t lds, int64_t src_bstrid
                      as_stream(stream), src, lds, src_bstride, period, dst, ldd, rows, cols, gpb);
   return launch_status();
 }
+
+// =====================================================================================================
+// TabularEncoder pieces (encoders.py:17-96)
+// =====================================================================================================
+// nn.Embedding(max_norm): rows with L2 norm > max_norm are rescaled IN PLACE by max_norm / (norm + 1e-7)
+__global__ __launch_bounds__(256) void embedding_renorm_kernel(float* __restrict__ w, int64_t rows, int cols, float max_norm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+    float* wr = w + r * cols;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += wr[c] * wr[c];
+    const float nrm = sqrtf(wave_sum(s));
+    if (nrm > max_norm) {
+      const float sc = max_norm / (nrm + 1e-7f);
+      for (int c = lane; c < cols; c += 64) wr[c] *= sc;
+    }
+  }
+}
+extern "C" int mca_embedding_renorm(float* weight, int64_t rows, int cols, float max_norm, mca_stream_t stream) {
+  if (!weight || rows <= 0 || cols <= 0) return MCA_E_BADARG;
+  int64_t blocks = (rows + 3) / 4; if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(embedding_renorm_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), weight, rows, cols, max_norm);
+  return launch_status();
+}
+
+// h1[r][d] = relu(min(x[r], max_value) * w1[d] + b1[d])  (Linear(1, D) + ReLU), bf16 out; padmask[r] = (x[r] == padding_value)
+__global__ __launch_bounds__(256) void tab_value_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                             const float* __restrict__ b1, u16* __restrict__ h1,
+                                                             uint8_t* __restrict__ padmask, int64_t rows, int cols,
+                                                             float max_value, float padding_value) {
+  const int chunks = cols / 8;
+  const int64_t total = rows * chunks;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / chunks;
+    const int c = (int)(idx % chunks) * 8;
+    const float xv = x[r];
+    const float xc = fminf(xv, max_value);
+    if (c == 0) padmask[r] = xv == padding_value ? 1 : 0;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = (short)f2bf(fmaxf(xc * w1[c + j] + b1[c + j], 0.f));
+    *reinterpret_cast<bf16x8*>(h1 + r * cols + c) = o;
+  }
+}
+extern "C" int mca_tab_value_fwd(const float* x, const float* w1, const float* b1, uint16_t* h1, uint8_t* padmask, int64_t rows,
+                                 int cols, float max_value, float padding_value, mca_stream_t stream) {
+  if (!x || !w1 || !b1 || !h1 || !padmask || rows <= 0 || cols <= 0 || cols % 8) return MCA_E_BADARG;
+  hipLaunchKernelGGL(tab_value_fwd_kernel, dim3(stream_grid(rows * (cols / 8))), dim3(256), 0, as_stream(stream), x, w1, b1, h1,
+                     padmask, rows, cols, max_value, padding_value);
+  return launch_status();
+}
+
+// dw1[d] += sum_r dh1[r][d] * [h1[r][d] > 0] * min(x[r], max_value);  db1[d] += sum_r dh1[r][d] * [h1 > 0]
+__global__ __launch_bounds__(256) void tab_value_bwd_kernel(const float* __restrict__ dh1, int64_t ld, const u16* __restrict__ h1,
+                                                             const float* __restrict__ x, float* __restrict__ dw1,
+                                                             float* __restrict__ db1, int64_t rows, int cols, float max_value,
+                                                             int64_t rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  int64_t r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
+  if (c >= cols) return;
+  float aw = 0.f, ab = 0.f;
+  for (int64_t r = r0; r < r1; r++) {
+    const float g = bf2f(h1[r * cols + c]) > 0.f ? dh1[r * ld + c] : 0.f;
+    aw += g * fminf(x[r], max_value);
+    ab += g;
+  }
+  atomicAdd(dw1 + c, aw);
+  atomicAdd(db1 + c, ab);
+}
+extern "C" int mca_tab_value_bwd(const float* dh1, int64_t ld, const uint16_t* h1, const float* x, float* dw1, float* db1,
+                                 int64_t rows, int cols, float max_value, mca_stream_t stream) {
+  if (!dh1 || !h1 || !x || !dw1 || !db1 || rows <= 0 || cols <= 0) return MCA_E_BADARG;
+  int64_t slabs = rows < 512 ? rows : 512;
+  const int64_t rpb = (rows + slabs - 1) / slabs;
+  slabs = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(tab_value_bwd_kernel, dim3((cols + 255) / 256, (unsigned)slabs), dim3(256), 0, as_stream(stream), dh1, ld, h1, x,
+                     dw1, db1, rows, cols, max_value, rpb);
+  return launch_status();
+}

@@ -378,7 +378,28 @@ class FusionEngine:
         return sample_mask
 
     def _encode_tabular(self, name, enc, bm, ws, mi):
-        raise NotImplementedError("TabularEncoder native path: see engine_tabular (round 1 covers EmbeddedSequenceEncoder)")
+        """encoders.py:90-96: E[t] (max_norm-renormalised in place) + LN(Linear2(ReLU(Linear1(min(x, max)))))), the value
+        part zeroed where x == padding_idx (-1).  The trunk's key-padding mask is the collator's attention_mask."""
+        D, N, b = self.D, self.N, ws["b"]
+        n, off = self.st.token_dims[mi], self.offsets[mi]
+        rows = b * n
+        e, ve = ws["enc"][name], enc.value_encoder
+        vals = bm["values"]
+        if vals.dtype != torch.float32 or not vals.is_contiguous():
+            vals = vals.float().contiguous()
+        if vals.shape != (b, n):
+            raise AssertionError(f"{vals.shape[1]} - {n}")                  # encoders.py:93
+        e["values"] = vals
+        amask = bm["attention_mask"]
+        ws["padding"].view(b, N)[:, off:off + n].copy_(amask.to(torch.bool))
+        emb = enc.token_encoder.embedding.weight
+        call("mca_embedding_renorm", ptr(emb.data), n, D, float(enc.token_encoder.max_norm), stream_ptr())
+        call("mca_tab_value_fwd", ptr(vals), ptr(ve.linear1.weight.data), ptr(ve.linear1.bias.data), ptr(e["h1_b"]), ptr(e["mask"]),
+             rows, D, float(ve.max_value), float(ve.padding_value), stream_ptr())
+        self.gemm_nt(e["h1_b"], self.we[name]["w2"], e["y"], rows, D, D, bias=ve.linear2.bias)
+        self.ln_fwd(e["y"], ve.norm.weight, rows, D, e["m2"], e["r2"], beta=ve.norm.bias, rowmask=e["mask"], add=emb.data,
+                    period=n, y=ws["x"][0][off:], ldy=D, y_bstride=N * D)
+        return (amask == 0).sum(dim=1) != 0
 
     def forward_trunk(self, ws):
         """fusion layers + final norm + attentive pooling -> ws['pooled'] (b*R, D)."""
@@ -521,7 +542,21 @@ class FusionEngine:
         self._bucket_ready(len(self.bucket_bounds) - 1)
 
     def _backward_tabular(self, name, enc, ws, mi, dx):
-        raise NotImplementedError
+        D, N, b = self.D, self.N, ws["b"]
+        n, off = self.st.token_dims[mi], self.offsets[mi]
+        rows = b * n
+        e, ve, G = ws["enc"][name], enc.value_encoder, self.grad_of
+        gemb = G(enc.token_encoder.embedding.weight)
+        # the table is added after the value path is masked: every row of dx reaches it; padding_idx row stays frozen
+        call("mca_reduce_rows", dx.data_ptr() + off * D * 4, D, N * D, n, ptr(gemb), D, rows, D, stream_ptr())
+        gemb[n - 1].zero_()
+        self.ln_bwd(dx[off:], D, e["y"], ve.norm.weight, e["m2"], e["r2"], rows, D, G(ve.norm.weight), dbeta=G(ve.norm.bias),
+                    rowmask=e["mask"], dx=e["dy"], dx_bf16=e["dy_b"], y_bstride=N * D, period=n)
+        call("mca_reduce_rows", ptr(e["dy"]), D, D, 1, ptr(G(ve.linear2.bias)), D, rows, D, stream_ptr())
+        self.gemm_tn_acc(e["dy_b"], e["h1_b"], G(ve.linear2.weight), rows, D, D)
+        self.gemm_nt(e["dy_b"], self.we[name]["w2T"], e["dh1"], rows, D, D)
+        call("mca_tab_value_bwd", ptr(e["dh1"]), D, ptr(e["h1_b"]), ptr(e["values"]), ptr(G(ve.linear1.weight)),
+             ptr(G(ve.linear1.bias)), rows, D, float(ve.max_value), stream_ptr())
 
     # ------------------------------------------------------------------------------------------------
     # model-level forward (autograd node)

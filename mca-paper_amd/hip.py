@@ -70,6 +70,9 @@ SIGNATURES = {
     "mca_f32_to_bf16": (_I, [_P, _I64, _P, _I64, _I64, _I64, _F, _P]),
     "mca_bcast_rows": (_I, [_P, _I64, _P, _I64, _I64, _I64, _I64, _I, _P]),
     "mca_reduce_rows": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I, _P]),
+    "mca_embedding_renorm": (_I, [_P, _I64, _I, _F, _P]),
+    "mca_tab_value_fwd": (_I, [_P, _P, _P, _P, _P, _I64, _I, _F, _F, _P]),
+    "mca_tab_value_bwd": (_I, [_P, _I64, _P, _P, _P, _P, _I64, _I, _F, _P]),
     "mca_build_keyinfo": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "mca_attn_vmean": (_I, [_P, _I64, _I64, _P, _I, _I, _I, _P]),
     "mca_attn_fwd": (_I, [C.POINTER(AttnFwdArgs), _P]),
@@ -118,7 +121,13 @@ def check(rc: int, what: str):
 
 # ---- optional live kernel timing (bench.py): HIP events recorded on the launch stream around selected entry points
 PROFILE = None          # None or {"names": set, "records": {key: [(start, end, flops)]}}
+_PROFILE_ON = True      # sampling switch: bench.py records only every n-th step to keep the event overhead < 1 %
 _TAG = ""
+
+
+def profile_enable(flag: bool):
+    global _PROFILE_ON
+    _PROFILE_ON = bool(flag)
 
 
 def set_tag(tag: str):
@@ -144,7 +153,7 @@ def profile_stop():
 
 
 def call(name: str, *args, flops: float = 0.0):
-    if PROFILE is not None and name in PROFILE["names"]:
+    if PROFILE is not None and _PROFILE_ON and name in PROFILE["names"]:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,150 @@
+"""Data-parallel path on CPU: world_size 2, gloo.  The collective logic of mca-paper_amd/dp.py (one packed
+all-gather of pooled embeddings + presence bits; bucketed gradient averaging) is driven with the ORACLE as the
+compute, and must reproduce a single-process run on the concatenated batch:
+    grads_DP  ==  d/dtheta [ (1/W) * sum_r loss_r ]     (DDP mean over ranks, all-gather with backprop)
+This also checks the formulation used by loss.hip: every rank evaluates d(sum_r loss_r)/d(its own pooled rows)
+from the gathered block, so no reduce-scatter is needed."""
+import importlib
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import mca_oracle as O
+
+
+def _cfg():
+    enc = {"a": {"type": "EmbeddedSequenceEncoder", "input_size": 6, "max_tokens": 10, "embedding_dim": 32},
+           "b": {"type": "EmbeddedSequenceEncoder", "input_size": 5, "max_tokens": 7, "embedding_dim": 32},
+           "c": {"type": "TabularEncoder", "num_embeddings": 9, "max_tokens": 9, "max_value": 100, "embedding_dim": 32}}
+    return dict(encoder_configs=enc, dim=32, depth=2, heads=2, dim_head=16, ff_mult=4, num_fusion_tokens=8, batch_size=4,
+                fcl=True, fcl_root=[0, 1, 2], bimodal_contrastive=True, non_fusion_fcl=False, fusion_combos=[3, 2], zorro=False,
+                eao=False, no_fusion=False, mean_pool=False)
+
+
+def _state(cfg):
+    """reference-keyed random state for the oracle (dim 32: the parameter containers are dimension-agnostic)."""
+    pkg = importlib.import_module("mca-paper_amd")
+    cfg2 = dict(cfg, dim_head=64)          # MCA() refuses dim_head != 64 for the kernels; shapes only depend on heads*dim_head
+    cfg2["heads"] = 1
+    cfg2["dim"] = 32
+    g = torch.Generator().manual_seed(5)
+    S = O.Structure(cfg)
+    sd = {}
+    D, I = 32, int(32 * 4 * 2 / 3)
+    r = lambda *s: torch.randn(*s, generator=g) * 0.2
+    for name, c in cfg["encoder_configs"].items():
+        p = f"encoders.{name}."
+        if c["type"] == "EmbeddedSequenceEncoder":
+            n_in = c["input_size"]
+            sd.update({p + "token_encoder.0.weight": 1 + r(n_in), p + "token_encoder.0.bias": r(n_in), p + "token_encoder.1.weight": r(D, n_in),
+                       p + "token_encoder.1.bias": r(D), p + "token_encoder.2.weight": 1 + r(D), p + "token_encoder.2.bias": r(D),
+                       p + "positional_encoder.pe": O.sinusoid_pe(c["max_tokens"], D)})
+        else:
+            n = c["num_embeddings"]
+            emb = torch.randn(n, D, generator=g); emb[::2] *= 0.05; emb[-1] = 0
+            sd.update({p + "token_encoder.embedding.weight": emb, p + "value_encoder.linear1.weight": r(D, 1), p + "value_encoder.linear1.bias": r(D),
+                       p + "value_encoder.linear2.weight": r(D, D), p + "value_encoder.linear2.bias": r(D),
+                       p + "value_encoder.norm.weight": 1 + r(D), p + "value_encoder.norm.bias": r(D)})
+    sd["fusion_tokens"] = torch.randn(8, D, generator=g)
+    sd["return_tokens"] = torch.randn(len(S.ret_types), D, generator=g)
+    for i in range(2):
+        p = f"layers.{i}."
+        sd.update({p + "attn.to_q.weight": r(D, D), p + "attn.to_kv.weight": r(2 * D, D), p + "attn.to_out.weight": r(D, D),
+                   p + "ff.feedforward.0.weight": r(2 * I, D), p + "ff.feedforward.2.weight": r(D, I), p + "norm.gamma": 1 + r(D)})
+    sd.update({"norm.gamma": 1 + r(D), "attn_pool.to_q.weight": r(D, D), "attn_pool.to_kv.weight": r(2 * D, D),
+               "attn_pool.to_out.weight": r(D, D), "loss.loss_fn.logit_scale": torch.tensor(2.6593)})
+    return sd
+
+
+def _batch(cfg, B):
+    pkg = importlib.import_module("mca-paper_amd")
+    return pkg.data.synthetic_batch(cfg, B, seed=99, p_drop=0.3)
+
+
+def _slice(batch, lo, hi):
+    return {k: {kk: vv[lo:hi] for kk, vv in v.items()} for k, v in batch.items()}
+
+
+def _present(sample_mask, names):
+    p = torch.zeros(len(next(iter(sample_mask.values()))), dtype=torch.int32)
+    for i, n in enumerate(names):
+        p |= sample_mask[n].to(torch.int32) << i
+    return p
+
+
+def _sum_of_rank_losses(S, pooled_all, present_all, logit_scale, b, W, names):
+    tot = 0
+    for r in range(W):
+        sm = {n: ((present_all[r * b:(r + 1) * b] >> i) & 1).bool() for i, n in enumerate(names)}
+        tot = tot + O.pretraining_loss(S, pooled_all[r * b:(r + 1) * b], sm, logit_scale, pooled_all=pooled_all, rank=r)["loss"]
+    return tot
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dp = importlib.import_module("mca-paper_amd.dp")
+        cfg = _cfg(); S = O.Structure(cfg); names = S.modalities
+        sd = _state(cfg)
+        params = {k: v for k, v in sd.items() if O.is_param(k)}
+        for p in params.values():
+            p.requires_grad_(True)
+        b = 4
+        local = _slice(_batch(cfg, b * world), rank * b, (rank + 1) * b)
+        P = O.Prec("fp32")
+        tokens, padding, sample_mask = O.encode_and_pack(S, sd, local, P)
+        pooled = O.mca_trunk(S, sd, tokens, padding, P)
+        present = _present(sample_mask, names)
+        pooled_all, present_all, row0 = dp.gather_pooled(pooled.detach(), present)          # <- collective A
+        assert row0 == rank * b and pooled_all.shape[0] == b * world
+        # what loss.hip returns: d(sum_r loss_r)/d(own rows) and d(loss_own)/d(logit_scale)
+        pa = pooled_all.clone().requires_grad_(True)
+        ls = sd["loss.loss_fn.logit_scale"]
+        tot = _sum_of_rank_losses(S, pa, present_all, ls.detach(), b, world, names)
+        d_pooled = torch.autograd.grad(tot, pa)[0][row0:row0 + b]
+        ls_leaf = ls.detach().clone().requires_grad_(True)
+        sm_loc = {n: ((present >> i) & 1).bool() for i, n in enumerate(names)}
+        own = O.pretraining_loss(S, pooled_all[row0:row0 + b], sm_loc, ls_leaf, pooled_all=pooled_all, rank=rank)["loss"]
+        d_ls = torch.autograd.grad(own, ls_leaf)[0]
+        pooled.backward(d_pooled)
+        order = [k for k in params if k != "loss.loss_fn.logit_scale"] + ["loss.loss_fn.logit_scale"]
+        flat = torch.cat([(params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])).reshape(-1) for k in order[:-1]]
+                         + [d_ls.reshape(1)])
+        red = dp.BucketReducer(flat)                                                          # <- collective B
+        third = flat.numel() // 3
+        for lo, hi in [(0, third), (third, 2 * third), (2 * third, flat.numel())]:
+            red.bucket_ready(lo, hi)
+        red.finish()
+        if rank == 0:
+            torch.save({"flat": flat, "order": order, "own_loss": own.detach()}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_world2_matches_single_process(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    # single process, concatenated batch: objective (1/W) sum_r loss_r with full autograd through the gather
+    cfg = _cfg(); S = O.Structure(cfg); names = S.modalities
+    sd = _state(cfg)
+    params = {k: v for k, v in sd.items() if O.is_param(k)}
+    for p in params.values():
+        p.requires_grad_(True)
+    W, b = 2, 4
+    P = O.Prec("fp32")
+    tokens, padding, sample_mask = O.encode_and_pack(S, sd, _batch(cfg, W * b), P)
+    pooled = O.mca_trunk(S, sd, tokens, padding, P)
+    present = _present(sample_mask, names)
+    obj = _sum_of_rank_losses(S, pooled, present, sd["loss.loss_fn.logit_scale"], b, W, names) / W
+    obj.backward()
+    ref = torch.cat([(params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])).reshape(-1) for k in got["order"]])
+    err = (got["flat"] - ref).abs().max() / ref.abs().max()
+    assert err < 2e-5, err
+    assert got["flat"].abs().max() > 0

@@ -52,12 +52,19 @@ def _check_losses(nat, ref_losses, ref_total, scale):
     assert abs(nat["loss"] - float(ref_total)) <= TOL_LOGIT * scale + 1e-4
 
 
-@pytest.mark.parametrize("variant,p_drop", [("mca", 0.0), ("mca", 0.35), ("zorro", 0.35), ("bimodal", 0.35)])
+@pytest.mark.parametrize("variant,p_drop", [("mca", 0.0), ("mca", 0.35), ("zorro", 0.35), ("bimodal", 0.35), ("tab", 0.35)])
 def test_small_step_vs_oracle(P, variant, p_drop):
     from oracle import mca_oracle as O
     cfg = small_config(variant)
     batch = P.data.synthetic_batch(cfg, 6, seed=5, p_drop=p_drop)
+    if variant == "tab":        # value-path sentinels: padding value -1, clamp above max_value, a missing entry
+        v = batch["video"]["values"]
+        v[0, 3], v[1, 5], v[2, 7] = -1.0, 250.0, -10000.0
+        batch["video"]["attention_mask"] = (v == -10000).to(torch.long)
     sd = P.params.init_state_dict(cfg, seed=3)
+    for k in sd:                # embedding rows on both sides of max_norm = 1
+        if k.endswith("embedding.weight"):
+            sd[k][::2] *= 0.05
     g = torch.Generator().manual_seed(9)            # non-trivial gammas / biases
     for k in sd:
         if k.endswith("gamma") or k.endswith("bias") or ("token_encoder" in k and sd[k].dim() == 1):
@@ -126,6 +133,33 @@ def test_cmu_b2_vs_reference_golden(P, case):
             bad.append((n + "[slice]", rel_err(nat["grads"][n].flatten()[:64], ref_sl), 0))
     assert not bad, bad[:8]
     assert sorted(rels)[len(rels) // 2] < 1e-2
+
+
+def test_tcga_shape_b2_vs_oracle(P):
+    """TCGA_config1-shaped step (4 TabularEncoder modalities, N = 2548, 60 loss terms) at b=2 against the oracle."""
+    from oracle import mca_oracle as O
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cfg = P.config.tcga_model_config(batch_size=2)
+    sd = P.params.init_state_dict(cfg, seed=43)
+    batch = P.data.synthetic_batch(cfg, 2, seed=77, p_drop=0.25)
+    nat = run_native_step(P, cfg, sd, batch, lr=1e-4, clip=2.0)
+    ref = run_oracle_step(O, cfg, sd, batch, "fp32", lr=1e-4, clip=2.0)
+    emu = run_oracle_step(O, cfg, sd, batch, "bf16emu", lr=1e-4, clip=2.0)
+    assert len(ref["losses"]) == 60
+    assert rel_err(nat["pooled"], ref["pooled"]) < TOL_POOLED
+    _check_losses(nat, ref["losses"], ref["loss"], _logit_scale(ref["pooled_full"]))
+    # 60 temperature-14 softmaxes over a batch of 2: gradients are extremely sensitive to the 1e-3 embedding error; the
+    # yardstick is the oracle with bf16 rounding at the kernels' rounding points (median 8 %, max 31 % vs fp32 here)
+    rels, rels_emu = [], []
+    for n, gref in ref["grads"].items():
+        if n.endswith("logit_scale") or gref.abs().max() == 0:
+            continue
+        e, e_emu = rel_err(nat["grads"][n], gref), rel_err(emu["grads"][n], gref)
+        rels.append(e); rels_emu.append(e_emu)
+        assert e < 1.5 * e_emu + 0.05, (n, e, e_emu)
+    med, med_emu = sorted(rels)[len(rels) // 2], sorted(rels_emu)[len(rels) // 2]
+    assert med < 1.3 * med_emu + 0.01, (med, med_emu)
+    assert abs(nat["grad_norm"] - ref["grad_norm"]) < TOL_GN * ref["grad_norm"]
 
 
 def test_dropin_loop_and_no_loss(P):

@@ -14,6 +14,9 @@ def small_config(variant="mca", depth=2):
     cfg = dict(encoder_configs=enc, dim=128, depth=depth, heads=2, dim_head=64, ff_mult=4, num_fusion_tokens=8,
                batch_size=4, fcl=True, fcl_root=[0, 1, 2], bimodal_contrastive=False, non_fusion_fcl=False,
                fusion_combos=[3, 2], zorro=False, eao=False, no_fusion=False, mean_pool=False)
+    if variant == "tab":        # mixed encoders: the middle modality is a dense table (TCGA-style)
+        enc["video"] = {"type": "TabularEncoder", "num_embeddings": 45, "max_tokens": 45, "max_value": 100, "embedding_dim": 128}
+        cfg.update(bimodal_contrastive=True, non_fusion_fcl=True)
     if variant == "zorro":
         cfg.update(zorro=True, fcl=False)
     elif variant == "bimodal":

@@ -1,0 +1,149 @@
+"""Training entrypoint with the reference's shape (train_accel_gpu.py:1-188):
+
+    python train_accel_gpu.py <config.yaml>                       # 1 GPU
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 train_accel_gpu.py <config.yaml>
+
+Same YAML keys (utils/config.py), same loop order (forward, zero_grad, backward, clip_grad_norm_, AdamW step, cosine
+schedule with warm-up, per-epoch checkpoint, final safetensors model).  What differs: the model step runs in the HIP
+kernels of mca-paper_amd, the optimizer is the fused clip+AdamW, data parallelism is mca-paper_amd/dp.py (RCCL), and
+logging goes to stdout / <output_dir>/log.jsonl instead of wandb.  `--synthetic STEPS` trains on synthetic batches of
+the configured shapes when the HF dataset named in the YAML is not on disk.
+"""
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+P = importlib.import_module("mca-paper_amd")
+optim = importlib.import_module("mca-paper_amd.optim")
+dpmod = importlib.import_module("mca-paper_amd.dp")
+
+
+def cosine_with_warmup(step, warmup, total):
+    """transformers.get_scheduler('cosine') (train_accel_gpu.py:81-86)."""
+    if step < warmup:
+        return step / max(1, warmup)
+    prog = (step - warmup) / max(1, total - warmup)
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+
+
+def move_to(obj, device):
+    if torch.is_tensor(obj):
+        return obj.to(device, non_blocking=True)
+    if isinstance(obj, dict):
+        return {k: move_to(v, device) for k, v in obj.items()}
+    if isinstance(obj, list):
+        return [move_to(v, device) for v in obj]
+    raise TypeError("Invalid type for move_to")
+
+
+def main():
+    if len(sys.argv) < 2:
+        raise SystemExit(__doc__)
+    synthetic_steps = int(sys.argv[sys.argv.index("--synthetic") + 1]) if "--synthetic" in sys.argv else 0
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=device)
+    config = P.config.training_config(sys.argv[1], make_output_dir=rank == 0)
+    torch.manual_seed(config.seed)
+    model_config = P.config.get_model_config(config)
+    if model_config["eao"]:
+        raise NotImplementedError("EAO baseline model is outside the native hot path (SURVEY.md section 2 #13)")
+    modality_config = config.get("modality_config", config.get("modality_configs", {}))
+
+    # ---- data
+    if synthetic_steps:
+        def batches(epoch):
+            for i in range(synthetic_steps):
+                yield P.data.synthetic_batch(model_config, config.batch_size, seed=1234 + rank + 1000 * (epoch * synthetic_steps + i),
+                                             p_drop=max([c.get("dropout", 0.0) for c in modality_config.values()] + [0.0]) if config.get("predrop") else 0.0)
+        steps_per_epoch = synthetic_steps
+        eval_batches = None
+    else:
+        from datasets import load_from_disk
+        from torch.utils.data import DataLoader
+        from torch.utils.data.distributed import DistributedSampler
+        ds = load_from_disk(config.dataset).with_format("torch")
+        if config.ds_frac < 1.0:
+            ds = ds.select(list(range(0, int(len(ds) * config.ds_frac))))
+        if config.split and config.split != 1.0:
+            ds = ds.train_test_split(config.split, seed=config.ds_seed)
+        collate = P.MultimodalCollator(modality_config)
+        sampler = DistributedSampler(ds["train"], world, rank, shuffle=True, drop_last=True) if world > 1 else None
+        train_dl = DataLoader(ds["train"], collate_fn=collate, batch_size=config.batch_size, shuffle=sampler is None, sampler=sampler,
+                              num_workers=8, prefetch_factor=4, drop_last=True)
+        eval_dl = DataLoader(ds["test"], collate_fn=collate, batch_size=config.batch_size, drop_last=True)
+        steps_per_epoch = len(train_dl)
+
+        def batches(epoch):
+            if sampler is not None:
+                sampler.set_epoch(epoch)
+            yield from train_dl
+        eval_batches = eval_dl
+
+    # ---- model, optimizer, schedule
+    model = P.MCA(**model_config).to(device)
+    opt = optim.FusedAdamW(model, lr=config.lr)
+    dp = dpmod.DataParallelMCA(model) if world > 1 else None
+    total_steps = config.epochs * steps_per_epoch
+    if config.restart:
+        sd = torch.load(os.path.join(config.restart, "state.pt"), map_location=device)
+        model.load_state_dict(sd["model"], strict=False); opt.load_state_dict(sd["optimizer"])
+    log = open(os.path.join(config.output_dir, "log.jsonl"), "a") if rank == 0 else None
+    step = config.start_epoch * steps_per_epoch
+    model.train()
+    for epoch in range(config.start_epoch, config.epochs):
+        t_epoch = time.time()
+        for idb, batch in enumerate(batches(epoch)):
+            batch = move_to(batch, device)
+            for g in opt.param_groups:
+                g["lr"] = config.lr * (cosine_with_warmup(step, config.num_warmup_steps, total_steps)
+                                       if config.lr_scheduler_type == "cosine" else 1.0)
+            outputs = model(batch)
+            opt.zero_grad()
+            loss = outputs["loss"]
+            loss.backward()
+            if dp is not None:
+                dp.finish_backward()
+            gnorm = optim.clip_grad_norm_(model, config.clip) if config.clip else None
+            opt.step()
+            step += 1
+            if rank == 0 and (idb % 10 == 0 or idb == steps_per_epoch - 1):
+                rec = {"epoch": epoch, "step": step, "total_loss": float(loss), "lr": opt.param_groups[0]["lr"],
+                       "grad_norm": float(gnorm) if gnorm is not None else None,
+                       **{k: float(v) for k, v in outputs["losses"].items() if "|" not in k}}
+                print(json.dumps(rec), flush=True)
+                log.write(json.dumps(rec) + "\n"); log.flush()
+            if config.n_step_checkpoint and idb % config.n_step_checkpoint == 0 and rank == 0:
+                torch.save({"model": model.state_dict(), "optimizer": opt.state_dict()}, os.path.join(config.output_dir, "state.pt"))
+        if rank == 0:
+            d = os.path.join(config.output_dir, str(epoch)); os.makedirs(d, exist_ok=True)
+            torch.save({"model": model.state_dict(), "optimizer": opt.state_dict()}, os.path.join(d, "state.pt"))
+            print(f"epoch {epoch} done in {time.time() - t_epoch:.1f}s", flush=True)
+        if config.run_eval_loop and eval_batches is not None:
+            model.eval()
+            with torch.no_grad():
+                tot, n = 0.0, 0
+                for batch in eval_batches:
+                    out = model(move_to(batch, device))
+                    tot += float(out["loss"]); n += 1
+            if rank == 0:
+                print(json.dumps({"epoch": epoch, "val_epoch_total_loss": tot / max(1, n)}), flush=True)
+            model.train()
+    if rank == 0:
+        from safetensors.torch import save_file
+        save_file({k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}, os.path.join(config.output_dir, "model.safetensors"))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
