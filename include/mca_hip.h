@@ -134,7 +134,7 @@ typedef struct {
   const uint32_t* qmask;            /* (nq) allowed key groups per query row                       */
   const uint8_t* keyinfo;           /* (b, nk_pad)                                                 */
   const uint8_t* ktile_flags;       /* (b, n_ktiles)                                               */
-  const int32_t* q_ptr; const int32_t* q_kt; const uint8_t* q_full; const int32_t* q_order;
+  const int32_t* q_ptr; const uint32_t* q_kt; const int32_t* q_order;   /* q_kt: key-tile index | (full << 31) */
   const float* vmean;               /* (b, heads*64)                                               */
   int batch, heads, nq, nk, nk_pad, n_qtiles, n_ktiles;
   float scale;                      /* dim_head ** -0.5                                            */
@@ -155,7 +155,7 @@ typedef struct {
   float* dq; int64_t dq_bstride; int64_t dq_ld;           /* fp32, ACCUMULATED with atomics       */
   uint16_t* dk; uint16_t* dv; int64_t dkv_bstride; int64_t dkv_ld;   /* bf16, written once        */
   const uint32_t* qmask; const uint8_t* keyinfo; const uint8_t* ktile_flags;
-  const int32_t* k_ptr; const int32_t* k_qt; const uint8_t* k_full; const int32_t* k_order;
+  const int32_t* k_ptr; const uint32_t* k_qt; const int32_t* k_order;   /* k_qt: query-tile index | (full << 31) */
   int batch, heads, nq, nk, nk_pad, n_qtiles, n_ktiles;
   float scale;
 } mca_attn_bwd_args;

@@ -58,6 +58,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a) {
   }
   const uint32_t kinfo = a.keyinfo[(int64_t)b * a.nk_pad + mykey];     // nk_pad covers every key block
   const bool key_ok = kinfo != 31u;
+  const uint32_t keybit = key_ok ? (1u << kinfo) : 0u;          // bit of this lane's key group; 0 = padded key
+  const bool wave_keys_ok = __all(key_ok);                      // wave-uniform
   // K image for the dQ product
   for (int id = tid; id < BKEYS * 8; id += 512) {
     const int r = id >> 3, c = id & 7;
@@ -99,16 +101,17 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a) {
 
   const int it_begin = a.k_ptr[kbi], it_end = a.k_ptr[kbi + 1];
   int buf = 0;
-  if (it_begin < it_end) { gload(a.k_qt[it_begin]); swrite(0); }
+  if (it_begin < it_end) { gload((int)(a.k_qt[it_begin] & 0x7fffffffu)); swrite(0); }
   __syncthreads();
 
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1, g4 = lane >> 4;
   const int qb = wave & 1, db = wave >> 1;       // this wavefront's 16x16 block of the dQ tile
 
   for (int it = it_begin; it < it_end; it++) {
-    const int qt = a.k_qt[it];
-    const bool full = a.k_full[it] != 0;
-    if (it + 1 < it_end) gload(a.k_qt[it + 1]);
+    const uint32_t ent = a.k_qt[it];
+    const int qt = (int)(ent & 0x7fffffffu);
+    const bool full = (ent >> 31) != 0;
+    if (it + 1 < it_end) gload((int)(a.k_qt[it + 1] & 0x7fffffffu));
     const u16* qs = Qs + buf * BQ * DH;
     const u16* os = Os + buf * BQ * DH;
     const float* rc = rowc + buf * 96;
@@ -125,23 +128,38 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a) {
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfrag, kf[st], s, 0, 0, 0);
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofrag, vf[st], dp, 0, 0, 0);
     }
-    // ---- P, dS
+    // ---- P, dS.  Fast path: a structurally full tile whose 32 keys (this wavefront's) are all valid needs no mask.
     bf16x8 pb[2], sb[2];
+    if (full && wave_keys_ok) {
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const f32x4 lse4 = *reinterpret_cast<const f32x4*>(rc + 8 * g + 4 * lh);
-      const f32x4 del4 = *reinterpret_cast<const f32x4*>(rc + 32 + 8 * g + 4 * lh);
-      const f32x4 qm4 = *reinterpret_cast<const f32x4*>(rc + 64 + 8 * g + 4 * lh);
+      for (int g = 0; g < 4; g++) {
+        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(rc + 8 * g + 4 * lh);
+        const f32x4 del4 = *reinterpret_cast<const f32x4*>(rc + 32 + 8 * g + 4 * lh);
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int r = 4 * g + e;
-        bool ok = key_ok;
-        if (!full) ok = ok && ((__float_as_uint(qm4[e]) >> kinfo) & 1u);
-        float p = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse4[e]));
-        p = ok ? p : 0.f;
-        const float dsv = p * (dp[r] - del4[e]);
-        pb[r >> 3][r & 7] = (short)f2bf(p);
-        sb[r >> 3][r & 7] = (short)f2bf(dsv);
+        for (int e = 0; e < 4; e++) {
+          const int r = 4 * g + e;
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse4[e]));
+          const float dsv = p * (dp[r] - del4[e]);
+          pb[r >> 3][r & 7] = (short)f2bf(p);
+          sb[r >> 3][r & 7] = (short)f2bf(dsv);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(rc + 8 * g + 4 * lh);
+        const f32x4 del4 = *reinterpret_cast<const f32x4*>(rc + 32 + 8 * g + 4 * lh);
+        const f32x4 qm4 = *reinterpret_cast<const f32x4*>(rc + 64 + 8 * g + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int r = 4 * g + e;
+          const uint32_t qsel = full ? 0xffffffffu : __float_as_uint(qm4[e]);
+          float p = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse4[e]));
+          p = (qsel & keybit) ? p : 0.f;
+          const float dsv = p * (dp[r] - del4[e]);
+          pb[r >> 3][r & 7] = (short)f2bf(p);
+          sb[r >> 3][r & 7] = (short)f2bf(dsv);
+        }
       }
     }
     // ---- dS^T to LDS: lane = key row, 4 consecutive q per store
@@ -228,7 +246,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a) {
 
 extern "C" int mca_attn_bwd(const mca_attn_bwd_args* a, mca_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->d_o || !a->lse || !a->delta || !a->dvmean || !a->dq || !a->dk || !a->dv ||
-      !a->qmask || !a->keyinfo || !a->k_ptr || !a->k_qt || !a->k_full || !a->k_order)
+      !a->qmask || !a->keyinfo || !a->k_ptr || !a->k_qt || !a->k_order)
     return MCA_E_BADARG;
   if (a->batch <= 0 || a->heads <= 0 || a->nq <= 0 || a->nk <= 0) return MCA_E_BADARG;
   if (a->n_qtiles != (a->nq + BQ - 1) / BQ || a->n_ktiles != (a->nk + BKEYS - 1) / BKEYS) return MCA_E_BADARG;

@@ -21,6 +21,7 @@
 #define AQ 128      // query rows per workgroup
 #define AK 64       // keys per tile
 #define DH 64       // head dim (fixed)
+#define MAX_KTILES 512
 
 // K tile image: [64 keys][64 d] bf16, 128-byte rows, chunk c (16 B) of row r at c ^ ((r>>1)&7)
 __device__ __forceinline__ int k_off(int r, int c) { return r * 64 + ((c ^ ((r >> 1) & 7)) << 3); }
@@ -31,6 +32,7 @@ __device__ __forceinline__ int v_off(int r, int c) { return r * 64 + ((c ^ (((r 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a) {
   __shared__ __attribute__((aligned(16))) u16 lds[2 * 2 * AK * DH];   // K,V double-buffered: 32 KiB
   __shared__ __attribute__((aligned(16))) uint8_t kinfo[2][AK];
+  __shared__ uint8_t flags_s[MAX_KTILES];       // this sample's key-tile flags (read from LDS: no vmcnt wait in the loop)
   u16* Ks = lds;
   u16* Vs = lds + 2 * AK * DH;
 
@@ -63,20 +65,42 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a) {
   const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
   const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
   const uint8_t* kinfo_g = a.keyinfo + (int64_t)b * a.nk_pad;
-  const uint8_t* flags = a.ktile_flags + (int64_t)b * a.n_ktiles;
+  {
+    const uint8_t* flags_g = a.ktile_flags + (int64_t)b * a.n_ktiles;
+    for (int i = tid; i < a.n_ktiles; i += 256) flags_s[i] = flags_g[i];
+  }
+  __syncthreads();
 
-  // staging: 512 chunks of 16 B per tile per operand, 2 per thread
+  // staging: 512 chunks of 16 B per tile per operand, 2 per thread.  The per-lane element offset inside a tile is
+  // loop-invariant; the tile base is wave-uniform (scalar), so the loads use the SGPR-base + VGPR-offset form and no
+  // address register is recycled while the prefetch is in flight.  Only the last key tile (which may run past nk)
+  // takes the per-lane clamped path.
   int srow[2], sc[2];
+  unsigned loff[2];
 #pragma unroll
-  for (int i = 0; i < 2; i++) { const int id = tid + 256 * i; srow[i] = id >> 3; sc[i] = id & 7; }
+  for (int i = 0; i < 2; i++) {
+    const int id = tid + 256 * i; srow[i] = id >> 3; sc[i] = id & 7;
+    loff[i] = (unsigned)(srow[i] * (int)a.kv_ld + sc[i] * 8);
+  }
+  const int last_kt = a.n_ktiles - 1;
   bf16x8 rk[2], rv[2];
   uint32_t rinfo = 0;
   auto gload = [&](int kt) {
+    const u16* kb = kbase + (int64_t)kt * AK * a.kv_ld;
+    const u16* vb = vbase + (int64_t)kt * AK * a.kv_ld;
+    if (kt != last_kt) {
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-      int key = kt * AK + srow[i]; if (key > a.nk - 1) key = a.nk - 1;
-      rk[i] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * a.kv_ld + sc[i] * 8);
-      rv[i] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * a.kv_ld + sc[i] * 8);
+      for (int i = 0; i < 2; i++) {
+        rk[i] = *reinterpret_cast<const bf16x8*>(kb + loff[i]);
+        rv[i] = *reinterpret_cast<const bf16x8*>(vb + loff[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        int key = kt * AK + srow[i]; if (key > a.nk - 1) key = a.nk - 1;
+        rk[i] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * a.kv_ld + sc[i] * 8);
+        rv[i] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * a.kv_ld + sc[i] * 8);
+      }
     }
     if (tid < 16) rinfo = *reinterpret_cast<const uint32_t*>(kinfo_g + kt * AK + tid * 4);
   };
@@ -92,18 +116,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a) {
   // the tile list of this query tile, minus tiles whose keys are all padded in this sample
   const int it_end = a.q_ptr[qt + 1];
   int it = a.q_ptr[qt];
-  auto next_live = [&](int i) { while (i < it_end && flags[a.q_kt[i]] == 0) i++; return i; };
+  auto next_live = [&](int i) { while (i < it_end && flags_s[a.q_kt[i] & 0x7fffffffu] == 0) i++; return i; };
   it = next_live(it);
   int buf = 0;
-  if (it < it_end) { gload(a.q_kt[it]); swrite(0); }
+  if (it < it_end) { gload((int)(a.q_kt[it] & 0x7fffffffu)); swrite(0); }
   __syncthreads();
 
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
   while (it < it_end) {
-    const int kt = a.q_kt[it];
-    const bool need_mask = (a.q_full[it] == 0) || (flags[kt] != 2);
+    const uint32_t ent = a.q_kt[it];
+    const int kt = (int)(ent & 0x7fffffffu);
+    const bool need_mask = (ent >> 31) == 0 || (flags_s[kt] != 2);
     const int nit = next_live(it + 1);
-    if (nit < it_end) gload(a.q_kt[nit]);
+    if (nit < it_end) gload((int)(a.q_kt[nit] & 0x7fffffffu));
 
     const u16* ks = Ks + buf * AK * DH;
     const u16* vs = Vs + buf * AK * DH;
@@ -212,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a) {
 
 extern "C" int mca_attn_fwd(const mca_attn_fwd_args* a, mca_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->o || !a->lse || !a->qmask || !a->keyinfo || !a->ktile_flags || !a->q_ptr ||
-      !a->q_kt || !a->q_full || !a->q_order || !a->vmean)
+      !a->q_kt || !a->q_order || !a->vmean)
     return MCA_E_BADARG;
   if (a->batch <= 0 || a->heads <= 0 || a->nq <= 0 || a->nk <= 0) return MCA_E_BADARG;
   if (a->n_qtiles != (a->nq + AQ - 1) / AQ || a->n_ktiles != (a->nk + AK - 1) / AK) return MCA_E_BADARG;
@@ -221,7 +246,7 @@ extern "C" int mca_attn_fwd(const mca_attn_fwd_args* a, mca_stream_t stream) {
   if ((uintptr_t)a->q % 16 || (uintptr_t)a->k % 16 || (uintptr_t)a->v % 16 || (uintptr_t)a->o % 8 ||
       (uintptr_t)a->keyinfo % 4)
     return MCA_E_ALIGN;
-  if (a->heads > 65535 || a->batch > 65535) return MCA_E_UNSUPPORTED;
+  if (a->heads > 65535 || a->batch > 65535 || a->n_ktiles > MAX_KTILES) return MCA_E_UNSUPPORTED;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(a->n_qtiles, a->heads, a->batch), dim3(256), 0, as_stream(stream), *a);
   return launch_status();
 }

@@ -16,6 +16,8 @@
 // A panel from that XCD's L2.
 #include "common.h"
 
+static int g_knob[8];      // A/B measurement knobs (mca_debug_set)
+
 #define BM 128
 #define BN 128
 #define BK 64
@@ -114,6 +116,55 @@ __device__ __forceinline__ void nt_epilogue_lds(f32x16 (&acc)[2][2], float* __re
 template <int BKT> __device__ __forceinline__ int gl_sw(int r) { return BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 template <int BKT> __device__ __forceinline__ int gl_off(int r, int c) { return r * BKT + ((c ^ gl_sw<BKT>(r)) << 3); }
 
+// One BK = 64 step of a wavefront's 64x64 sub-tile: 4 k16-steps of 2x2 MFMA 32x32x16.  The fragment reads are
+// inline asm with hand-counted lgkmcnt so that the reads of step ks+1 are in flight while the MFMAs of step ks
+// issue (hipcc otherwise re-uses one register set and waits lgkmcnt(0) in front of every group of 4 MFMAs).
+// Byte address of (row r, k16-step ks): P ^ (32*ks) with P = tile_base + r*128 + 16*(lh ^ swizzle(r)); the XOR
+// form holds because every base is a multiple of 128 bytes.
+struct NtFragAddr { unsigned a[2], b[2]; };
+__device__ __forceinline__ NtFragAddr nt_frag_addr(const u16* lds_base, int a_elem_off, int b_elem_off, int wm, int wn, int l31, int lh) {
+  NtFragAddr f;
+  const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const u16*)lds_base;
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int ra = wm * 64 + i * 32 + l31, rb = wn * 64 + i * 32 + l31;
+    f.a[i] = base + 2u * (unsigned)a_elem_off + (unsigned)(ra * 128) + 16u * (unsigned)(lh ^ ((ra >> 1) & 7));
+    f.b[i] = base + 2u * (unsigned)b_elem_off + (unsigned)(rb * 128) + 16u * (unsigned)(lh ^ ((rb >> 1) & 7));
+  }
+  return f;
+}
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+#define NT_DSREAD(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+__device__ __forceinline__ void nt_compute_step(const NtFragAddr& f, unsigned stage_byte_off, f32x16 (&acc)[2][2]) {
+  u32x4v fa[2][2], fb[2][2];          // [parity][i]
+  const unsigned a0 = f.a[0] + stage_byte_off, a1 = f.a[1] + stage_byte_off;
+  const unsigned b0 = f.b[0] + stage_byte_off, b1 = f.b[1] + stage_byte_off;
+#define NT_ISSUE(KS, PAR)                                                                            \
+  NT_DSREAD(fa[PAR][0], a0 ^ (32u * (KS))); NT_DSREAD(fb[PAR][0], b0 ^ (32u * (KS)));                \
+  NT_DSREAD(fa[PAR][1], a1 ^ (32u * (KS))); NT_DSREAD(fb[PAR][1], b1 ^ (32u * (KS)));
+#define NT_MFMA(PAR)                                                                                 \
+  _Pragma("unroll") for (int i = 0; i < 2; i++)                                                      \
+    _Pragma("unroll") for (int j = 0; j < 2; j++)                                                    \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&fa[PAR][i]), \
+                                                          *reinterpret_cast<const bf16x8*>(&fb[PAR][j]), acc[i][j], 0, 0, 0);
+  NT_ISSUE(0, 0)
+  NT_ISSUE(1, 1)
+  asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+  NT_MFMA(0)
+  __builtin_amdgcn_sched_barrier(0);
+  NT_ISSUE(2, 0)
+  asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+  NT_MFMA(1)
+  __builtin_amdgcn_sched_barrier(0);
+  NT_ISSUE(3, 1)
+  asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+  NT_MFMA(0)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+  NT_MFMA(1)
+#undef NT_ISSUE
+#undef NT_MFMA
+}
+
 template <bool OUT_BF16, int RES, int BKT>
 __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(
     const u16* __restrict__ A, int64_t lda, const u16* __restrict__ B, int64_t ldb, void* __restrict__ Cv,
@@ -164,27 +215,13 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   const int nkt = K / BKT;
+  const NtFragAddr frag = nt_frag_addr(lds, 0, 2 * TILE, wm, wn, l31, lh);
   stage(0, 0);
   __syncthreads();
   for (int kt = 0; kt < nkt; kt++) {
     const int cur = kt & 1;
     if (kt + 1 < nkt) stage((kt + 1) * BKT, cur ^ 1);
-    const u16* as = As + cur * TILE;
-    const u16* bs = Bs + cur * TILE;
-#pragma unroll
-    for (int ks = 0; ks < BKT / 16; ks++) {
-      bf16x8 af[2], bfr[2];
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        af[i] = *reinterpret_cast<const bf16x8*>(as + gl_off<BKT>(wm * 64 + i * 32 + l31, 2 * ks + lh));
-        bfr[i] = *reinterpret_cast<const bf16x8*>(bs + gl_off<BKT>(wn * 64 + i * 32 + l31, 2 * ks + lh));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
+    nt_compute_step(frag, (unsigned)cur * (unsigned)(TILE * 2), acc);
     __syncthreads();          // waits for this wave's LDS-DMA (vmcnt(0)) and for every wave's reads of `cur`
   }
   static_assert(BKT == 64, "the LDS epilogue needs the 64 KiB of operand buffers");
@@ -192,7 +229,142 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(
                                  wm, wn, l31, lh, tid);
 }
 
-static int g_knob[8];
+// ---------------------------------------------------------------------------------------------------------
+// NT kernel, large-M variant: 256x128x64 tile, 8 wavefronts (4x2, 64x64 each), THREE LDS stages (144 KiB) filled
+// by global_load_lds two k-steps ahead; one raw s_barrier per k-step with a counted s_waitcnt vmcnt so the DMA of
+// the next stage stays in flight across the barrier (cdna guide: "Pipelining across barriers").  25 % fewer
+// global->LDS bytes per flop than the 128x128 tile.
+// ---------------------------------------------------------------------------------------------------------
+#define BM2 256
+template <bool OUT_BF16, int RES>
+__global__ __launch_bounds__(512) void gemm_nt_256_kernel(
+    const u16* __restrict__ A, int64_t lda, const u16* __restrict__ B, int64_t ldb, void* __restrict__ Cv,
+    int64_t ldc, const float* __restrict__ bias, const float* __restrict__ residual, int64_t ldres,
+    int64_t res_period, int M, int N, int K, int tiles_n, int nwg) {
+  extern __shared__ __attribute__((aligned(16))) u16 lds2[];
+  constexpr int STAGE = (BM2 + BN) * 64;          // elements per stage: A tile then B tile
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * BM2, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const u16* ga[4];
+  const u16* gb[2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int p = (i * 8 + wave) * 64 + lane, r = p >> 3, c = (p & 7) ^ gl_sw<64>(r);
+    int ra = m0 + r; if (ra > M - 1) ra = M - 1;
+    ga[i] = A + (int64_t)ra * lda + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int p = (i * 8 + wave) * 64 + lane, r = p >> 3, c = (p & 7) ^ gl_sw<64>(r);
+    int rb = n0 + r; if (rb > N - 1) rb = N - 1;
+    gb[i] = B + (int64_t)rb * ldb + c * 8;
+  }
+  auto stage = [&](int k0, int st) {
+    u16* base = lds2 + st * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + (i * 8 + wave) * 512), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + BM2 * 64 + (i * 8 + wave) * 512), 16, 0, 0);
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int nkt = K / 64;
+  const NtFragAddr frag = nt_frag_addr(lds2, 0, BM2 * 64, wm, wn, l31, lh);
+  stage(0, 0);
+  if (nkt > 1) stage(64, 1);
+  int st = 0;
+  for (int kt = 0; kt < nkt; kt++) {
+    // this wave's DMA for stage kt has landed once at most the 6 loads of stage kt+1 are outstanding
+    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nkt) { int s2 = st + 2; if (s2 >= 3) s2 -= 3; stage((kt + 2) * 64, s2); }
+    nt_compute_step(frag, (unsigned)st * (unsigned)(STAGE * 2), acc);
+    st = st == 2 ? 0 : st + 1;
+  }
+  __syncthreads();
+  // epilogue through LDS: 256x128 fp32 = 128 KiB
+  float* cs = reinterpret_cast<float*>(lds2);
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        cs[row * 128 + wn * 64 + j * 32 + l31] = acc[i][j][r];
+      }
+  __syncthreads();
+  constexpr int EPT = OUT_BF16 ? 8 : 4;
+  constexpr int PPR = 128 / EPT;
+#pragma unroll 4
+  for (int it = 0; it < (BM2 * PPR) / 512; it++) {
+    const int id = tid + 512 * it;
+    const int row = id / PPR, c0 = (id % PPR) * EPT;
+    const int m = m0 + row, n = n0 + c0;
+    if (m >= M || n >= N) continue;
+    float v[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e += 4) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(cs + row * 128 + c0 + e);
+      v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
+    }
+    const bool full = n + EPT <= N;
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < EPT; e++) if (full || n + e < N) v[e] += bias[n + e];
+    }
+    if (RES != 0) {
+      const int64_t rr = RES == 2 ? (int64_t)(m % (int)res_period) : (int64_t)m;
+      const float* rp = residual + rr * ldres + n;
+      if (full && (((uintptr_t)rp) & 15) == 0) {
+#pragma unroll
+        for (int e = 0; e < EPT; e += 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(rp + e);
+          v[e] += t[0]; v[e + 1] += t[1]; v[e + 2] += t[2]; v[e + 3] += t[3];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPT; e++) if (n + e < N) v[e] += rp[e];
+      }
+    }
+    if (OUT_BF16) {
+      u16* cp = reinterpret_cast<u16*>(Cv) + (int64_t)m * ldc + n;
+      if (full && (((uintptr_t)cp) & 15) == 0) {
+        uint4 pk;
+        pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4 % EPT], v[5 % EPT]); pk.w = pack2bf(v[6 % EPT], v[7 % EPT]);
+        *reinterpret_cast<uint4*>(cp) = pk;
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPT; e++) if (n + e < N) cp[e] = f2bf(v[e]);
+      }
+    } else {
+      float* cp = reinterpret_cast<float*>(Cv) + (int64_t)m * ldc + n;
+      if (full && (((uintptr_t)cp) & 15) == 0) *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+      else {
+#pragma unroll
+        for (int e = 0; e < EPT; e++) if (n + e < N) cp[e] = v[e];
+      }
+    }
+  }
+}
+#define NT256_LDS_BYTES (3 * (BM2 + BN) * 64 * 2)
+
 extern "C" int mca_debug_set(int key, int value) { if (key >= 0 && key < 8) g_knob[key] = value; return 0; }
 
 extern "C" int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
@@ -205,10 +377,24 @@ extern "C" int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, in
   const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
   const int nwg = tiles_m * tiles_n;
   const int res = !residual ? 0 : (res_period > 0 ? 2 : 1);
+  const bool big = M >= 2048 && g_knob[1] != 1;            // knob 1 = 1 forces the 128x128 kernel (A/B measurements)
+  const int nwg2 = (int)((M + BM2 - 1) / BM2) * tiles_n;
 #define NT_LAUNCH_G(OB, RS)                                                                                              \
   hipLaunchKernelGGL((gemm_nt_glds_kernel<OB, RS, 64>), dim3(nwg), dim3(256), 0, as_stream(stream), A, lda, B, ldb, C,   \
                      ldc, bias, residual, ldres, res_period, (int)M, (int)N, (int)K, tiles_n, nwg)
-#define NT_PICK_PF(OB, RS) NT_LAUNCH_G(OB, RS)
+#define NT_LAUNCH_256(OB, RS)                                                                                            \
+  do {                                                                                                                   \
+    static bool attr = false;                                                                                            \
+    if (!attr) {                                                                                                         \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<OB, RS>),                                 \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS_BYTES) != hipSuccess)                \
+        return MCA_E_LAUNCH;                                                                                             \
+      attr = true;                                                                                                       \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((gemm_nt_256_kernel<OB, RS>), dim3(nwg2), dim3(512), NT256_LDS_BYTES, as_stream(stream), A, lda,  \
+                       B, ldb, C, ldc, bias, residual, ldres, res_period, (int)M, (int)N, (int)K, tiles_n, nwg2);        \
+  } while (0)
+#define NT_PICK_PF(OB, RS) do { if (big) NT_LAUNCH_256(OB, RS); else NT_LAUNCH_G(OB, RS); } while (0)
   if (out_bf16) { if (res == 0) NT_PICK_PF(true, 0); else if (res == 1) NT_PICK_PF(true, 1); else NT_PICK_PF(true, 2); }
   else { if (res == 0) NT_PICK_PF(false, 0); else if (res == 1) NT_PICK_PF(false, 1); else NT_PICK_PF(false, 2); }
   return launch_status();
@@ -223,9 +409,11 @@ extern "C" int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, in
 #define BR 64
 __device__ __forceinline__ int tn_off(int r, int c) { return r * 128 + ((c ^ ((r & 3) << 2)) << 3); }
 
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const u16* __restrict__ A, int64_t lda,
                                                        const u16* __restrict__ B, int64_t ldb, float* __restrict__ C,
-                                                       int64_t ldc, int R, int N, int K, int tiles_k, int rows_per_split) {
+                                                       int64_t ldc, int R, int N, int K, int tiles_k, int rows_per_split, int dbg) {
   __shared__ __attribute__((aligned(16))) u16 lds[2 * 2 * BR * 128];    // 64 KiB
   u16* As = lds;
   u16* Bs = lds + 2 * BR * 128;
@@ -238,31 +426,34 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const u16* __restrict__ A,
   const int wn = wave >> 1, wk = wave & 1;
   const int lh = lane >> 5;
 
-  // staging: tile = 64 rows x 16 chunks = 1024 chunks per operand, 4 per thread
-  int srow[4], scol[4], soff[4];
+  // direct global->LDS staging: the tile image is 64 rows x 16 chunks (1024 chunks) per operand, 4 wave-instructions
+  // per wave; LDS position p = (i*4 + wave)*64 + lane holds logical chunk (p & 15) ^ ((row & 3) << 2) of row p >> 4.
+  // Rows past the end of this split and column chunks past N / K are fetched from a 16-byte zero block.
+  int srow[4];
+  const u16* pa[4];
+  const u16* pb[4];
+  bool ca_ok[4], cb_ok[4];
+  const u16* zero = reinterpret_cast<const u16*>(g_zero16);
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int id = tid + 256 * i; srow[i] = id >> 4; scol[i] = id & 15; soff[i] = tn_off(srow[i], scol[i]);
+    const int p = (i * 4 + wave) * 64 + lane, r = p >> 4, c = (p & 15) ^ ((r & 3) << 2);
+    srow[i] = r;
+    ca_ok[i] = n0 + c * 8 < N;
+    cb_ok[i] = k0 + c * 8 < K;
+    pa[i] = A + n0 + c * 8;
+    pb[i] = B + k0 + c * 8;
   }
-  bf16x8 ra_[4], rb_[4];
-  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto gload = [&](int r0) {
+  auto stage = [&](int r0, int buf) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int r = r0 + srow[i];
       const bool rok = r < r_end;
-      // a chunk that starts inside [0,N) / [0,K) is read whole: rows are allocated up to the next multiple
-      // of 8 columns (checked on the host); outputs past N / K are discarded at the store
-      const int ca = n0 + scol[i] * 8, cb = k0 + scol[i] * 8;
-      ra_[i] = (rok && ca < N) ? *reinterpret_cast<const bf16x8*>(A + (int64_t)r * lda + ca) : zero;
-      rb_[i] = (rok && cb < K) ? *reinterpret_cast<const bf16x8*>(B + (int64_t)r * ldb + cb) : zero;
-    }
-  };
-  auto swrite = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      *reinterpret_cast<bf16x8*>(As + buf * BR * 128 + soff[i]) = ra_[i];
-      *reinterpret_cast<bf16x8*>(Bs + buf * BR * 128 + soff[i]) = rb_[i];
+      const u16* sa = (rok && ca_ok[i]) ? pa[i] + (int64_t)r * lda : zero;
+      const u16* sb = (rok && cb_ok[i]) ? pb[i] + (int64_t)r * ldb : zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                       (__attribute__((address_space(3))) void*)(As + buf * BR * 128 + (i * 4 + wave) * 512), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                       (__attribute__((address_space(3))) void*)(Bs + buf * BR * 128 + (i * 4 + wave) * 512), 16, 0, 0);
     }
   };
   f32x16 acc[2][2];
@@ -274,42 +465,69 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const u16* __restrict__ A,
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   // per-lane transposed-read coordinates: 16-lane group g = lane>>4 covers matrix rows 16*(g&1)..+15 of the
-  // 32-row operand block and k-half lh; lane 4q+p supplies LDS row q, columns 4p..4p+3 of the 4x16 block
+  // 32-row operand block and k-half lh; lane 4q+p supplies LDS row q, columns 4p..4p+3 of the 4x16 block.
+  // The reads are issued as inline asm with hand-counted lgkmcnt: hipcc otherwise orders every
+  // ds_read_b64_tr_b16 behind the LDS-DMA of the NEXT stage (s_waitcnt vmcnt(0) at the top of each step), which
+  // serialises the DMA with the MFMAs.  Byte address of (ks, t, i): lane_base[i] + buf*16384 + ks*4096 + t*1024.
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  unsigned abase[2], bbase[2];
+  {
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) u16*)lds;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int ca = wn * 64 + i * 32 + 16 * tg + 4 * tp, cb = wk * 64 + i * 32 + 16 * tg + 4 * tp;
+      abase[i] = lds0 + 2u * (unsigned)((8 * lh + tq) * 128 + (((ca >> 3) ^ (tq << 2)) << 3) + (ca & 7));
+      bbase[i] = lds0 + 2u * (unsigned)((8 * lh + tq) * 128 + (((cb >> 3) ^ (tq << 2)) << 3) + (cb & 7)) + 2u * 2 * BR * 128;
+    }
+  }
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#define TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
   const int nsteps = (r_end - r_begin + BR - 1) / BR;
-  gload(r_begin);
-  swrite(0);
+  stage(r_begin, 0);
   __syncthreads();
   for (int st = 0; st < nsteps; st++) {
     const int cur = st & 1;
-    if (st + 1 < nsteps) gload(r_begin + (st + 1) * BR);
-    const u16* as = As + cur * BR * 128;
-    const u16* bs = Bs + cur * BR * 128;
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) {          // 16 reduction rows per MFMA
-      bf16x8 af[2], bfr[2];
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-          const int r = 16 * ks + 8 * lh + 4 * t + tq;
-          const int ca = wn * 64 + i * 32 + 16 * tg + 4 * tp;      // element column inside the 128-wide tile
-          const int cb = wk * 64 + i * 32 + 16 * tg + 4 * tp;
-          const bf16x4 va = lds_read_tr16(as + tn_off(r, ca >> 3) + (ca & 7));
-          const bf16x4 vb = lds_read_tr16(bs + tn_off(r, cb >> 3) + (cb & 7));
-#pragma unroll
-          for (int e = 0; e < 4; e++) { af[i][4 * t + e] = va[e]; bfr[i][4 * t + e] = vb[e]; }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    if (st + 1 < nsteps) stage(r_begin + (st + 1) * BR, cur ^ 1);
+    const unsigned a0 = abase[0] + cur * 16384u, a1 = abase[1] + cur * 16384u;
+    const unsigned b0 = bbase[0] + cur * 16384u, b1 = bbase[1] + cur * 16384u;
+    u32x2 fa[2][2][2], fb[2][2][2];          // [parity][i][t]
+#define TN_ISSUE(KS, PAR)                                                        \
+    TR_READ(fa[PAR][0][0], a0, (KS) * 4096); TR_READ(fa[PAR][0][1], a0, (KS) * 4096 + 1024); \
+    TR_READ(fa[PAR][1][0], a1, (KS) * 4096); TR_READ(fa[PAR][1][1], a1, (KS) * 4096 + 1024); \
+    TR_READ(fb[PAR][0][0], b0, (KS) * 4096); TR_READ(fb[PAR][0][1], b0, (KS) * 4096 + 1024); \
+    TR_READ(fb[PAR][1][0], b1, (KS) * 4096); TR_READ(fb[PAR][1][1], b1, (KS) * 4096 + 1024);
+#define TN_MFMA(PAR)                                                             \
+    {                                                                            \
+      bf16x8 af[2], bfr[2];                                                      \
+      _Pragma("unroll") for (int i = 0; i < 2; i++) {                            \
+        const uint4 ua = make_uint4(fa[PAR][i][0][0], fa[PAR][i][0][1], fa[PAR][i][1][0], fa[PAR][i][1][1]); \
+        const uint4 ub = make_uint4(fb[PAR][i][0][0], fb[PAR][i][0][1], fb[PAR][i][1][0], fb[PAR][i][1][1]); \
+        af[i] = *reinterpret_cast<const bf16x8*>(&ua);                           \
+        bfr[i] = *reinterpret_cast<const bf16x8*>(&ub);                          \
+      }                                                                          \
+      _Pragma("unroll") for (int i = 0; i < 2; i++)                              \
+        _Pragma("unroll") for (int j = 0; j < 2; j++)                            \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0); \
     }
-    if (st + 1 < nsteps) swrite(cur ^ 1);
+    TN_ISSUE(0, 0)
+    TN_ISSUE(1, 1)
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    TN_MFMA(0)
+    __builtin_amdgcn_sched_barrier(0);
+    TN_ISSUE(2, 0)
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    TN_MFMA(1)
+    __builtin_amdgcn_sched_barrier(0);
+    TN_ISSUE(3, 1)
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    TN_MFMA(0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    TN_MFMA(1)
     __syncthreads();
   }
+#undef TN_ISSUE
+#undef TN_MFMA
+#undef TR_READ
   // C[n][k]: row n in registers, column k on the lane -> 128-byte contiguous atomic segments per row
   const int l31 = lane & 31;
 #pragma unroll
@@ -321,7 +539,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const u16* __restrict__ A,
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < N) atomicAdd(C + (int64_t)n * ldc + k, acc[i][j][r]);
+        if (n < N && !(dbg & 1)) atomicAdd(C + (int64_t)n * ldc + k, acc[i][j][r]);
+        if ((dbg & 1) && acc[i][j][r] == 123.456f) C[0] = 1.f;
       }
   }
 }
@@ -334,9 +553,11 @@ extern "C" int mca_gemm_tn_acc(const uint16_t* A, int64_t lda, const uint16_t* B
   if (R > (1LL << 30)) return MCA_E_UNSUPPORTED;
   const int tiles_n = (int)((N + 127) / 128), tiles_k = (int)((K + 127) / 128);
   const int tiles = tiles_n * tiles_k;
-  // split the reduction so that ~4 workgroups per CU are in flight, at least 4 steps of 64 rows each
-  int64_t splits = (1024 + tiles - 1) / tiles;
+  // split the reduction so that ~2-3 workgroups per CU are in flight (every split adds N*K*4 bytes of fp32 atomics),
+  // at least 4 steps of 64 rows each
+  int64_t splits = tiles <= 32 ? 512 / tiles : 1024 / tiles;        // one or two full rounds of 2 workgroups per CU
   const int64_t max_splits = (R + 4 * BR - 1) / (4 * BR);
+  if (g_knob[3] > 0) splits = g_knob[3];
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   if (splits > 65535) splits = 65535;
@@ -344,6 +565,6 @@ extern "C" int mca_gemm_tn_acc(const uint16_t* A, int64_t lda, const uint16_t* B
   rps = (rps + BR - 1) / BR * BR;
   splits = (R + rps - 1) / rps;
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, as_stream(stream), A, lda, B, ldb, C,
-                     ldc, (int)R, (int)N, (int)K, tiles_k, (int)rps);
+                     ldc, (int)R, (int)N, (int)K, tiles_k, (int)rps, g_knob[2]);
   return launch_status();
 }

@@ -45,10 +45,10 @@ class _Sched:
 
     def __init__(self, s, device):
         self.s = s
-        self.q_ptr, self.q_kt, self.q_full, self.q_order = (_dev(s.q_ptr, device), _dev(s.q_kt, device),
-                                                            _dev(s.q_full, device), _dev(s.q_order, device))
-        self.k_ptr, self.k_qt, self.k_full, self.k_order = (_dev(s.k_ptr, device), _dev(s.k_qt, device),
-                                                            _dev(s.k_full, device), _dev(s.k_order, device))
+        # tile index with the "structurally full" flag in bit 31: one scalar load per tile in the kernels
+        pack = lambda idx, full: (idx.astype(np.uint32) | (full.astype(np.uint32) << 31)).view(np.int32)
+        self.q_ptr, self.q_kt, self.q_order = _dev(s.q_ptr, device), _dev(pack(s.q_kt, s.q_full), device), _dev(s.q_order, device)
+        self.k_ptr, self.k_qt, self.k_order = _dev(s.k_ptr, device), _dev(pack(s.k_qt, s.k_full), device), _dev(s.k_order, device)
 
 
 class FusionEngine:
@@ -291,8 +291,7 @@ class FusionEngine:
         a.o, a.o_bstride, a.o_ld = o.data_ptr(), nq * o.stride(0), o.stride(0)
         a.lse = lse.data_ptr()
         a.qmask, a.keyinfo, a.ktile_flags = qmask.data_ptr(), ws["keyinfo"].data_ptr(), ws["kflags"].data_ptr()
-        a.q_ptr, a.q_kt, a.q_full, a.q_order = (sched.q_ptr.data_ptr(), sched.q_kt.data_ptr(), sched.q_full.data_ptr(),
-                                                sched.q_order.data_ptr())
+        a.q_ptr, a.q_kt, a.q_order = sched.q_ptr.data_ptr(), sched.q_kt.data_ptr(), sched.q_order.data_ptr()
         a.vmean = ws["vmean"].data_ptr()
         a.batch, a.heads, a.nq, a.nk, a.nk_pad = b, self.H, nq, N, self.nk_pad
         a.n_qtiles, a.n_ktiles, a.scale = sched.s.n_q, sched.s.n_k, self.scale
@@ -317,8 +316,7 @@ class FusionEngine:
         a.dk, a.dv = dkv.data_ptr() + dk_off * esz, dkv.data_ptr() + dv_off * esz
         a.dkv_bstride, a.dkv_ld = N * dkv_ld, dkv_ld
         a.qmask, a.keyinfo, a.ktile_flags = qmask.data_ptr(), ws["keyinfo"].data_ptr(), ws["kflags"].data_ptr()
-        a.k_ptr, a.k_qt, a.k_full, a.k_order = (sched.k_ptr.data_ptr(), sched.k_qt.data_ptr(), sched.k_full.data_ptr(),
-                                                sched.k_order.data_ptr())
+        a.k_ptr, a.k_qt, a.k_order = sched.k_ptr.data_ptr(), sched.k_qt.data_ptr(), sched.k_order.data_ptr()
         a.batch, a.heads, a.nq, a.nk, a.nk_pad = b, self.H, nq, N, self.nk_pad
         a.n_qtiles, a.n_ktiles, a.scale = sched.s.n_q, sched.s.n_k, self.scale
         hip.set_tag("pool" if nq != N else "layer")
@@ -509,8 +507,10 @@ class FusionEngine:
                            ws["delta"], ws["dq32"], N * D, ws["dqkv"], D, 2 * D, 3 * D, self.qmask_attn, self.sched_attn_b,
                            ws, b, N)
             call("mca_f32_to_bf16", ptr(ws["dq32"]), D, ptr(ws["dqkv"]), 3 * D, T, D, 1.0, stream_ptr())
-            self.gemm_tn_acc(ws["dqkv"], a["xn_b"], G(ly.attn.to_q.weight), T, D, D)
-            self.gemm_tn_acc(ws["dqkv"][:, D:], a["xn_b"], G(ly.attn.to_kv.weight), T, 2 * D, D)
+            # to_q.weight and to_kv.weight are adjacent in the flat gradient buffer: one (3D, D) weight-gradient GEMM
+            gq = G(ly.attn.to_q.weight)
+            assert G(ly.attn.to_kv.weight).data_ptr() == gq.data_ptr() + D * D * 4
+            self.gemm_tn_acc(ws["dqkv"], a["xn_b"], gq, T, 3 * D, D)
             self.gemm_nt(ws["dqkv"], w["qkvT"], dx_other, T, D, 3 * D, residual=dx)   # d xn = dqkv @ Wqkv + d x1
             self.ln_bwd(dx_other, D, ws["x"][i], g, a["m1"], a["r1"], T, D, G(g), dx=dx, dx_bf16=ws["dx_b"])  # dx = d x_in
             self._bucket_ready(bi + 1)

@@ -32,7 +32,7 @@ class AttnFwdArgs(C.Structure):
         ("k", C.c_void_p), ("v", C.c_void_p), ("kv_bstride", C.c_int64), ("kv_ld", C.c_int64),
         ("o", C.c_void_p), ("o_bstride", C.c_int64), ("o_ld", C.c_int64),
         ("lse", C.c_void_p), ("qmask", C.c_void_p), ("keyinfo", C.c_void_p), ("ktile_flags", C.c_void_p),
-        ("q_ptr", C.c_void_p), ("q_kt", C.c_void_p), ("q_full", C.c_void_p), ("q_order", C.c_void_p),
+        ("q_ptr", C.c_void_p), ("q_kt", C.c_void_p), ("q_order", C.c_void_p),
         ("vmean", C.c_void_p),
         ("batch", C.c_int), ("heads", C.c_int), ("nq", C.c_int), ("nk", C.c_int), ("nk_pad", C.c_int),
         ("n_qtiles", C.c_int), ("n_ktiles", C.c_int), ("scale", C.c_float),
@@ -48,7 +48,7 @@ class AttnBwdArgs(C.Structure):
         ("dq", C.c_void_p), ("dq_bstride", C.c_int64), ("dq_ld", C.c_int64),
         ("dk", C.c_void_p), ("dv", C.c_void_p), ("dkv_bstride", C.c_int64), ("dkv_ld", C.c_int64),
         ("qmask", C.c_void_p), ("keyinfo", C.c_void_p), ("ktile_flags", C.c_void_p),
-        ("k_ptr", C.c_void_p), ("k_qt", C.c_void_p), ("k_full", C.c_void_p), ("k_order", C.c_void_p),
+        ("k_ptr", C.c_void_p), ("k_qt", C.c_void_p), ("k_order", C.c_void_p),
         ("batch", C.c_int), ("heads", C.c_int), ("nq", C.c_int), ("nk", C.c_int), ("nk_pad", C.c_int),
         ("n_qtiles", C.c_int), ("n_ktiles", C.c_int), ("scale", C.c_float),
     ]

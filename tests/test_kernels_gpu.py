@@ -235,7 +235,7 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first):
     a.k, a.v, a.kv_bstride, a.kv_ld = qkv.data_ptr() + D * 2, vptr, N * 3 * D, 3 * D
     a.o, a.o_bstride, a.o_ld, a.lse = o.data_ptr(), nq * D, D, lse.data_ptr()
     a.qmask, a.keyinfo, a.ktile_flags = qmask.data_ptr(), keyinfo.data_ptr(), kflags.data_ptr()
-    a.q_ptr, a.q_kt, a.q_full, a.q_order = sf.q_ptr.data_ptr(), sf.q_kt.data_ptr(), sf.q_full.data_ptr(), sf.q_order.data_ptr()
+    a.q_ptr, a.q_kt, a.q_order = sf.q_ptr.data_ptr(), sf.q_kt.data_ptr(), sf.q_order.data_ptr()
     a.vmean = vmean.data_ptr()
     a.batch, a.heads, a.nq, a.nk, a.nk_pad, a.n_qtiles, a.n_ktiles, a.scale = b, heads, nq, N, nk_pad, sf.s.n_q, sf.s.n_k, 0.125
     H.call("mca_attn_fwd", C.byref(a), H.stream_ptr())
@@ -268,7 +268,7 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first):
     ab.dq, ab.dq_bstride, ab.dq_ld = dq.data_ptr(), nq * D, D
     ab.dk, ab.dv, ab.dkv_bstride, ab.dkv_ld = dkv.data_ptr() + D * 2, dkv.data_ptr() + 2 * D * 2, N * 3 * D, 3 * D
     ab.qmask, ab.keyinfo, ab.ktile_flags = qmask.data_ptr(), keyinfo.data_ptr(), kflags.data_ptr()
-    ab.k_ptr, ab.k_qt, ab.k_full, ab.k_order = sb.k_ptr.data_ptr(), sb.k_qt.data_ptr(), sb.k_full.data_ptr(), sb.k_order.data_ptr()
+    ab.k_ptr, ab.k_qt, ab.k_order = sb.k_ptr.data_ptr(), sb.k_qt.data_ptr(), sb.k_order.data_ptr()
     ab.batch, ab.heads, ab.nq, ab.nk, ab.nk_pad, ab.n_qtiles, ab.n_ktiles, ab.scale = b, heads, nq, N, nk_pad, sb.s.n_q, sb.s.n_k, 0.125
     H.call("mca_attn_bwd", C.byref(ab), H.stream_ptr())
     torch.cuda.synchronize()

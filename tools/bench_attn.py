@@ -1,0 +1,29 @@
+"""Times the layer attention kernels (fwd, bwd) on the CMU structure at b=32, H=8."""
+import importlib, os, sys, ctypes as C, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+P = importlib.import_module("mca-paper_amd"); H = importlib.import_module("mca-paper_amd.hip"); E = importlib.import_module("mca-paper_amd.engine")
+b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+cfg = P.config.cmu_model_config(batch_size=b)
+torch.manual_seed(0)
+model = P.MCA(**cfg).cuda(); eng = model.engine
+ws = eng.workspace(b)
+N, D, Hh = eng.N, eng.D, eng.H
+ws["padding"].zero_()
+H.call("mca_build_keyinfo", ws["padding"].data_ptr(), eng.kgroup.data_ptr(), ws["keyinfo"].data_ptr(), ws["kflags"].data_ptr(), b, N, eng.nk_pad, H.stream_ptr())
+a = ws["layers"][0]
+a["qkv"].copy_(torch.randn_like(a["qkv"].float()).bfloat16())
+ws["do"].copy_(torch.randn_like(ws["do"].float()).bfloat16())
+def fwd(): eng._attn_fwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], a["lse"], eng.qmask_attn, eng.sched_attn_f, ws, b, N)
+def bwd():
+    ws["dq32"].zero_()
+    eng._attn_bwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], ws["do"], a["lse"], ws["delta"], ws["dq32"], N*D, ws["dqkv"], D, 2*D, 3*D, eng.qmask_attn, eng.sched_attn_b, ws, b, N)
+def timeit(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    H.profile_start(("mca_attn_fwd", "mca_attn_bwd"))
+    for _ in range(n): fn()
+    return H.profile_stop()
+for nm, fn in (("fwd", fwd), ("bwd", bwd)):
+    r = timeit(fn)
+    for k, (n, ms, fl) in r.items():
+        print(f"{k}: {ms/n*1e3:.1f} us  {fl/ms/1e9:.1f} TF/s algorithmic ({fl/ms/1e9/2500*100:.1f}% of MFMA peak)")
