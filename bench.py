@@ -28,6 +28,23 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guid
 STEP_GFLOP = {"cmu_mca": 334.8, "cmu_mma": 337.4}
 
 
+def pmc_traffic(kernel_key: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 per
+    MI355X_MICROARCH.md section HBM, + WRITE_SIZE; separate --pmc passes of this same command, see profiles/README.md).
+    None when no PMC summary is committed for that kernel."""
+    path = os.path.join(REPO, "profiles", "r01_hbm_traffic_pmc.json")
+    names = {"mca_gemm_nt": "gemm_nt_256_kernel", "mca_gemm_tn_acc": "gemm_tn_kernel", "mca_attn_fwd/layer": "attn_fwd_kernel",
+             "mca_attn_bwd/layer": "attn_bwd_kernel"}
+    if not os.path.exists(path) or kernel_key not in names:
+        return None
+    tot_b, tot_n = 0.0, 0
+    for k, v in json.load(open(path)).items():
+        if names[kernel_key] in k:
+            tot_b += (v["fetch_MB_x2_gfx950"] + v["write_MB_per_launch"]) * 1e6 * v["launches"]
+            tot_n += v["launches"]
+    return {"bytes_per_launch": round(tot_b / tot_n), "source": "profiles/r01_hbm_traffic_pmc.json"} if tot_n else None
+
+
 def cpu_baseline(P, cfg, threads: int, b: int = 4):
     from oracle import mca_oracle as O
     torch.set_num_threads(threads)
@@ -145,7 +162,7 @@ def main():
             n, ms, fl = dom[1]
             ach = fl / (ms * 1e-3) / 1e12
             line["roofline"] = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom[0]),
                                 "avg_launch_us": round(ms / n * 1e3, 1), "alg_flops_per_launch": fl / n,
                                 "sampled_steps": sampled}
             line["kernels"] = kern
