@@ -34,7 +34,11 @@ def gather_pooled(pooled: torch.Tensor, present: torch.Tensor, group=None) -> Tu
     msg[:, : R * D] = pooled.reshape(b, R * D)
     msg[:, R * D] = present.to(torch.float32)             # <= 2^24: exact in fp32
     out = torch.empty(W * b, R * D + 1, dtype=torch.float32, device=pooled.device)
-    dist.all_gather_into_tensor(out, msg, group=group)
+    if dist.get_backend(group) == "gloo":          # CPU tests / single-GPU rehearsal: gloo has no flat all-gather on device tensors
+        parts = list(out.view(W, b, R * D + 1).unbind(0))
+        dist.all_gather(parts, msg, group=group)
+    else:
+        dist.all_gather_into_tensor(out, msg, group=group)
     pooled_all = out[:, : R * D].reshape(W * b, R, D).contiguous()
     present_all = out[:, R * D].to(torch.int32).contiguous()
     return pooled_all, present_all, rank * b
