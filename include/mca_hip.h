@@ -159,7 +159,7 @@ typedef struct {
   int batch, heads, nq, nk, nk_pad, n_qtiles, n_ktiles;
   float scale;
 } mca_attn_bwd_args;
-/* key block 256 (one workgroup), query step 32.                                                  */
+/* key block 256 (one workgroup), query step 64.                                                  */
 int mca_attn_bwd(const mca_attn_bwd_args* args, mca_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -13,11 +13,11 @@
 //     dK^T[d][key] += Q^T · dS        A = Q^T  (transposed reads),                         B = dS accumulators
 //     dQ[q][d]     += dS · K          dS crosses LDS once (transposed image), 16x16x32 MFMA, each wavefront
 //                                     owns one 16x16 block of the 32x64 dQ tile -> fp32 atomics to HBM
-// One barrier per query tile.
+// One barrier per 64-query step (two 32-row sub-tiles back to back, so the MFMAs of one overlap the VALU of the other).
 #include "common.h"
 
 #define BKEYS 256
-#define BQ 32
+#define BQ 64        // query rows per step: two 32-row sub-tiles between barriers
 #define DH 64
 
 // [32 rows][64 d] image used for BOTH row reads and transposed reads (Q and dO tiles)
@@ -32,11 +32,11 @@ __device__ __forceinline__ int ds_off(int key, int c) { return key * 32 + ((c ^ 
 
 __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a) {
   extern __shared__ __attribute__((aligned(16))) u16 lds[];
-  u16* Qs = lds;                               // 2 x 32 x 64
-  u16* Os = Qs + 2 * BQ * DH;                  // 2 x 32 x 64   (dO)
-  u16* Ds = Os + 2 * BQ * DH;                  // 2 x 256 x 32  (dS^T)
+  u16* Qs = lds;                               // 2 x 64 x 64
+  u16* Os = Qs + 2 * BQ * DH;                  // 2 x 64 x 64   (dO)
+  u16* Ds = Os + 2 * BQ * DH;                  // 2 x [2 sub-tiles] x 256 x 32  (dS^T)
   u16* Kimg = Ds + 2 * BKEYS * BQ;             // 256 x 64
-  float* rowc = reinterpret_cast<float*>(Kimg + BKEYS * DH);      // [2][3][32]: lse, delta, qmask(bits)
+  float* rowc = reinterpret_cast<float*>(Kimg + BKEYS * DH);      // [2][3][64]: lse, delta, qmask(bits)
 
   const int kbi = a.k_order[blockIdx.x];
   const int h = blockIdx.y, b = blockIdx.z;
@@ -78,25 +78,26 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a) {
   const float* lse_g = a.lse + ((int64_t)b * a.heads + h) * a.nq;
   const float* delta_g = a.delta + ((int64_t)b * a.heads + h) * a.nq;
 
-  // staging: threads 0..255 -> Q chunks, 256..511 -> dO chunks; threads 0..95 -> row constants
-  const int sid = tid & 255, srow = sid >> 3, sc = sid & 7;
-  bf16x8 stage;
+  // staging: a 64-row tile is 512 chunks of 16 B per operand: one Q chunk and one dO chunk per thread; threads
+  // 0..191 also carry the row constants (lse, delta, qmask)
+  const int srow = tid >> 3, sc = tid & 7;
+  bf16x8 stage_q, stage_o;
   float stage_c = 0.f;
   auto gload = [&](int qt) {
     int q = qt * BQ + srow; if (q > a.nq - 1) q = a.nq - 1;
-    if (tid < 256) stage = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)q * a.q_ld + sc * 8);
-    else stage = *reinterpret_cast<const bf16x8*>(obase + (int64_t)q * a.o_ld + sc * 8);
-    if (tid < 96) {
-      const int which = tid >> 5, r = tid & 31, qq = qt * BQ + r;
+    stage_q = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)q * a.q_ld + sc * 8);
+    stage_o = *reinterpret_cast<const bf16x8*>(obase + (int64_t)q * a.o_ld + sc * 8);
+    if (tid < 192) {
+      const int which = tid >> 6, r = tid & 63, qq = qt * BQ + r;
       if (which == 0) stage_c = qq < a.nq ? lse_g[qq] : INFINITY;          // rows past nq contribute nothing
       else if (which == 1) stage_c = qq < a.nq ? delta_g[qq] : 0.f;
       else stage_c = __uint_as_float(qq < a.nq ? a.qmask[qq] : 0u);
     }
   };
   auto swrite = [&](int buf) {
-    if (tid < 256) *reinterpret_cast<bf16x8*>(Qs + buf * BQ * DH + qd_off(srow, sc)) = stage;
-    else *reinterpret_cast<bf16x8*>(Os + buf * BQ * DH + qd_off(srow, sc)) = stage;
-    if (tid < 96) rowc[buf * 96 + tid] = stage_c;
+    *reinterpret_cast<bf16x8*>(Qs + buf * BQ * DH + qd_off(srow, sc)) = stage_q;
+    *reinterpret_cast<bf16x8*>(Os + buf * BQ * DH + qd_off(srow, sc)) = stage_o;
+    if (tid < 192) rowc[buf * 192 + tid] = stage_c;
   };
 
   const int it_begin = a.k_ptr[kbi], it_end = a.k_ptr[kbi + 1];
@@ -112,10 +113,12 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a) {
     const int qt = (int)(ent & 0x7fffffffu);
     const bool full = (ent >> 31) != 0;
     if (it + 1 < it_end) gload((int)(a.k_qt[it + 1] & 0x7fffffffu));
-    const u16* qs = Qs + buf * BQ * DH;
-    const u16* os = Os + buf * BQ * DH;
-    const float* rc = rowc + buf * 96;
-    u16* ds = Ds + buf * BKEYS * BQ;
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+    const u16* qs = Qs + buf * BQ * DH + sub * 32 * DH;
+    const u16* os = Os + buf * BQ * DH + sub * 32 * DH;
+    const float* rc = rowc + buf * 192 + sub * 32;
+    u16* ds = Ds + buf * BKEYS * BQ + sub * BKEYS * 32;
 
     // ---- S and dP (rows = q in registers, column = key on the lane)
     f32x16 s, dp;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a) {
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const f32x4 lse4 = *reinterpret_cast<const f32x4*>(rc + 8 * g + 4 * lh);
-        const f32x4 del4 = *reinterpret_cast<const f32x4*>(rc + 32 + 8 * g + 4 * lh);
+        const f32x4 del4 = *reinterpret_cast<const f32x4*>(rc + 64 + 8 * g + 4 * lh);
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int r = 4 * g + e;
@@ -148,8 +151,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a) {
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const f32x4 lse4 = *reinterpret_cast<const f32x4*>(rc + 8 * g + 4 * lh);
-        const f32x4 del4 = *reinterpret_cast<const f32x4*>(rc + 32 + 8 * g + 4 * lh);
-        const f32x4 qm4 = *reinterpret_cast<const f32x4*>(rc + 64 + 8 * g + 4 * lh);
+        const f32x4 del4 = *reinterpret_cast<const f32x4*>(rc + 64 + 8 * g + 4 * lh);
+        const f32x4 qm4 = *reinterpret_cast<const f32x4*>(rc + 128 + 8 * g + 4 * lh);
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int r = 4 * g + e;
@@ -189,34 +192,45 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a) {
         dk[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, sb[sp], dk[n], 0, 0, 0);
       }
 
+    }
     if (it + 1 < it_end) swrite(buf ^ 1);
     __syncthreads();
 
-    // ---- dQ tile (32 x 64) = dS (32 x 256) · K (256 x 64): this wavefront's 16x16 block, 8 k-steps of 32 keys.
-    //      key carried by (lane group g4, read t, element e): 32ks + 16(g4>>1) + 8t + 4(g4&1) + e
-    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) {
-      bf16x8 af, bfr;
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const int key = 32 * ks + 16 * (g4 >> 1) + 8 * t + 4 * (g4 & 1) + tq;
-        const int qc = qb * 16 + 4 * tp;          // q column inside the dS^T row
-        const int dc = db * 16 + 4 * tp;          // d column inside the K row
-        const bf16x4 a4 = lds_read_tr16(ds + ds_off(key, qc >> 3) + (qc & 7));
-        const bf16x4 b4 = lds_read_tr16(Kimg + kt_off(key, dc >> 3) + (dc & 7));
-#pragma unroll
-        for (int e = 0; e < 4; e++) { af[4 * t + e] = a4[e]; bfr[4 * t + e] = b4[e]; }
-      }
-      dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, dq, 0, 0, 0);
-    }
+    // ---- dQ tile (64 x 64) = dS (64 x 256) · K (256 x 64): per 32-row sub-tile this wavefront owns one 16x16 block,
+    //      8 k-steps of 32 keys.  key carried by (lane group g4, read t, element e): 32ks + 16(g4>>1) + 8t + 4(g4&1) + e
     {
+      const u16* dsb = Ds + buf * BKEYS * BQ;
+      f32x4 dq[2];
+      dq[0] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[1] = dq[0];
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        bf16x8 af[2], bfr;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const int key = 32 * ks + 16 * (g4 >> 1) + 8 * t + 4 * (g4 & 1) + tq;
+          const int qc = qb * 16 + 4 * tp;          // q column inside the dS^T row
+          const int dc = db * 16 + 4 * tp;          // d column inside the K row
+          const bf16x4 b4 = lds_read_tr16(Kimg + kt_off(key, dc >> 3) + (dc & 7));
+#pragma unroll
+          for (int sub = 0; sub < 2; sub++) {
+            const bf16x4 a4 = lds_read_tr16(dsb + sub * BKEYS * 32 + ds_off(key, qc >> 3) + (qc & 7));
+#pragma unroll
+            for (int e = 0; e < 4; e++) af[sub][4 * t + e] = a4[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; e++) bfr[4 * t + e] = b4[e];
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++) dq[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[sub], bfr, dq[sub], 0, 0, 0);
+      }
       float* dqp = a.dq + (int64_t)b * a.dq_bstride + h * DH + db * 16 + (lane & 15);
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int q = qt * BQ + qb * 16 + 4 * g4 + e;
-        if (q < a.nq) atomicAdd(dqp + (int64_t)q * a.dq_ld, dq[e] * a.scale);
-      }
+      for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int q = qt * BQ + sub * 32 + qb * 16 + 4 * g4 + e;
+          if (q < a.nq) atomicAdd(dqp + (int64_t)q * a.dq_ld, dq[sub][e] * a.scale);
+        }
     }
     buf ^= 1;
   }
@@ -242,7 +256,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a) {
   }
 }
 
-#define BWD_LDS_BYTES ((2 * BQ * DH * 2 + 2 * BKEYS * BQ + BKEYS * DH) * 2 + 2 * 96 * 4)
+#define BWD_LDS_BYTES ((2 * BQ * DH * 2 + 2 * BKEYS * BQ + BKEYS * DH) * 2 + 2 * 192 * 4)
 
 extern "C" int mca_attn_bwd(const mca_attn_bwd_args* a, mca_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->d_o || !a->lse || !a->delta || !a->dvmean || !a->dq || !a->dk || !a->dv ||

@@ -385,7 +385,7 @@ extern "C" int mca_reduce_rows(const float* src, int64_t lds, int64_t src_bstrid
   if (!src || !dst || rows < 0 || cols <= 0 || period <= 0) return MCA_E_BADARG;
   if (rows == 0) return MCA_OK;
   const int64_t ngroups = (rows + period - 1) / period;
-  int64_t slabs = ngroups < 64 ? ngroups : 64;
+  int64_t slabs = ngroups < 1024 ? ngroups : 1024;      // enough blocks to keep HBM busy on tall column sums
   // keep the grid reasonable when period is large
   while (slabs > 1 && slabs * period * ((cols + 255) / 256) > 65536) slabs /= 2;
   const int64_t gpb = (ngroups + slabs - 1) / slabs;

@@ -162,25 +162,35 @@ __global__ __launch_bounds__(256) void dgram_kernel(float* __restrict__ G, const
 
 // d_pooled[i_local][slot][:] = sum over terms with slot_a == slot of sum_j dG[i][j] b_j
 //                            + sum over terms with slot_b == slot of sum_i' dG[i'][i] a_i'
-// grid (R, b_local), block = 128 threads each covering D/128 strided columns
-__global__ __launch_bounds__(128) void dpooled_kernel(const float* __restrict__ dG, const float* __restrict__ pooled,
+// grid (R, b_local), block = 4 slices of the j / i' range x 128 columns, partial sums combined through LDS
+__global__ __launch_bounds__(512) void dpooled_kernel(const float* __restrict__ dG, const float* __restrict__ pooled,
                                                        const mca_loss_term* __restrict__ terms, int T, int B, int R, int D,
                                                        int row0, float* __restrict__ d_pooled) {
+  __shared__ float red[4][128];
   const int slot = blockIdx.x, il = blockIdx.y, i = row0 + il;
-  for (int d = threadIdx.x; d < D; d += 128) {
+  const int dl = threadIdx.x & 127, sl = threadIdx.x >> 7;
+  for (int d0 = 0; d0 < D; d0 += 128) {
+    const int d = d0 + dl;
     float acc = 0.f;
-    for (int t = 0; t < T; t++) {
-      const float* g = dG + (int64_t)t * B * B;
-      if (terms[t].slot_a == slot) {
-        const int sb = terms[t].slot_b;
-        for (int j = 0; j < B; j++) acc += g[(int64_t)i * B + j] * pooled[((int64_t)j * R + sb) * D + d];
-      }
-      if (terms[t].slot_b == slot) {
-        const int sa = terms[t].slot_a;
-        for (int k = 0; k < B; k++) acc += g[(int64_t)k * B + i] * pooled[((int64_t)k * R + sa) * D + d];
+    if (d < D) {
+      for (int t = 0; t < T; t++) {
+        const float* g = dG + (int64_t)t * B * B;
+        if (terms[t].slot_a == slot) {
+          const int sb = terms[t].slot_b;
+#pragma unroll 4
+          for (int j = sl; j < B; j += 4) acc += g[(int64_t)i * B + j] * pooled[((int64_t)j * R + sb) * D + d];
+        }
+        if (terms[t].slot_b == slot) {
+          const int sa = terms[t].slot_a;
+#pragma unroll 4
+          for (int k = sl; k < B; k += 4) acc += g[(int64_t)k * B + i] * pooled[((int64_t)k * R + sa) * D + d];
+        }
       }
     }
-    d_pooled[((int64_t)il * R + slot) * D + d] = acc;
+    red[sl][dl] = acc;
+    __syncthreads();
+    if (sl == 0 && d < D) d_pooled[((int64_t)il * R + slot) * D + d] = red[0][dl] + red[1][dl] + red[2][dl] + red[3][dl];
+    __syncthreads();
   }
 }
 
@@ -210,6 +220,6 @@ extern "C" int mca_contrastive_fwd_bwd(const float* pooled_all, const uint32_t* 
                      b_local, row0, w, term_loss, loss, d_logit_scale);
   int gx = (int)(((int64_t)B * B + 255) / 256); if (gx > 1024) gx = 1024;
   hipLaunchKernelGGL(dgram_kernel, dim3(gx, T), dim3(256), 0, s, G, stats, present_all, terms, w, logit_scale, B, b_local);
-  hipLaunchKernelGGL(dpooled_kernel, dim3(R, b_local), dim3(128), 0, s, G, pooled_all, terms, T, B, R, D, row0, d_pooled);
+  hipLaunchKernelGGL(dpooled_kernel, dim3(R, b_local), dim3(512), 0, s, G, pooled_all, terms, T, B, R, D, row0, d_pooled);
   return launch_status();
 }

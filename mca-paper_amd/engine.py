@@ -29,7 +29,7 @@ from .hip import AttnBwdArgs, AttnFwdArgs, LossTerm, call, ptr, stream_ptr
 
 LN_EPS = 1e-5
 FWD_BQ, FWD_BK = 128, 64
-BWD_BQ, BWD_BK = 32, 256
+BWD_BQ, BWD_BK = 64, 256
 
 
 def _pad_to(x: int, m: int) -> int:

@@ -39,7 +39,7 @@ def test_group_structure_reproduces_reference_masks(pkg):
         assert np.array_equal(st.token_types, OS.token_types.numpy())
 
 
-@pytest.mark.parametrize("bq,bk", [(128, 64), (32, 256)])
+@pytest.mark.parametrize("bq,bk", [(128, 64), (64, 256)])
 def test_tile_schedule_covers_exactly_the_allowed_pairs(pkg, bq, bk):
     S = pkg.structure
     st = S.FusionStructure([1500, 450, 450, 50], 88, (4, 3, 2), fcl=True)

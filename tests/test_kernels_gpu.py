@@ -189,7 +189,7 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first):
     qmask_np = st.qmask_pool if pool else st.qmask_attn
     nq = len(qmask_np)
     sf = eng._Sched(st.pool_schedule(128, 64) if pool else st.attn_schedule(128, 64), dev)
-    sb = eng._Sched(st.pool_schedule(32, 256) if pool else st.attn_schedule(32, 256), dev)
+    sb = eng._Sched(st.pool_schedule(64, 256) if pool else st.attn_schedule(64, 256), dev)
     qmask = torch.from_numpy(qmask_np.astype(np.uint32).view(np.int32)).to(dev)
     kgroup = torch.from_numpy(st.kgroup).to(dev)
     allowed = torch.from_numpy(~(st.dense_pool_mask() if pool else st.dense_attn_mask())).to(dev)
