@@ -236,7 +236,21 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(
 // global->LDS bytes per flop than the 128x128 tile.
 // ---------------------------------------------------------------------------------------------------------
 #define BM2 256
-template <bool OUT_BF16, int RES>
+__device__ __forceinline__ void wait_vmcnt(int n) {          // s_waitcnt needs an immediate
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+  }
+}
+// PF = 1 (fp32 output with a full-row residual, whole column tile inside N): the residual tile (256x128 fp32 =
+// 16 float4 per thread) is fetched into registers two pieces per k-step during the first 8 k-steps, so the epilogue
+// does not start with a 128 KiB read.  vmcnt counts DMA and residual loads together, in issue order: the wait in
+// front of step kt lets everything issued after stage kt's DMA stay in flight.
+template <bool OUT_BF16, int RES, int PF>
 __global__ __launch_bounds__(512) void gemm_nt_256_kernel(
     const u16* __restrict__ A, int64_t lda, const u16* __restrict__ B, int64_t ldb, void* __restrict__ Cv,
     int64_t ldc, const float* __restrict__ bias, const float* __restrict__ residual, int64_t ldres,
@@ -285,18 +299,44 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(
 
   const int nkt = K / 64;
   const NtFragAddr frag = nt_frag_addr(lds2, 0, BM2 * 64, wm, wn, l31, lh);
+  f32x4 rres[PF ? 16 : 1];
+  auto res_issue = [&](int it) -> f32x4 {          // piece `it` of this thread's share of the residual tile
+    const int id = tid + 512 * it, row = id >> 5, c0 = (id & 31) * 4;
+    const int m = m0 + row;
+    return m < M ? *reinterpret_cast<const f32x4*>(residual + (int64_t)m * ldres + n0 + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
   stage(0, 0);
   if (nkt > 1) stage(64, 1);
   int st = 0;
-  for (int kt = 0; kt < nkt; kt++) {
-    // this wave's DMA for stage kt has landed once at most the 6 loads of stage kt+1 are outstanding
-    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nkt) { int s2 = st + 2; if (s2 >= 3) s2 -= 3; stage((kt + 2) * 64, s2); }
-    nt_compute_step(frag, (unsigned)st * (unsigned)(STAGE * 2), acc);
-    st = st == 2 ? 0 : st + 1;
+#define NT256_STEP(KT, WAITN)                                                                  \
+  {                                                                                            \
+    wait_vmcnt(WAITN);                                                                         \
+    __builtin_amdgcn_s_barrier();                                                              \
+    if ((KT) + 2 < nkt) { int s2 = st + 2; if (s2 >= 3) s2 -= 3; stage(((KT) + 2) * 64, s2); } \
+    nt_compute_step(frag, (unsigned)st * (unsigned)(STAGE * 2), acc);                          \
+    st = st == 2 ? 0 : st + 1;                                                                 \
   }
+  if (PF) {
+    // nkt >= 8 is guaranteed by the host for PF kernels
+    NT256_STEP(0, 6)   rres[0] = res_issue(0);   rres[1 % (PF ? 16 : 1)] = res_issue(1);
+    NT256_STEP(1, 8)   rres[2 % (PF ? 16 : 1)] = res_issue(2);   rres[3 % (PF ? 16 : 1)] = res_issue(3);
+    NT256_STEP(2, 10)  rres[4 % (PF ? 16 : 1)] = res_issue(4);   rres[5 % (PF ? 16 : 1)] = res_issue(5);
+    NT256_STEP(3, 10)  rres[6 % (PF ? 16 : 1)] = res_issue(6);   rres[7 % (PF ? 16 : 1)] = res_issue(7);
+    NT256_STEP(4, 10)  rres[8 % (PF ? 16 : 1)] = res_issue(8);   rres[9 % (PF ? 16 : 1)] = res_issue(9);
+    NT256_STEP(5, 10)  rres[10 % (PF ? 16 : 1)] = res_issue(10); rres[11 % (PF ? 16 : 1)] = res_issue(11);
+    NT256_STEP(6, 10)  rres[12 % (PF ? 16 : 1)] = res_issue(12); rres[13 % (PF ? 16 : 1)] = res_issue(13);
+    NT256_STEP(7, nkt > 8 ? 10 : 4) rres[14 % (PF ? 16 : 1)] = res_issue(14); rres[15 % (PF ? 16 : 1)] = res_issue(15);
+    for (int kt = 8; kt < nkt; kt++) {
+      const int more = kt + 1 < nkt ? 6 : 0;
+      NT256_STEP(kt, kt == 8 ? 4 + more : (kt == 9 ? 2 + more : more))
+    }
+  } else {
+    for (int kt = 0; kt < nkt; kt++) {
+      // this wave's DMA for stage kt has landed once at most the 6 loads of stage kt+1 are outstanding
+      NT256_STEP(kt, kt + 1 < nkt ? 6 : 0)
+    }
+  }
+#undef NT256_STEP
   __syncthreads();
   // epilogue through LDS: 256x128 fp32 = 128 KiB
   float* cs = reinterpret_cast<float*>(lds2);
@@ -310,6 +350,22 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(
         cs[row * 128 + wn * 64 + j * 32 + l31] = acc[i][j][r];
       }
   __syncthreads();
+  if (PF) {
+    // fast epilogue: residual already in registers, whole 128-column tile valid, 16-byte stores
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int id = tid + 512 * it, row = id >> 5, c0 = (id & 31) * 4;
+      const int m = m0 + row;
+      if (m < M) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(cs + row * 128 + c0);
+        const f32x4 r = rres[it % (PF ? 16 : 1)];
+        v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+        if (bias) { v[0] += bias[n0 + c0]; v[1] += bias[n0 + c0 + 1]; v[2] += bias[n0 + c0 + 2]; v[3] += bias[n0 + c0 + 3]; }
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cv) + (int64_t)m * ldc + n0 + c0) = v;
+      }
+    }
+    return;
+  }
   constexpr int EPT = OUT_BF16 ? 8 : 4;
   constexpr int PPR = 128 / EPT;
 #pragma unroll 4
@@ -382,19 +438,22 @@ extern "C" int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, in
 #define NT_LAUNCH_G(OB, RS)                                                                                              \
   hipLaunchKernelGGL((gemm_nt_glds_kernel<OB, RS, 64>), dim3(nwg), dim3(256), 0, as_stream(stream), A, lda, B, ldb, C,   \
                      ldc, bias, residual, ldres, res_period, (int)M, (int)N, (int)K, tiles_n, nwg)
-#define NT_LAUNCH_256(OB, RS)                                                                                            \
+#define NT_LAUNCH_256(OB, RS, PFV)                                                                                          \
   do {                                                                                                                   \
     static bool attr = false;                                                                                            \
     if (!attr) {                                                                                                         \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<OB, RS>),                                 \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<OB, RS, PFV>),                            \
                               hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS_BYTES) != hipSuccess)                \
         return MCA_E_LAUNCH;                                                                                             \
       attr = true;                                                                                                       \
     }                                                                                                                    \
-    hipLaunchKernelGGL((gemm_nt_256_kernel<OB, RS>), dim3(nwg2), dim3(512), NT256_LDS_BYTES, as_stream(stream), A, lda,  \
+    hipLaunchKernelGGL((gemm_nt_256_kernel<OB, RS, PFV>), dim3(nwg2), dim3(512), NT256_LDS_BYTES, as_stream(stream), A, lda, \
                        B, ldb, C, ldc, bias, residual, ldres, res_period, (int)M, (int)N, (int)K, tiles_n, nwg2);        \
   } while (0)
-#define NT_PICK_PF(OB, RS) do { if (big) NT_LAUNCH_256(OB, RS); else NT_LAUNCH_G(OB, RS); } while (0)
+#define NT_PICK_PF(OB, RS) do { if (big) NT_LAUNCH_256(OB, RS, 0); else NT_LAUNCH_G(OB, RS); } while (0)
+  const bool pf = big && !out_bf16 && res == 1 && N % BN == 0 && K >= 512 && ldres % 4 == 0 && ldc % 4 == 0 &&
+                  (uintptr_t)residual % 16 == 0 && (uintptr_t)C % 16 == 0 && (!bias || (uintptr_t)bias % 4 == 0) && g_knob[4] != 1;
+  if (pf) { NT_LAUNCH_256(false, 1, 1); return launch_status(); }
   if (out_bf16) { if (res == 0) NT_PICK_PF(true, 0); else if (res == 1) NT_PICK_PF(true, 1); else NT_PICK_PF(true, 2); }
   else { if (res == 0) NT_PICK_PF(false, 0); else if (res == 1) NT_PICK_PF(false, 1); else NT_PICK_PF(false, 2); }
   return launch_status();

@@ -16,7 +16,7 @@ shapes = [("qkv  bf16", 1536, 512, True, False), ("out  f32+res", 512, 512, Fals
           ("ff2  f32+res", 512, 1408, False, True), ("dgrad ff2 bf16", 1408, 512, True, False), ("dgrad ff1 f32+res", 512, 2816, False, True),
           ("dgrad qkv f32+res", 512, 1536, False, True), ("plain f32", 512, 512, False, False), ("big-K bf16", 2048, 4096, True, False)]
 names = ["mca_gemm_nt"]
-pfs = [1, 0]
+pfs = [1, 0]   # knob 4: 1 = residual prefetch off
 for nm, N, K, obf, res in shapes:
     A = torch.randn(M, K, device=dev).bfloat16(); B = torch.randn(N, K, device=dev).bfloat16()
     C = torch.empty(M, N, device=dev, dtype=torch.bfloat16 if obf else torch.float32)
@@ -24,10 +24,10 @@ for nm, N, K, obf, res in shapes:
     fl = 2.0 * M * N * K
     row = f"{nm:20s} N={N:5d} K={K:5d}"
     for pf in pfs:
-        H.lib().mca_debug_set(1, pf)
+        H.lib().mca_debug_set(4, pf)
         fn_name = "mca_gemm_nt"
         ms = timeit(lambda: H.call(fn_name, A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), N, int(obf), None, H.ptr(R), N, 0, M, N, K, H.stream_ptr()))
-        row += f" | {['256x128','128x128'][pf]} {ms*1e3:7.1f} us {fl/ms/1e9:7.1f} TF"
+        row += f" | {['res-prefetch','no-prefetch'][pf]} {ms*1e3:7.1f} us {fl/ms/1e9:7.1f} TF"
     ms = timeit(lambda: torch.matmul(A, B.t()))
     row += f" | torch.matmul(bf16 out) {ms*1e3:7.1f} us {fl/ms/1e9:7.1f} TF"
     print(row, flush=True)
