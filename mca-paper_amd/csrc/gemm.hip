@@ -604,25 +604,178 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const u16* __restrict__ A,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// weight gradient, large variant: 256(n) x 128(k) output tile, 8 wavefronts (4x2, 64x64 each), three LDS stages of
+// [64 r][256 n] + [64 r][128 k] (144 KiB) filled by global_load_lds two steps ahead, one raw s_barrier per step with a
+// counted vmcnt (same pipeline as gemm_nt_256_kernel), transposed fragment reads in inline asm.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tn_off256(int r, int c) { return r * 256 + ((c ^ ((r & 3) << 2)) << 3); }
+
+__global__ __launch_bounds__(512) void gemm_tn_256_kernel(const u16* __restrict__ A, int64_t lda,
+                                                           const u16* __restrict__ B, int64_t ldb, float* __restrict__ C,
+                                                           int64_t ldc, int R, int N, int K, int tiles_k, int rows_per_split) {
+  extern __shared__ __attribute__((aligned(16))) u16 ldst[];
+  constexpr int STAGE = BR * (256 + 128);        // elements per stage
+  const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+  const int n0 = tn * 256, k0 = tk * 128;
+  const int r_begin = blockIdx.y * rows_per_split;
+  int r_end = r_begin + rows_per_split; if (r_end > R) r_end = R;
+  if (r_begin >= r_end) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int lh = lane >> 5;
+  const u16* zero = reinterpret_cast<const u16*>(g_zero16);
+
+  int arow[4], brow[2];
+  const u16* pa[4];
+  const u16* pb[2];
+  bool ca_ok[4], cb_ok[2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int p = (i * 8 + wave) * 64 + lane, r = p >> 5, c = (p & 31) ^ ((r & 3) << 2);
+    arow[i] = r; ca_ok[i] = n0 + c * 8 < N; pa[i] = A + n0 + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int p = (i * 8 + wave) * 64 + lane, r = p >> 4, c = (p & 15) ^ ((r & 3) << 2);
+    brow[i] = r; cb_ok[i] = k0 + c * 8 < K; pb[i] = B + k0 + c * 8;
+  }
+  auto stage = [&](int r0, int st) {
+    u16* base = ldst + st * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int r = r0 + arow[i];
+      const u16* src = (r < r_end && ca_ok[i]) ? pa[i] + (int64_t)r * lda : zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + (i * 8 + wave) * 512), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int r = r0 + brow[i];
+      const u16* src = (r < r_end && cb_ok[i]) ? pb[i] + (int64_t)r * ldb : zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + BR * 256 + (i * 8 + wave) * 512), 16, 0, 0);
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  unsigned abase[2], bbase[2];
+  {
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) u16*)ldst;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int ca = wn * 64 + i * 32 + 16 * tg + 4 * tp, cb = wk * 64 + i * 32 + 16 * tg + 4 * tp;
+      abase[i] = lds0 + 2u * (unsigned)((8 * lh + tq) * 256 + (((ca >> 3) ^ (tq << 2)) << 3) + (ca & 7));
+      bbase[i] = lds0 + 2u * (unsigned)(BR * 256) + 2u * (unsigned)((8 * lh + tq) * 128 + (((cb >> 3) ^ (tq << 2)) << 3) + (cb & 7));
+    }
+  }
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#define TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+  const int nsteps = (r_end - r_begin + BR - 1) / BR;
+  stage(r_begin, 0);
+  if (nsteps > 1) stage(r_begin + BR, 1);
+  int st = 0;
+  for (int sp = 0; sp < nsteps; sp++) {
+    if (sp + 1 < nsteps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (sp + 2 < nsteps) { int s2 = st + 2; if (s2 >= 3) s2 -= 3; stage(r_begin + (sp + 2) * BR, s2); }
+    const unsigned so = (unsigned)st * (unsigned)(STAGE * 2);
+    const unsigned a0 = abase[0] + so, a1 = abase[1] + so, b0 = bbase[0] + so, b1 = bbase[1] + so;
+    u32x2 fa[2][2][2], fb[2][2][2];          // [parity][i][t]
+#define TN_ISSUE(KS, PAR)                                                        \
+    TR_READ(fa[PAR][0][0], a0, (KS) * 8192); TR_READ(fa[PAR][0][1], a0, (KS) * 8192 + 2048); \
+    TR_READ(fa[PAR][1][0], a1, (KS) * 8192); TR_READ(fa[PAR][1][1], a1, (KS) * 8192 + 2048); \
+    TR_READ(fb[PAR][0][0], b0, (KS) * 4096); TR_READ(fb[PAR][0][1], b0, (KS) * 4096 + 1024); \
+    TR_READ(fb[PAR][1][0], b1, (KS) * 4096); TR_READ(fb[PAR][1][1], b1, (KS) * 4096 + 1024);
+#define TN_MFMA(PAR)                                                             \
+    {                                                                            \
+      bf16x8 af[2], bfr[2];                                                      \
+      _Pragma("unroll") for (int i = 0; i < 2; i++) {                            \
+        const uint4 ua = make_uint4(fa[PAR][i][0][0], fa[PAR][i][0][1], fa[PAR][i][1][0], fa[PAR][i][1][1]); \
+        const uint4 ub = make_uint4(fb[PAR][i][0][0], fb[PAR][i][0][1], fb[PAR][i][1][0], fb[PAR][i][1][1]); \
+        af[i] = *reinterpret_cast<const bf16x8*>(&ua);                           \
+        bfr[i] = *reinterpret_cast<const bf16x8*>(&ub);                          \
+      }                                                                          \
+      _Pragma("unroll") for (int i = 0; i < 2; i++)                              \
+        _Pragma("unroll") for (int j = 0; j < 2; j++)                            \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0); \
+    }
+    TN_ISSUE(0, 0)
+    TN_ISSUE(1, 1)
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    TN_MFMA(0)
+    __builtin_amdgcn_sched_barrier(0);
+    TN_ISSUE(2, 0)
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    TN_MFMA(1)
+    __builtin_amdgcn_sched_barrier(0);
+    TN_ISSUE(3, 1)
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    TN_MFMA(0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    TN_MFMA(1)
+    st = st == 2 ? 0 : st + 1;
+  }
+#undef TN_ISSUE
+#undef TN_MFMA
+#undef TR_READ
+  const int l31 = lane & 31;
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int k = k0 + wk * 64 + j * 32 + l31;
+    if (k >= K) continue;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n < N) atomicAdd(C + (int64_t)n * ldc + k, acc[i][j][r]);
+      }
+  }
+}
+#define TN256_LDS_BYTES (3 * BR * (256 + 128) * 2)
+
 extern "C" int mca_gemm_tn_acc(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,
                                int64_t R, int64_t N, int64_t K, mca_stream_t stream) {
   if (!A || !B || !C || R <= 0 || N <= 0 || K <= 0) return MCA_E_BADARG;
   if (lda % 8 || ldb % 8 || (uintptr_t)A % 16 || (uintptr_t)B % 16) return MCA_E_ALIGN;
   if (lda < (N + 7) / 8 * 8 || ldb < (K + 7) / 8 * 8 || ldc < K) return MCA_E_BADARG;
   if (R > (1LL << 30)) return MCA_E_UNSUPPORTED;
-  const int tiles_n = (int)((N + 127) / 128), tiles_k = (int)((K + 127) / 128);
+  const bool big = N >= 512 && R >= 4096 && g_knob[5] != 1;          // knob 5 = 1 forces the 128x128 kernel
+  const int tiles_k = (int)((K + 127) / 128);
+  const int tiles_n = big ? (int)((N + 255) / 256) : (int)((N + 127) / 128);
   const int tiles = tiles_n * tiles_k;
-  // split the reduction so that ~2-3 workgroups per CU are in flight (every split adds N*K*4 bytes of fp32 atomics),
-  // at least 4 steps of 64 rows each
-  int64_t splits = tiles <= 32 ? 512 / tiles : 1024 / tiles;        // one or two full rounds of 2 workgroups per CU
-  const int64_t max_splits = (R + 4 * BR - 1) / (4 * BR);
+  // split the reduction: one (big: 1 WG/CU) or two (2 WGs/CU) full rounds of workgroups; every split adds N*K*4 bytes
+  // of fp32 atomics; at least 4 steps of 64 rows each
+  int64_t splits = big ? (tiles <= 16 ? 256 / tiles : 512 / tiles) : (tiles <= 32 ? 512 / tiles : 1024 / tiles);
   if (g_knob[3] > 0) splits = g_knob[3];
+  const int64_t max_splits = (R + 4 * BR - 1) / (4 * BR);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   if (splits > 65535) splits = 65535;
   int64_t rps = (R + splits - 1) / splits;
   rps = (rps + BR - 1) / BR * BR;
   splits = (R + rps - 1) / rps;
+  if (big) {
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              TN256_LDS_BYTES) != hipSuccess)
+        return MCA_E_LAUNCH;
+      attr = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_256_kernel, dim3(tiles, (unsigned)splits), dim3(512), TN256_LDS_BYTES, as_stream(stream), A, lda, B,
+                       ldb, C, ldc, (int)R, (int)N, (int)K, tiles_k, (int)rps);
+    return launch_status();
+  }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, as_stream(stream), A, lda, B, ldb, C,
                      ldc, (int)R, (int)N, (int)K, tiles_k, (int)rps, g_knob[2]);
   return launch_status();
