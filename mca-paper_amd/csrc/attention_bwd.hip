@@ -30,7 +30,7 @@ __device__ __forceinline__ int kt_off(int key, int c) { return key * 64 + ((c ^ 
 // [256 keys][32 q] dS^T image (64-byte rows)
 __device__ __forceinline__ int ds_off(int key, int c) { return key * 32 + ((c ^ ((key >> 1) & 3)) << 3); }
 
-__global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a) {
+__global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int dbg) {
   extern __shared__ __attribute__((aligned(16))) u16 lds[];
   u16* Qs = lds;                               // 2 x 64 x 64
   u16* Os = Qs + 2 * BQ * DH;                  // 2 x 64 x 64   (dO)
@@ -229,7 +229,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a) {
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int q = qt * BQ + sub * 32 + qb * 16 + 4 * g4 + e;
-          if (q < a.nq) atomicAdd(dqp + (int64_t)q * a.dq_ld, dq[sub][e] * a.scale);
+          if (q < a.nq && !(dbg & 1)) atomicAdd(dqp + (int64_t)q * a.dq_ld, dq[sub][e] * a.scale);
+          if ((dbg & 1) && dq[sub][e] == 123.456f) dqp[0] = 1.f;
         }
     }
     buf ^= 1;
@@ -279,7 +280,7 @@ extern "C" int mca_attn_bwd(const mca_attn_bwd_args* a, mca_stream_t stream) {
       return MCA_E_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(a->n_ktiles, a->heads, a->batch), dim3(512), BWD_LDS_BYTES, as_stream(stream), *a);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(a->n_ktiles, a->heads, a->batch), dim3(512), BWD_LDS_BYTES, as_stream(stream), *a, mca_knobs[6]);
   return launch_status();
 }
 

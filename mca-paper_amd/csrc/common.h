@@ -39,5 +39,7 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const u16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3)))*)(p));
 }
 
+extern int mca_knobs[8];      // A/B measurement knobs, set through mca_debug_set (defined in optim.hip)
+
 static inline hipStream_t as_stream(mca_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? MCA_OK : MCA_E_LAUNCH; }

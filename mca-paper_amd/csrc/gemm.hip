@@ -16,7 +16,7 @@
 // A panel from that XCD's L2.
 #include "common.h"
 
-static int g_knob[8];      // A/B measurement knobs (mca_debug_set)
+#define g_knob mca_knobs     // A/B measurement knobs (mca_debug_set, optim.hip)
 
 #define BM 128
 #define BN 128
@@ -421,7 +421,6 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(
 }
 #define NT256_LDS_BYTES (3 * (BM2 + BN) * 64 * 2)
 
-extern "C" int mca_debug_set(int key, int value) { if (key >= 0 && key < 8) g_knob[key] = value; return 0; }
 
 extern "C" int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
                            int out_bf16, const float* bias, const float* residual, int64_t ldres,

@@ -23,7 +23,9 @@ def timeit(fn, n=10):
     H.profile_start(("mca_attn_fwd", "mca_attn_bwd"))
     for _ in range(n): fn()
     return H.profile_stop()
-for nm, fn in (("fwd", fwd), ("bwd", bwd)):
+for nm, fn, knob in (("fwd", fwd, 0), ("bwd", bwd, 0), ("bwd no-atomics", bwd, 1)):
+    H.lib().mca_debug_set(6, knob)
     r = timeit(fn)
+    print(nm, end=" -> ")
     for k, (n, ms, fl) in r.items():
         print(f"{k}: {ms/n*1e3:.1f} us  {fl/ms/1e9:.1f} TF/s algorithmic ({fl/ms/1e9/2500*100:.1f}% of MFMA peak)")
