@@ -89,6 +89,9 @@ int mca_geglu_bwd(const uint16_t* dg, const uint16_t* h, uint16_t* dh, int64_t r
 int mca_cast_pad_bf16(const float* src, int64_t lds, int64_t rows, int64_t cols,
                       uint16_t* dst, int64_t ldd, int64_t rows_pad, int64_t cols_pad, int transpose,
                       mca_stream_t stream);
+/* the same for n tensors in ONE launch; descs_dev is a device array (built once by the caller)   */
+typedef struct { const void* src; void* dst; int64_t lds, rows, cols, ldd, rows_pad, cols_pad; int32_t transpose, pad_; } mca_cast_desc;
+int mca_cast_pad_bf16_multi(const mca_cast_desc* descs_dev, int n, mca_stream_t stream);
 /* dst[r*ldd + c] = bf16(src[r*lds + c] * scale) */
 int mca_f32_to_bf16(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t rows, int64_t cols,
                     float scale, mca_stream_t stream);

@@ -323,6 +323,26 @@ extern "C" int mca_cast_pad_bf16(const float* src, int64_t lds, int64_t rows, in
   return launch_status();
 }
 
+// multi-tensor form of the above: one launch refreshes every bf16 weight copy (descriptor table in device memory)
+__global__ __launch_bounds__(256) void cast_pad_multi_kernel(const mca_cast_desc* __restrict__ descs) {
+  const mca_cast_desc d = descs[blockIdx.y];
+  const float* src = reinterpret_cast<const float*>(d.src);
+  u16* dst = reinterpret_cast<u16*>(d.dst);
+  const int64_t total = d.rows_pad * d.cols_pad;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / d.cols_pad, c = idx % d.cols_pad;
+    float v = 0.f;
+    if (!d.transpose) { if (r < d.rows && c < d.cols) v = src[r * d.lds + c]; }
+    else { if (c < d.rows && r < d.cols) v = src[c * d.lds + r]; }
+    dst[r * d.ldd + c] = f2bf(v);
+  }
+}
+extern "C" int mca_cast_pad_bf16_multi(const mca_cast_desc* descs_dev, int n, mca_stream_t stream) {
+  if (!descs_dev || n <= 0 || n > 65535) return MCA_E_BADARG;
+  hipLaunchKernelGGL(cast_pad_multi_kernel, dim3(64, n), dim3(256), 0, as_stream(stream), descs_dev);
+  return launch_status();
+}
+
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, int64_t lds,
                                                            u16* __restrict__ dst, int64_t ldd, int64_t rows,
                                                            int64_t cols4, float scale) {

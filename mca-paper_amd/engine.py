@@ -166,16 +166,22 @@ class FusionEngine:
                 self.we[name] = dict(w2=bf(D, D), w2T=bf(D, D))
 
     def _cast(self, src: torch.Tensor, dst: torch.Tensor, transpose=False, dst_row0=0, dst_col0=0):
-        """dst[dst_row0:, dst_col0:] (bf16) <- src (fp32 2-D), zero padding untouched (buffers start zeroed)."""
+        """dst[dst_row0:, dst_col0:] (bf16) <- src (fp32 2-D), zero padding untouched (buffers start zeroed).  Only
+        RECORDS the copy: all of them run as one multi-tensor launch (the parameter / copy addresses never change)."""
         r, c = src.shape
         d = dst[dst_row0:, dst_col0:]
         rp, cp = (c, r) if transpose else (r, c)
-        call("mca_cast_pad_bf16", ptr(src), src.stride(0), r, c, ptr(d), dst.stride(0), rp, cp, int(transpose), stream_ptr())
+        self._cast_list.append(hip.CastDesc(ptr(src), ptr(d), src.stride(0), r, c, dst.stride(0), rp, cp, int(transpose), 0))
 
     def refresh_weights(self, force=False):
         v = self.flat._version
         if not force and v == self._weights_version:
             return
+        if getattr(self, "_cast_table", None) is not None:
+            call("mca_cast_pad_bf16_multi", ptr(self._cast_table), self._cast_n, stream_ptr())
+            self._weights_version = v
+            return
+        self._cast_list = []
         m, D, I, Ip = self.model, self.D, self.I, self.Ip
         for i, ly in enumerate(m.layers):
             w = self.wl[i]
@@ -205,6 +211,10 @@ class FusionEngine:
             elif isinstance(enc, TabularEncoder):
                 self._cast(enc.value_encoder.linear2.weight.data, self.we[name]["w2"])
                 self._cast(enc.value_encoder.linear2.weight.data, self.we[name]["w2T"], transpose=True)
+        arr = (hip.CastDesc * len(self._cast_list))(*self._cast_list)
+        self._cast_n = len(self._cast_list)
+        self._cast_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        call("mca_cast_pad_bf16_multi", ptr(self._cast_table), self._cast_n, stream_ptr())
         self._weights_version = v
 
     # ------------------------------------------------------------------------------------------------
@@ -562,6 +572,10 @@ class FusionEngine:
     # model-level forward (autograd node)
     # ------------------------------------------------------------------------------------------------
     def model_forward(self, batch, no_loss=False):
+        with hip.cached_stream():
+            return self._model_forward(batch, no_loss)
+
+    def _model_forward(self, batch, no_loss=False):
         m = self.model
         first = batch[m.modality_types[0]]
         b = next(iter(first.values())).shape[0]
@@ -635,7 +649,8 @@ class _MCAStep(torch.autograd.Function):
             d_pooled = d_pooled + g_pooled
         params = engine.param_order
         live = params[0].grad is not None and params[0].grad.data_ptr() == engine.grad_of(params[0]).data_ptr()
-        engine.backward(ws, d_pooled, res["d_logit"] * g_loss.reshape(()), accumulate=live)
+        with hip.cached_stream():
+            engine.backward(ws, d_pooled, res["d_logit"] * g_loss.reshape(()), accumulate=live)
         for p in params:
             p.grad = engine.grad_of(p)
         return (None, None, None, None) + tuple(None for _ in params)

@@ -26,6 +26,11 @@ class LossTerm(C.Structure):
     _fields_ = [("slot_a", C.c_int32), ("slot_b", C.c_int32), ("and_bits", C.c_uint32), ("or_bits", C.c_uint32)]
 
 
+class CastDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("lds", C.c_int64), ("rows", C.c_int64), ("cols", C.c_int64),
+                ("ldd", C.c_int64), ("rows_pad", C.c_int64), ("cols_pad", C.c_int64), ("transpose", C.c_int32), ("pad_", C.c_int32)]
+
+
 class AttnFwdArgs(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("q_bstride", C.c_int64), ("q_ld", C.c_int64),
@@ -67,6 +72,7 @@ SIGNATURES = {
     "mca_geglu_fwd": (_I, [_P, _P, _I64, _I, _P]),
     "mca_geglu_bwd": (_I, [_P, _P, _P, _I64, _I, _P]),
     "mca_cast_pad_bf16": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I, _P]),
+    "mca_cast_pad_bf16_multi": (_I, [_P, _I, _P]),
     "mca_f32_to_bf16": (_I, [_P, _I64, _P, _I64, _I64, _I64, _F, _P]),
     "mca_bcast_rows": (_I, [_P, _I64, _P, _I64, _I64, _I64, _I64, _I, _P]),
     "mca_reduce_rows": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I, _P]),
@@ -104,8 +110,26 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_STREAM_CACHE = None     # set by the engine for the duration of a step (the stream does not change inside it)
+
+
 def stream_ptr() -> int:
+    if _STREAM_CACHE is not None:
+        return _STREAM_CACHE
     return torch.cuda.current_stream().cuda_stream
+
+
+class cached_stream:
+    """context manager: query torch's current stream once and reuse the handle for every launch inside."""
+
+    def __enter__(self):
+        global _STREAM_CACHE
+        self.prev = _STREAM_CACHE
+        _STREAM_CACHE = torch.cuda.current_stream().cuda_stream
+
+    def __exit__(self, *exc):
+        global _STREAM_CACHE
+        _STREAM_CACHE = self.prev
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
