@@ -294,6 +294,13 @@ def test_attention_cmu_shape(H, variant, pool):
     _attention_case(H, st, b=2, heads=2, pool=pool, seed=12, drop_first=True)
 
 
+def test_attention_long_sequence_shape(H):
+    """BASELINE config 5 shape: every modality padded to 1500 tokens (N = 6088, 96 key tiles)."""
+    S = importlib.import_module("mca-paper_amd.structure")
+    st = S.FusionStructure([1500, 1500, 1500, 1500], 88, (4, 3, 2), fcl=True)
+    _attention_case(H, st, b=1, heads=2, pool=False, seed=13, drop_first=False)
+
+
 # ------------------------------------------------------------------------------------------------ loss
 @pytest.mark.parametrize("variant,world", [("mca", 1), ("bimodal", 1), ("zorro", 1), ("mca", 2), ("bimodal", 4)])
 def test_contrastive_loss(H, variant, world):

@@ -162,6 +162,27 @@ def test_tcga_shape_b2_vs_oracle(P):
     assert abs(nat["grad_norm"] - ref["grad_norm"]) < TOL_GN * ref["grad_norm"]
 
 
+def test_long_sequence_step_runs(P):
+    """BASELINE config 5 layout (4 x 1500 tokens + 88 fusion = 6088) at a small batch: the step runs, loss finite, every
+    parameter receives a finite gradient."""
+    optim = importlib.import_module("mca-paper_amd.optim")
+    cfg = P.config.cmu_model_config(batch_size=2, long_seq=True)
+    torch.manual_seed(1)
+    model = P.MCA(**copy.deepcopy(cfg)).cuda()
+    opt = optim.FusedAdamW(model, lr=1e-4)
+    batch = to_device(P.data.synthetic_batch(cfg, 2, seed=3, p_drop=0.2), "cuda")
+    out = model(batch)
+    opt.zero_grad()
+    out["loss"].backward()
+    optim.clip_grad_norm_(model, 2.0)
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["loss"])
+    for n, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        assert torch.isfinite(p).all(), n
+
+
 def test_dropin_loop_and_no_loss(P):
     """the reference's loop shape (train_accel_gpu.py:108-119) runs unchanged; no_loss returns embeddings only."""
     optim = importlib.import_module("mca-paper_amd.optim")
