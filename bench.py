@@ -120,7 +120,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    timed = ("mca_attn_fwd", "mca_attn_bwd", "mca_gemm_nt", "mca_gemm_tn_acc")
+    timed = ("mca_attn_fwd", "mca_attn_bwd", "mca_gemm_nt", "mca_gemm_nt_geglu_bwd", "mca_gemm_tn_acc")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -129,10 +129,14 @@ def main():
     t0 = time.perf_counter()
     sampled = 0
     for i in range(args.steps):
-        rec = (i % args.sample_every) == 0
+        rec = (not args.no_kernel_timing) and (i % args.sample_every) == 0
         hip.profile_enable(rec)
         sampled += int(rec)
+        if rec:
+            torch.cuda.synchronize()          # sampled step starts on an empty queue ...
         loss = step()
+        if rec:
+            hip.profile_collect()             # ... and its timing events are resolved and released right away
     hip.profile_enable(True)
     torch.cuda.synchronize()
     if world > 1:

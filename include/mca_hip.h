@@ -44,6 +44,11 @@ int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
                 const float* bias, const float* residual, int64_t ldres, int64_t res_period,
                 int64_t M, int64_t N, int64_t K, mca_stream_t stream);
 
+/* Fused data-gradient GEMM + GEGLU backward (model.py:35-54 autograd): dg = A[M,K]·B[ip,K]^T is never stored;
+ * dh[:, n] = dg*gelu(gate), dh[:, ip+n] = dg*a*gelu'(gate) with h = [a | gate].  h, dh: bf16 [M, 2*ip], row stride ldh. */
+int mca_gemm_nt_geglu_bwd(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* h,
+                          uint16_t* dh, int64_t ldh, int64_t ip, int64_t M, int64_t K, mca_stream_t stream);
+
 /* C[N,K] += A[R,N]^T · B[R,K]   (weight gradient: reduction over the R token rows; fp32 atomics
  * into C, which the caller zeroes once per step).  lda/ldb % 8 == 0; N and K are arbitrary but the
  * rows of A / B must be readable up to the next multiple of 8 columns (lda >= roundup8(N) etc.).  */

@@ -39,6 +39,14 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const u16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3)))*)(p));
 }
 
+// exact (erf) GELU and its derivative (model.py:38 F.gelu default)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
 extern int mca_knobs[8];      // A/B measurement knobs, set through mca_debug_set (defined in optim.hip)
 
 static inline hipStream_t as_stream(mca_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

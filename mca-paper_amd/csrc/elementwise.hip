@@ -230,13 +230,6 @@ extern "C" int mca_layernorm_bwd(const float* dy, int64_t ldy, int64_t y_bstride
 // =====================================================================================================
 // GEGLU (model.py:35-38).  h = [a | gate], g = gelu_erf(gate) * a.  8 bf16 per lane per access.
 // =====================================================================================================
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
-}
-
 __global__ __launch_bounds__(256) void geglu_fwd_kernel(const u16* __restrict__ h, u16* __restrict__ g,
                                                          int64_t rows, int ip) {
   const int chunks = ip / 8;

@@ -34,11 +34,28 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // all 64 banks exactly once.
 __device__ __forceinline__ int nt_off(int r, int c) { return r * 64 + ((c ^ ((r >> 1) & 7)) << 3); }
 
+// Fused GEGLU backward (model.py:35-38 autograd) for 8 consecutive columns n..n+7 of row m of dg = dY·W2 (fp32 in v):
+// h = [a | gate] (bf16, row stride ldh, halves ip apart);  dh_a = dg*gelu(gate),  dh_gate = dg*a*gelu'(gate).
+__device__ __forceinline__ void geglu_bwd_piece(const float (&v)[8], const u16* __restrict__ h, u16* __restrict__ dh, int64_t ldh,
+                                                int ip, int64_t m, int n) {
+  const bf16x8 av = *reinterpret_cast<const bf16x8*>(h + m * ldh + n);
+  const bf16x8 gv = *reinterpret_cast<const bf16x8*>(h + m * ldh + ip + n);
+  bf16x8 da, dgt;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const float g = bf2f((u16)gv[e]), a = bf2f((u16)av[e]);
+    da[e] = (short)f2bf(v[e] * gelu_erf(g));
+    dgt[e] = (short)f2bf(v[e] * a * gelu_erf_grad(g));
+  }
+  *reinterpret_cast<bf16x8*>(dh + m * ldh + n) = da;
+  *reinterpret_cast<bf16x8*>(dh + m * ldh + ip + n) = dgt;
+}
+
 // Epilogue through LDS (BK = 64 kernels: the 64 KiB of operand buffers hold exactly one 128x128 fp32 tile).  The
 // accumulators are written lane = column / register = row, then every thread reads whole 16-byte pieces of rows,
 // adds bias / residual with 16-byte loads and stores 16 bytes: 4x (fp32) or 8x (bf16) fewer store instructions,
 // every global access a full 128-byte-line segment of a row.
-template <bool OUT_BF16, int RES>
+template <bool OUT_BF16, int RES, int EPI>
 __device__ __forceinline__ void nt_epilogue_lds(f32x16 (&acc)[2][2], float* __restrict__ cs, void* __restrict__ Cv, int64_t ldc,
                                                 const float* __restrict__ bias, const float* __restrict__ residual,
                                                 int64_t ldres, int64_t res_period, int M, int N, int m0, int n0, int wm, int wn,
@@ -68,6 +85,11 @@ __device__ __forceinline__ void nt_epilogue_lds(f32x16 (&acc)[2][2], float* __re
       v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
     }
     const bool full = n + EPT <= N;
+    if (EPI == 1) {          // GEGLU backward: Cv = dh, residual = h (bf16), ldres = row stride of both, N = ip (multiple of 8)
+      if (OUT_BF16) geglu_bwd_piece(reinterpret_cast<const float(&)[8]>(v), reinterpret_cast<const u16*>(residual),
+                                    reinterpret_cast<u16*>(Cv), ldres, N, (int64_t)m, n);
+      continue;
+    }
     if (bias) {
 #pragma unroll
       for (int e = 0; e < EPT; e++) if (full || n + e < N) v[e] += bias[n + e];
@@ -165,7 +187,7 @@ __device__ __forceinline__ void nt_compute_step(const NtFragAddr& f, unsigned st
 #undef NT_MFMA
 }
 
-template <bool OUT_BF16, int RES, int BKT>
+template <bool OUT_BF16, int RES, int BKT, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(
     const u16* __restrict__ A, int64_t lda, const u16* __restrict__ B, int64_t ldb, void* __restrict__ Cv,
     int64_t ldc, const float* __restrict__ bias, const float* __restrict__ residual, int64_t ldres,
@@ -225,7 +247,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(
     __syncthreads();          // waits for this wave's LDS-DMA (vmcnt(0)) and for every wave's reads of `cur`
   }
   static_assert(BKT == 64, "the LDS epilogue needs the 64 KiB of operand buffers");
-  nt_epilogue_lds<OUT_BF16, RES>(acc, reinterpret_cast<float*>(lds), Cv, ldc, bias, residual, ldres, res_period, M, N, m0, n0,
+  nt_epilogue_lds<OUT_BF16, RES, EPI>(acc, reinterpret_cast<float*>(lds), Cv, ldc, bias, residual, ldres, res_period, M, N, m0, n0,
                                  wm, wn, l31, lh, tid);
 }
 
@@ -250,7 +272,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {          // s_waitcnt needs 
 // 16 float4 per thread) is fetched into registers two pieces per k-step during the first 8 k-steps, so the epilogue
 // does not start with a 128 KiB read.  vmcnt counts DMA and residual loads together, in issue order: the wait in
 // front of step kt lets everything issued after stage kt's DMA stay in flight.
-template <bool OUT_BF16, int RES, int PF>
+template <bool OUT_BF16, int RES, int PF, int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_256_kernel(
     const u16* __restrict__ A, int64_t lda, const u16* __restrict__ B, int64_t ldb, void* __restrict__ Cv,
     int64_t ldc, const float* __restrict__ bias, const float* __restrict__ residual, int64_t ldres,
@@ -381,6 +403,11 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(
       v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
     }
     const bool full = n + EPT <= N;
+    if (EPI == 1) {          // GEGLU backward: Cv = dh, residual = h (bf16), ldres = row stride of both, N = ip (multiple of 8)
+      if (OUT_BF16) geglu_bwd_piece(reinterpret_cast<const float(&)[8]>(v), reinterpret_cast<const u16*>(residual),
+                                    reinterpret_cast<u16*>(Cv), ldres, N, (int64_t)m, n);
+      continue;
+    }
     if (bias) {
 #pragma unroll
       for (int e = 0; e < EPT; e++) if (full || n + e < N) v[e] += bias[n + e];
@@ -435,18 +462,18 @@ extern "C" int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, in
   const bool big = M >= 2048 && g_knob[1] != 1;            // knob 1 = 1 forces the 128x128 kernel (A/B measurements)
   const int nwg2 = (int)((M + BM2 - 1) / BM2) * tiles_n;
 #define NT_LAUNCH_G(OB, RS)                                                                                              \
-  hipLaunchKernelGGL((gemm_nt_glds_kernel<OB, RS, 64>), dim3(nwg), dim3(256), 0, as_stream(stream), A, lda, B, ldb, C,   \
+  hipLaunchKernelGGL((gemm_nt_glds_kernel<OB, RS, 64, 0>), dim3(nwg), dim3(256), 0, as_stream(stream), A, lda, B, ldb, C,   \
                      ldc, bias, residual, ldres, res_period, (int)M, (int)N, (int)K, tiles_n, nwg)
 #define NT_LAUNCH_256(OB, RS, PFV)                                                                                          \
   do {                                                                                                                   \
     static bool attr = false;                                                                                            \
     if (!attr) {                                                                                                         \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<OB, RS, PFV>),                            \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<OB, RS, PFV, 0>),                            \
                               hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS_BYTES) != hipSuccess)                \
         return MCA_E_LAUNCH;                                                                                             \
       attr = true;                                                                                                       \
     }                                                                                                                    \
-    hipLaunchKernelGGL((gemm_nt_256_kernel<OB, RS, PFV>), dim3(nwg2), dim3(512), NT256_LDS_BYTES, as_stream(stream), A, lda, \
+    hipLaunchKernelGGL((gemm_nt_256_kernel<OB, RS, PFV, 0>), dim3(nwg2), dim3(512), NT256_LDS_BYTES, as_stream(stream), A, lda, \
                        B, ldb, C, ldc, bias, residual, ldres, res_period, (int)M, (int)N, (int)K, tiles_n, nwg2);        \
   } while (0)
 #define NT_PICK_PF(OB, RS) do { if (big) NT_LAUNCH_256(OB, RS, 0); else NT_LAUNCH_G(OB, RS); } while (0)
@@ -455,6 +482,39 @@ extern "C" int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, in
   if (pf) { NT_LAUNCH_256(false, 1, 1); return launch_status(); }
   if (out_bf16) { if (res == 0) NT_PICK_PF(true, 0); else if (res == 1) NT_PICK_PF(true, 1); else NT_PICK_PF(true, 2); }
   else { if (res == 0) NT_PICK_PF(false, 0); else if (res == 1) NT_PICK_PF(false, 1); else NT_PICK_PF(false, 2); }
+  return launch_status();
+}
+
+
+// dh = GEGLU'(h) applied to dg = A·B^T without materialising dg (fused epilogue).  A[M,K] (= d x_out, bf16), B[ip,K] (= W2^T
+// copy), h / dh [M, 2*ip] bf16.
+extern "C" int mca_gemm_nt_geglu_bwd(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* h,
+                                     uint16_t* dh, int64_t ldh, int64_t ip, int64_t M, int64_t K, mca_stream_t stream) {
+  if (!A || !B || !h || !dh || M <= 0 || ip <= 0 || K <= 0) return MCA_E_BADARG;
+  if (K % 64 || lda % 8 || ldb % 8 || ldh % 8 || ip % 8 || (uintptr_t)A % 16 || (uintptr_t)B % 16 || (uintptr_t)h % 16 || (uintptr_t)dh % 16)
+    return MCA_E_ALIGN;
+  if (lda < K || ldb < K || ldh < 2 * ip) return MCA_E_BADARG;
+  if (M > (1LL << 30)) return MCA_E_UNSUPPORTED;
+  const int64_t N = ip;
+  const int tiles_n = (int)((N + BN - 1) / BN);
+  const float* hres = reinterpret_cast<const float*>(h);
+  void* C = dh;
+  if (M >= 2048) {
+    const int nwg2 = (int)((M + BM2 - 1) / BM2) * tiles_n;
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<true, 0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              NT256_LDS_BYTES) != hipSuccess)
+        return MCA_E_LAUNCH;
+      attr = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_256_kernel<true, 0, 0, 1>), dim3(nwg2), dim3(512), NT256_LDS_BYTES, as_stream(stream), A, lda, B, ldb, C,
+                       ldh, nullptr, hres, ldh, 0, (int)M, (int)N, (int)K, tiles_n, nwg2);
+  } else {
+    const int nwg = (int)((M + BM - 1) / BM) * tiles_n;
+    hipLaunchKernelGGL((gemm_nt_glds_kernel<true, 0, 64, 1>), dim3(nwg), dim3(256), 0, as_stream(stream), A, lda, B, ldb, C, ldh, nullptr,
+                       hres, ldh, 0, (int)M, (int)N, (int)K, tiles_n, nwg);
+  }
   return launch_status();
 }
 

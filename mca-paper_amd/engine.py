@@ -78,6 +78,7 @@ class FusionEngine:
         self.grad_bucket_hook: Optional[Callable[[int, int], None]] = None   # (lo, hi) offsets ready
         self.gather_hook: Optional[Callable] = None                          # DP: pooled/present all-gather
         self.check_finite = True
+        self.fuse_geglu_bwd = True
 
     # ------------------------------------------------------------------------------------------------
     # parameters -> one flat buffer (and one for gradients)
@@ -501,9 +502,14 @@ class FusionEngine:
             ly, w, a = m.layers[i], self.wl[i], ws["layers"][i]
             g = ly.norm.gamma
             # x_out = g @ W2^T + x1n            (dx = d x_out, fp32 + bf16 copy in ws['dx_b'])
-            self.gemm_nt(ws["dx_b"], w["w2T"], ws["dg"], T, Ip, D)
+            if self.fuse_geglu_bwd:
+                # dh = GEGLU'(h) * (dx @ W2): the (T, Ip) intermediate dg is never written (fused GEMM epilogue)
+                call("mca_gemm_nt_geglu_bwd", ptr(ws["dx_b"]), D, ptr(w["w2T"]), D, ptr(a["h"]), ptr(ws["dh"]), 2 * Ip, Ip, T, D,
+                     stream_ptr(), flops=2.0 * T * Ip * D)
+            else:
+                self.gemm_nt(ws["dx_b"], w["w2T"], ws["dg"], T, Ip, D)
+                call("mca_geglu_bwd", ptr(ws["dg"]), ptr(a["h"]), ptr(ws["dh"]), T, Ip, stream_ptr())
             self.gemm_tn_acc(ws["dx_b"], a["g"], G(ly.ff.feedforward[2].weight), T, D, I)
-            call("mca_geglu_bwd", ptr(ws["dg"]), ptr(a["h"]), ptr(ws["dh"]), T, Ip, stream_ptr())
             gw1 = G(ly.ff.feedforward[0].weight)
             self.gemm_tn_acc(ws["dh"], a["x1n_b"], gw1, T, I, D)
             self.gemm_tn_acc(ws["dh"][:, Ip:], a["x1n_b"], gw1[I:], T, I, D)

@@ -66,6 +66,7 @@ SIGNATURES = {
     "mca_version": (C.c_char_p, []),
     "mca_debug_set": (_I, [_I, _I]),
     "mca_gemm_nt": (_I, [_P, _I64, _P, _I64, _P, _I64, _I, _P, _P, _I64, _I64, _I64, _I64, _I64, _P]),
+    "mca_gemm_nt_geglu_bwd": (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P]),
     "mca_gemm_tn_acc": (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P]),
     "mca_layernorm_fwd": (_I, [_P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _I, _P, _P, _I64, _I, _F, _P]),
     "mca_layernorm_bwd": (_I, [_P, _I64, _I64, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I, _P]),
@@ -164,16 +165,23 @@ def profile_start(names):
     PROFILE = {"names": set(names), "records": {}}
 
 
+def profile_collect():
+    """Resolve the events recorded so far into (launches, ms, flops) totals and release them (synchronises).  Called after
+    every sampled step so that at most one step's worth of timing events is ever outstanding on the queue."""
+    torch.cuda.synchronize()
+    tot = PROFILE.setdefault("totals", {})
+    for key, recs in PROFILE["records"].items():
+        n, ms, fl = tot.get(key, (0, 0.0, 0.0))
+        tot[key] = (n + len(recs), ms + sum(s.elapsed_time(e) for s, e, _ in recs), fl + sum(f for _, _, f in recs))
+    PROFILE["records"] = {}
+
+
 def profile_stop():
     """-> {key: (launches, total_ms, total_flops)} (synchronises)."""
     global PROFILE
+    profile_collect()
     prof, PROFILE = PROFILE, None
-    torch.cuda.synchronize()
-    out = {}
-    for key, recs in prof["records"].items():
-        ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-        out[key] = (len(recs), ms, sum(f for _, _, f in recs))
-    return out
+    return prof["totals"]
 
 
 def call(name: str, *args, flops: float = 0.0):

@@ -141,6 +141,21 @@ def test_geglu(H):
     assert rel(dh.float(), hr.grad) < 4e-3
 
 
+@pytest.mark.parametrize("rows", [500, 4100])
+def test_gemm_geglu_bwd_fused(H, rows):
+    g = torch.Generator(device="cuda").manual_seed(41)
+    ip, D = 384, 128
+    h = bf(torch.randn(rows, 2 * ip, device="cuda", generator=g))
+    dx = bf(torch.randn(rows, D, device="cuda", generator=g))
+    w2T = bf(torch.randn(ip, D, device="cuda", generator=g) * 0.1)
+    dh = torch.zeros(rows, 2 * ip, device="cuda", dtype=torch.bfloat16)
+    H.call("mca_gemm_nt_geglu_bwd", dx.data_ptr(), D, w2T.data_ptr(), D, h.data_ptr(), dh.data_ptr(), 2 * ip, ip, rows, D, H.stream_ptr())
+    hr = h.float().requires_grad_(True)
+    out = torch.nn.functional.gelu(hr[:, ip:]) * hr[:, :ip]
+    out.backward(dx.float() @ w2T.float().t())
+    assert rel(dh.float(), hr.grad) < 4e-3
+
+
 # ------------------------------------------------------------------------------------- data movement
 def test_cast_bcast_reduce(H):
     g = torch.Generator(device="cuda").manual_seed(5)
