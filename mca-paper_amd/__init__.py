@@ -3,7 +3,7 @@
 train_accel_gpu.py).  Import by name: ``importlib.import_module("mca-paper_amd")`` (the directory name
 has a hyphen), or use the root-level shims ``model.py`` / ``encoders.py``.
 """
-from . import config, data, encoders, params, structure  # noqa: F401
+from . import checkpoint, config, data, encoders, metrics, params, structure  # noqa: F401
 from .encoders import MultimodalCollator, collators, encoders_dict  # noqa: F401
 from .model import MCA  # noqa: F401
 

@@ -45,3 +45,39 @@ def synthetic_batch(model_config: dict, batch_size: int, seed: int = 1234, p_dro
         else:
             raise NotImplementedError(c["type"])
     return batch
+
+
+class BatchPreDropout:
+    """Per-sample modality pre-dropout of the reference's dataset pipeline (utils/dataset.py:29-57): with probability
+    ``dropout`` a sample's modality is deleted (every column -> None, which the collators turn into a fully padded row) or
+    filled with constants.  Uses torch's global RNG exactly like the reference (``torch.rand(1) < dropout``)."""
+
+    def __init__(self, mode: str = "delete", kvs=None, dropout: float = 0.1, random_seed: int = 42):
+        self.mode = mode
+        self.kvs = kvs or {"attention_mask": 1, "tokens": 0}
+        self.dropout = dropout
+
+    def drop(self) -> bool:
+        return bool(torch.rand(1) < self.dropout)
+
+    def __call__(self, sample_modality: dict) -> dict:
+        if not self.drop():
+            return sample_modality
+        if self.mode == "delete":
+            return {k: None for k in sample_modality}
+        if self.mode == "fill":
+            return {k: (torch.full_like(v, self.kvs[k]) if v is not None else None) for k, v in sample_modality.items()}
+        raise Exception(f"Did not recognize batch dropout mode {self.mode}")
+
+
+def batch_predrop(modality_config: dict, random_seed: int = 42):
+    """-> callable(sample) for ``datasets.Dataset.map(..., batched=False)`` (utils/dataset.py:59-69): modalities whose
+    config has a non-zero ``dropout`` are pre-dropped per sample."""
+    droppers = {name: BatchPreDropout(kvs={"attention_mask": c.get("pad_token", 1), "data": 0.0}, dropout=c["dropout"],
+                                      random_seed=random_seed)
+                for name, c in modality_config.items() if c.get("dropout")}
+
+    def apply(sample: dict) -> dict:
+        return {k: (droppers[k](v) if k in droppers else v) for k, v in sample.items()}
+
+    return apply

@@ -95,8 +95,7 @@ def main():
     dp = dpmod.DataParallelMCA(model) if world > 1 else None
     total_steps = config.epochs * steps_per_epoch
     if config.restart:
-        sd = torch.load(os.path.join(config.restart, "state.pt"), map_location=device)
-        model.load_state_dict(sd["model"], strict=False); opt.load_state_dict(sd["optimizer"])
+        P.checkpoint.load_state(config.restart, model, opt)                  # train_accel_gpu.py:97-99
     log = open(os.path.join(config.output_dir, "log.jsonl"), "a") if rank == 0 else None
     step = config.start_epoch * steps_per_epoch
     model.train()
@@ -123,24 +122,35 @@ def main():
                 print(json.dumps(rec), flush=True)
                 log.write(json.dumps(rec) + "\n"); log.flush()
             if config.n_step_checkpoint and idb % config.n_step_checkpoint == 0 and rank == 0:
-                torch.save({"model": model.state_dict(), "optimizer": opt.state_dict()}, os.path.join(config.output_dir, "state.pt"))
+                P.checkpoint.save_state(config.output_dir, model, opt, step)
         if rank == 0:
-            d = os.path.join(config.output_dir, str(epoch)); os.makedirs(d, exist_ok=True)
-            torch.save({"model": model.state_dict(), "optimizer": opt.state_dict()}, os.path.join(d, "state.pt"))
+            P.checkpoint.save_state(os.path.join(config.output_dir, str(epoch)), model, opt, step)
             print(f"epoch {epoch} done in {time.time() - t_epoch:.1f}s", flush=True)
         if config.run_eval_loop and eval_batches is not None:
+            # eval loop of the reference (train_accel_gpu.py:137-181): losses + Wang-Isola alignment / uniformity
             model.eval()
+            names = list(model_config["encoder_configs"].keys())
+            uni = {k: P.metrics.Uniformity() for k in names + ["fusion"]}
+            ali = {k: P.metrics.Alignment() for k in names}
             with torch.no_grad():
                 tot, n = 0.0, 0
                 for batch in eval_batches:
                     out = model(move_to(batch, device))
                     tot += float(out["loss"]); n += 1
+                    for k in names:
+                        sm = out["modality_sample_mask"][k]
+                        uni[k].update(out[k][sm]); ali[k].update(out[k][sm], out["fusion"][sm])
+                    uni["fusion"].update(out["fusion"])
             if rank == 0:
-                print(json.dumps({"epoch": epoch, "val_epoch_total_loss": tot / max(1, n)}), flush=True)
+                rec = {"epoch": epoch, "val_epoch_total_loss": tot / max(1, n)}
+                rec.update({f"val_epoch_uniformity_{k}": float(v.compute()) for k, v in uni.items()})
+                rec.update({f"val_epoch_alignment_{k}": float(v.compute()) for k, v in ali.items()})
+                rec.update({f"val_epoch_norm_uniformity_{k}": float(v.compute(norm=True)) for k, v in uni.items()})
+                rec.update({f"val_epoch_norm_alignment_{k}": float(v.compute(norm=True)) for k, v in ali.items()})
+                print(json.dumps(rec), flush=True)
             model.train()
     if rank == 0:
-        from safetensors.torch import save_file
-        save_file({k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}, os.path.join(config.output_dir, "model.safetensors"))
+        P.checkpoint.save_model(model, config.output_dir, safe_serialization=True)   # train_accel_gpu.py:187
     if world > 1:
         torch.distributed.destroy_process_group()
 
