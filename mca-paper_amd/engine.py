@@ -79,6 +79,9 @@ class FusionEngine:
         self.gather_hook: Optional[Callable] = None                          # DP: pooled/present all-gather
         self.check_finite = True
         self.fuse_geglu_bwd = True
+        self.overlap_wgrad = True                  # weight-gradient GEMMs on a side stream, concurrent with the backward chain
+        self._side = torch.cuda.Stream(device=self.device)
+        self._side_events: List[torch.cuda.Event] = []
 
     # ------------------------------------------------------------------------------------------------
     # parameters -> one flat buffer (and one for gradients)
@@ -232,7 +235,10 @@ class FusionEngine:
         ws = dict(b=b, T=T)
         ws["x"] = [f32(T, D) for _ in range(self.L + 1)]
         ws["layers"] = [dict(x1=f32(T, D), m1=f32(T), r1=f32(T), m2=f32(T), r2=f32(T), xn_b=bf(T, D), qkv=bf(T, 3 * D),
-                             o=bf(T, D), lse=f32(b, H, N), x1n_b=bf(T, D), h=bf(T, 2 * Ip), g=bf(T, Ip))
+                             o=bf(T, D), lse=f32(b, H, N), x1n_b=bf(T, D), h=bf(T, 2 * Ip), g=bf(T, Ip),
+                             # backward operands of the weight-gradient GEMMs: one set PER LAYER, so those GEMMs can run
+                             # on a side stream without write-after-read hazards against the next layer's backward
+                             dxo_b=bf(T, D), dx1_b=bf(T, D), dh=bf(T, 2 * Ip), dqkv=bf(T, 3 * D))
                         for _ in range(self.L)]
         ws["xn"], ws["x1n"] = f32(T, D), f32(T, D)
         ws["mf"], ws["rf"], ws["t_b"], ws["kvp"] = f32(T), f32(T), bf(T, D), bf(T, 2 * D)
@@ -243,7 +249,7 @@ class FusionEngine:
         ws["padding"] = u8(b, N)
         # backward
         ws["dxa"], ws["dxb"], ws["dx_b"] = f32(T, D), f32(T, D), bf(T, D)
-        ws["dg"], ws["dh"], ws["do"], ws["dq32"], ws["dqkv"] = bf(T, Ip), bf(T, 2 * Ip), bf(T, D), f32(T, D), bf(T, 3 * D)
+        ws["dg"], ws["do"], ws["dq32"] = bf(T, Ip), bf(T, D), f32(T, D)
         ws["dpool_b"], ws["dop"], ws["dqp32"], ws["dqp_sum"], ws["dqp_b"] = bf(b * R, D), bf(b * R, D), f32(b * R, D), f32(R, D), bf(R, D)
         ws["dkvp"], ws["drt"] = bf(T, 2 * D), f32(R, D)
         ws["enc"] = {}
@@ -460,6 +466,19 @@ class FusionEngine:
     # ------------------------------------------------------------------------------------------------
     # backward
     # ------------------------------------------------------------------------------------------------
+    def _on_side(self, fn, slot: int):
+        """Run fn() on the side stream, ordered after everything enqueued so far on the main stream."""
+        if not self.overlap_wgrad:
+            fn()
+            return
+        while len(self._side_events) <= slot:
+            self._side_events.append(torch.cuda.Event())
+        ev = self._side_events[slot]
+        ev.record()
+        with torch.cuda.stream(self._side), hip.use_stream(self._side.cuda_stream):
+            self._side.wait_event(ev)
+            fn()
+
     def _bucket_ready(self, idx):
         if self.grad_bucket_hook is not None:
             lo = 0 if idx == 0 else self.bucket_bounds[idx - 1]
@@ -476,11 +495,20 @@ class FusionEngine:
             G(m.loss.loss_fn.logit_scale).add_(d_logit_scale.reshape(()))
         dpool = d_pooled.reshape(b * R, D).contiguous()
         ap = m.attn_pool
+        # Weight-gradient GEMMs (mca_gemm_tn_acc) only feed the optimizer: they are issued on a side stream, ordered after
+        # the kernel that produced their operand, and run concurrently with the rest of the backward chain (their
+        # operands live in per-layer buffers, so nothing overwrites them).  slot = unique id of the call site.
+        side, tn = self._on_side, self.gemm_tn_acc
+        slot = [0]
+
+        def on_side(fn):
+            side(fn, slot[0]); slot[0] += 1
+
         # pooled = op @ Wo^T + return_tokens
         call("mca_reduce_rows", ptr(dpool), D, R * D, R, ptr(G(m.return_tokens)), D, b * R, D, stream_ptr())
         call("mca_f32_to_bf16", ptr(dpool), D, ptr(ws["dpool_b"]), D, b * R, D, 1.0, stream_ptr())
         self.gemm_nt(ws["dpool_b"], self.wp["oT"], ws["dop"], b * R, D, D)
-        self.gemm_tn_acc(ws["dpool_b"], ws["op"], G(ap.to_out.weight), b * R, D, D)
+        on_side(lambda: tn(ws["dpool_b"], ws["op"], G(ap.to_out.weight), b * R, D, D))
         # pooling attention
         ws["dqp32"].zero_()
         self._attn_bwd(ws["qp"].data_ptr(), 0, D, ws["kvp"], 0, D, 2 * D, ws["op"], ws["dop"], ws["lse_p"], ws["delta_p"],
@@ -488,48 +516,48 @@ class FusionEngine:
         ws["dqp_sum"].zero_()
         call("mca_reduce_rows", ptr(ws["dqp32"]), D, R * D, R, ptr(ws["dqp_sum"]), D, b * R, D, stream_ptr())
         call("mca_f32_to_bf16", ptr(ws["dqp_sum"]), D, ptr(ws["dqp_b"]), D, R, D, 1.0, stream_ptr())
-        self.gemm_tn_acc(ws["dqp_b"], ws["rt_b"], G(ap.to_q.weight), R, D, D)
         self.gemm_nt(ws["dqp_b"], self.wp["qT"], ws["drt"], R, D, D)                 # d return_tokens via to_q
         G(m.return_tokens).add_(ws["drt"])
-        self.gemm_tn_acc(ws["dkvp"], ws["t_b"], G(ap.to_kv.weight), T, 2 * D, D)
+        on_side(lambda: (tn(ws["dqp_b"], ws["rt_b"], G(ap.to_q.weight), R, D, D),
+                         tn(ws["dkvp"], ws["t_b"], G(ap.to_kv.weight), T, 2 * D, D)))
         dx, dx_other = ws["dxa"], ws["dxb"]
         self.gemm_nt(ws["dkvp"], self.wp["kvT"], dx, T, D, 2 * D)                    # d (final-normed tokens), fp32
-        self.ln_bwd(dx, D, ws["x"][self.L], m.norm.gamma, ws["mf"], ws["rf"], T, D, G(m.norm.gamma), dx=dx_other,
-                    dx_bf16=ws["dx_b"])
+        top = ws["layers"][self.L - 1]["dxo_b"] if self.L else ws["dx_b"]
+        self.ln_bwd(dx, D, ws["x"][self.L], m.norm.gamma, ws["mf"], ws["rf"], T, D, G(m.norm.gamma), dx=dx_other, dx_bf16=top)
         dx, dx_other = dx_other, dx
-        self._bucket_ready(0)
+        on_side(lambda: self._bucket_ready(0))
         for bi, i in enumerate(reversed(range(self.L))):
             ly, w, a = m.layers[i], self.wl[i], ws["layers"][i]
             g = ly.norm.gamma
-            # x_out = g @ W2^T + x1n            (dx = d x_out, fp32 + bf16 copy in ws['dx_b'])
+            dxo, dx1, dh, dqkv = a["dxo_b"], a["dx1_b"], a["dh"], a["dqkv"]
+            below = ws["layers"][i - 1]["dxo_b"] if i > 0 else ws["dx_b"]
+            # x_out = g @ W2^T + x1n            (dx = d x_out fp32, dxo = its bf16 copy)
+            on_side(lambda dxo=dxo, a=a, ly=ly: tn(dxo, a["g"], G(ly.ff.feedforward[2].weight), T, D, I))
             if self.fuse_geglu_bwd:
                 # dh = GEGLU'(h) * (dx @ W2): the (T, Ip) intermediate dg is never written (fused GEMM epilogue)
-                call("mca_gemm_nt_geglu_bwd", ptr(ws["dx_b"]), D, ptr(w["w2T"]), D, ptr(a["h"]), ptr(ws["dh"]), 2 * Ip, Ip, T, D,
+                call("mca_gemm_nt_geglu_bwd", ptr(dxo), D, ptr(w["w2T"]), D, ptr(a["h"]), ptr(dh), 2 * Ip, Ip, T, D,
                      stream_ptr(), flops=2.0 * T * Ip * D)
             else:
-                self.gemm_nt(ws["dx_b"], w["w2T"], ws["dg"], T, Ip, D)
-                call("mca_geglu_bwd", ptr(ws["dg"]), ptr(a["h"]), ptr(ws["dh"]), T, Ip, stream_ptr())
-            self.gemm_tn_acc(ws["dx_b"], a["g"], G(ly.ff.feedforward[2].weight), T, D, I)
+                self.gemm_nt(dxo, w["w2T"], ws["dg"], T, Ip, D)
+                call("mca_geglu_bwd", ptr(ws["dg"]), ptr(a["h"]), ptr(dh), T, Ip, stream_ptr())
             gw1 = G(ly.ff.feedforward[0].weight)
-            self.gemm_tn_acc(ws["dh"], a["x1n_b"], gw1, T, I, D)
-            self.gemm_tn_acc(ws["dh"][:, Ip:], a["x1n_b"], gw1[I:], T, I, D)
-            self.gemm_nt(ws["dh"], w["w1T"], dx_other, T, D, 2 * Ip, residual=dx)      # d x1n = dh @ W1 + dx
-            self.ln_bwd(dx_other, D, a["x1"], g, a["m2"], a["r2"], T, D, G(g), dx=dx, dx_bf16=ws["dx_b"])   # dx = d x1
+            on_side(lambda dh=dh, a=a, gw1=gw1: (tn(dh, a["x1n_b"], gw1, T, I, D), tn(dh[:, Ip:], a["x1n_b"], gw1[I:], T, I, D)))
+            self.gemm_nt(dh, w["w1T"], dx_other, T, D, 2 * Ip, residual=dx)            # d x1n = dh @ W1 + dx
+            self.ln_bwd(dx_other, D, a["x1"], g, a["m2"], a["r2"], T, D, G(g), dx=dx, dx_bf16=dx1)   # dx = d x1
             # x1 = o @ Wo^T + xn
-            self.gemm_nt(ws["dx_b"], w["oT"], ws["do"], T, D, D)
-            self.gemm_tn_acc(ws["dx_b"], a["o"], G(ly.attn.to_out.weight), T, D, D)
+            on_side(lambda dx1=dx1, a=a, ly=ly: tn(dx1, a["o"], G(ly.attn.to_out.weight), T, D, D))
+            self.gemm_nt(dx1, w["oT"], ws["do"], T, D, D)
             ws["dq32"].zero_()
             self._attn_bwd(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], ws["do"], a["lse"],
-                           ws["delta"], ws["dq32"], N * D, ws["dqkv"], D, 2 * D, 3 * D, self.qmask_attn, self.sched_attn_b,
-                           ws, b, N)
-            call("mca_f32_to_bf16", ptr(ws["dq32"]), D, ptr(ws["dqkv"]), 3 * D, T, D, 1.0, stream_ptr())
+                           ws["delta"], ws["dq32"], N * D, dqkv, D, 2 * D, 3 * D, self.qmask_attn, self.sched_attn_b, ws, b, N)
+            call("mca_f32_to_bf16", ptr(ws["dq32"]), D, ptr(dqkv), 3 * D, T, D, 1.0, stream_ptr())
             # to_q.weight and to_kv.weight are adjacent in the flat gradient buffer: one (3D, D) weight-gradient GEMM
             gq = G(ly.attn.to_q.weight)
             assert G(ly.attn.to_kv.weight).data_ptr() == gq.data_ptr() + D * D * 4
-            self.gemm_tn_acc(ws["dqkv"], a["xn_b"], gq, T, 3 * D, D)
-            self.gemm_nt(ws["dqkv"], w["qkvT"], dx_other, T, D, 3 * D, residual=dx)   # d xn = dqkv @ Wqkv + d x1
-            self.ln_bwd(dx_other, D, ws["x"][i], g, a["m1"], a["r1"], T, D, G(g), dx=dx, dx_bf16=ws["dx_b"])  # dx = d x_in
-            self._bucket_ready(bi + 1)
+            on_side(lambda dqkv=dqkv, a=a, gq=gq: tn(dqkv, a["xn_b"], gq, T, 3 * D, D))
+            self.gemm_nt(dqkv, w["qkvT"], dx_other, T, D, 3 * D, residual=dx)          # d xn = dqkv @ Wqkv + d x1
+            self.ln_bwd(dx_other, D, ws["x"][i], g, a["m1"], a["r1"], T, D, G(g), dx=dx, dx_bf16=below)  # dx = d x_in
+            on_side(lambda bi=bi: self._bucket_ready(bi + 1))
         # dx = gradient w.r.t. the packed encoder output (b, N, D)
         if self.F:
             call("mca_reduce_rows", dx.data_ptr() + (N - self.F) * D * 4, D, N * D, self.F, ptr(G(m.fusion_tokens)), D,
@@ -544,7 +572,7 @@ class FusionEngine:
                 self.ln_bwd(dx[off:], D, e["y"], te[2].weight, e["m2"], e["r2"], rows, D, G(te[2].weight), dbeta=G(te[2].bias),
                             rowmask=e["mask"], dx=e["dy"], dx_bf16=e["dy_b"], y_bstride=N * D, period=n)
                 call("mca_reduce_rows", ptr(e["dy"]), D, D, 1, ptr(G(te[1].bias)), D, rows, D, stream_ptr())
-                self.gemm_tn_acc(e["dy_b"], e["xin_b"], G(te[1].weight), rows, D, enc.input_size)
+                on_side(lambda e=e, te=te, rows=rows, enc=enc: tn(e["dy_b"], e["xin_b"], G(te[1].weight), rows, D, enc.input_size))
                 self.gemm_nt(e["dy_b"], self.we[name]["wT"], e["dxin"], rows, kp, D)
                 t2 = e["tokens"].view(rows, enc.input_size)
                 self.ln_bwd(e["dxin"], kp, t2, te[0].weight, e["m0"], e["r0"], rows, enc.input_size, G(te[0].weight),
@@ -555,7 +583,9 @@ class FusionEngine:
                 toks = ws["foreign"][name]
                 if toks.requires_grad:
                     torch.autograd.backward(toks, dx.view(b, N, D)[:, off:off + n].to(toks.dtype))
-        self._bucket_ready(len(self.bucket_bounds) - 1)
+        on_side(lambda: self._bucket_ready(len(self.bucket_bounds) - 1))
+        if self.overlap_wgrad:
+            torch.cuda.current_stream().wait_stream(self._side)          # every weight gradient is in before clip / AdamW
 
     def _backward_tabular(self, name, enc, ws, mi, dx):
         D, N, b = self.D, self.N, ws["b"]
@@ -569,7 +599,7 @@ class FusionEngine:
         self.ln_bwd(dx[off:], D, e["y"], ve.norm.weight, e["m2"], e["r2"], rows, D, G(ve.norm.weight), dbeta=G(ve.norm.bias),
                     rowmask=e["mask"], dx=e["dy"], dx_bf16=e["dy_b"], y_bstride=N * D, period=n)
         call("mca_reduce_rows", ptr(e["dy"]), D, D, 1, ptr(G(ve.linear2.bias)), D, rows, D, stream_ptr())
-        self.gemm_tn_acc(e["dy_b"], e["h1_b"], G(ve.linear2.weight), rows, D, D)
+        self._on_side(lambda: self.gemm_tn_acc(e["dy_b"], e["h1_b"], G(ve.linear2.weight), rows, D, D), 200 + mi)
         self.gemm_nt(e["dy_b"], self.we[name]["w2T"], e["dh1"], rows, D, D)
         call("mca_tab_value_bwd", ptr(e["dh1"]), D, ptr(e["h1_b"]), ptr(e["values"]), ptr(G(ve.linear1.weight)),
              ptr(G(ve.linear1.bias)), rows, D, float(ve.max_value), stream_ptr())

@@ -120,6 +120,22 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class use_stream:
+    """context manager: launch through an explicit stream handle (side-stream weight gradients)."""
+
+    def __init__(self, handle: int):
+        self.handle = handle
+
+    def __enter__(self):
+        global _STREAM_CACHE
+        self.prev = _STREAM_CACHE
+        _STREAM_CACHE = self.handle
+
+    def __exit__(self, *exc):
+        global _STREAM_CACHE
+        _STREAM_CACHE = self.prev
+
+
 class cached_stream:
     """context manager: query torch's current stream once and reuse the handle for every launch inside."""
 
