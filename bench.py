@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--p-drop", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--sample-every", type=int, default=4, help="record per-kernel HIP events on every n-th timed step")
+    ap.add_argument("--sample-every", type=int, default=5, help="record per-kernel HIP events on every n-th timed step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,7 +103,8 @@ def main():
     cfg = P.config.cmu_model_config(batch_size=b, zorro=args.variant == "mma")
     torch.manual_seed(43)
     model = P.MCA(**cfg).to(dev)
-    model.engine.check_finite = False          # no host syncs inside the timed region (checked once after it)
+    eng = model.engine
+    eng.check_finite = False                   # no host syncs inside the timed region (checked once after it)
     opt = optim.FusedAdamW(model, lr=1e-4)
     dp = dpmod.DataParallelMCA(model) if world > 1 else None
     batch = P.data.synthetic_batch(cfg, b, seed=1234 + rank, p_drop=args.p_drop, lengths=args.lengths, device=dev)
@@ -118,8 +119,13 @@ def main():
         opt.step()
         return out["loss"]
 
-    for _ in range(args.warmup):
+    for w in range(args.warmup):
+        exclusive = w == 0 and not args.no_kernel_timing and args.warmup > 1      # also warm the schedule the sampled steps use
+        saved = (eng.overlap_wgrad, eng.micro_batches)
+        if exclusive:
+            eng.overlap_wgrad, eng.micro_batches = False, 1
         step()
+        eng.overlap_wgrad, eng.micro_batches = saved
     timed = ("mca_attn_fwd", "mca_attn_bwd", "mca_gemm_nt", "mca_gemm_nt_geglu_bwd", "mca_gemm_tn_acc")
     if world > 1:
         dist.barrier()
@@ -134,9 +140,14 @@ def main():
         sampled += int(rec)
         if rec:
             torch.cuda.synchronize()          # sampled step starts on an empty queue ...
+            # ... and runs every kernel alone (no side-stream weight gradients, no half-batch interleave), so that an
+            # event pair brackets ONE kernel's own duration; the other steps run the overlapped production schedule
+            saved = (eng.overlap_wgrad, eng.micro_batches)
+            eng.overlap_wgrad, eng.micro_batches = False, 1
         loss = step()
         if rec:
-            hip.profile_collect()             # ... and its timing events are resolved and released right away
+            hip.profile_collect()             # its timing events are resolved and released right away
+            eng.overlap_wgrad, eng.micro_batches = saved
     hip.profile_enable(True)
     torch.cuda.synchronize()
     if world > 1:

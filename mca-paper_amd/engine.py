@@ -16,6 +16,8 @@ encoders encoders.py:196-214 / :90-96, backward = autograd of those (train_accel
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import math
 from typing import Callable, Dict, List, Optional
@@ -79,9 +81,13 @@ class FusionEngine:
         self.gather_hook: Optional[Callable] = None                          # DP: pooled/present all-gather
         self.check_finite = True
         self.fuse_geglu_bwd = True
-        self.overlap_wgrad = True                  # weight-gradient GEMMs on a side stream, concurrent with the backward chain
-        self._side = torch.cuda.Stream(device=self.device)
-        self._side_events: List[torch.cuda.Event] = []
+        # weight-gradient GEMMs on a side stream, concurrent with the backward chain
+        self.overlap_wgrad = os.environ.get("MCA_OVERLAP_WGRAD", "1") != "0"
+        # micro-batch interleave (opt-in, MCA_MICRO_BATCHES=2): batches of at least micro_batch_min samples run as two
+        # halves on two streams.  Measured on CMU b=32: 26.3 vs 26.7 ms/step when the host runs ahead, no gain when it
+        # does not (tools/ab_step.py 102 1 2, tools/diag_switch.py) - kept off by default.
+        self.micro_batches = int(os.environ.get("MCA_MICRO_BATCHES", "1"))
+        self.micro_batch_min = 32
 
     # ------------------------------------------------------------------------------------------------
     # parameters -> one flat buffer (and one for gradients)
@@ -224,9 +230,9 @@ class FusionEngine:
     # ------------------------------------------------------------------------------------------------
     # workspaces for a given local batch size
     # ------------------------------------------------------------------------------------------------
-    def workspace(self, b: int) -> dict:
-        if b in self._ws:
-            return self._ws[b]
+    def workspace(self, b: int, part: int = 0) -> dict:
+        if (b, part) in self._ws:
+            return self._ws[(b, part)]
         D, N, H, Ip, R, dev = self.D, self.N, self.H, self.Ip, self.R, self.device
         T = b * N
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -264,9 +270,27 @@ class FusionEngine:
             elif isinstance(enc, TabularEncoder):
                 ws["enc"][name] = dict(h1_b=bf(rows, D), y=f32(rows, D), m2=f32(rows), r2=f32(rows), dy=f32(rows, D),
                                        dy_b=bf(rows, D), dh1=f32(rows, D), mask=u8(rows))
-        ws["sqnorm"] = f32(1)
-        self._ws[b] = ws
+        # each workspace has its own side stream for the weight-gradient GEMMs (micro-batch halves run concurrently)
+        ws["side"], ws["side_events"] = torch.cuda.Stream(device=dev), []
+        self._ws[(b, part)] = ws
         return ws
+
+    def split_workspace(self, b: int) -> dict:
+        """Two half-batch workspaces run on two streams (see _model_forward): the samples of a batch only meet in the
+        contrastive loss, so the MFMA-bound kernels of one half overlap the HBM-bound ones of the other."""
+        key = ("split", b)
+        if key not in self._ws:
+            h = b // 2
+            pooled = torch.empty(b * self.R, self.D, dtype=torch.float32, device=self.device)
+            parts = []
+            for pi in range(2):
+                part = dict(self.workspace(h, pi))
+                part["pooled"] = pooled[pi * h * self.R:(pi + 1) * h * self.R]
+                part["done"] = [torch.cuda.Event() for _ in range(len(self.bucket_bounds))]
+                parts.append(part)
+            self._ws[key] = dict(b=b, parts=parts, pooled=pooled, stream=torch.cuda.Stream(device=self.device),
+                                 start=torch.cuda.Event())
+        return self._ws[key]
 
     # ------------------------------------------------------------------------------------------------
     # thin kernel wrappers
@@ -343,7 +367,7 @@ class FusionEngine:
     # ------------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------------
-    def _encode(self, batch, ws, need_grad: bool):
+    def _encode(self, batch, ws, need_grad: bool, renorm: bool = True):
         """encoders + packing (model.py:455-466): writes ws['x'][0] (b, N, D) and ws['padding'] (b, N)."""
         m, D, N, b = self.model, self.D, self.N, ws["b"]
         x0 = ws["x"][0]
@@ -377,7 +401,7 @@ class FusionEngine:
                             period=n, y=x0[off:], ldy=D, y_bstride=N * D)
                 sample_mask[name] = ~mask.all(dim=1)
             elif isinstance(enc, TabularEncoder):
-                sample_mask[name] = self._encode_tabular(name, enc, bm, ws, mi)
+                sample_mask[name] = self._encode_tabular(name, enc, bm, ws, mi, renorm)
             else:
                 # user-registered torch encoder: run it with autograd and feed its tokens to the native trunk
                 with torch.enable_grad() if need_grad else torch.no_grad():
@@ -392,7 +416,11 @@ class FusionEngine:
             ws["padding"].view(b, N)[:, N - self.F:] = 0
         return sample_mask
 
-    def _encode_tabular(self, name, enc, bm, ws, mi):
+    def _renorm_table(self, enc, n):
+        emb = enc.token_encoder.embedding.weight
+        call("mca_embedding_renorm", ptr(emb.data), n, self.D, float(enc.token_encoder.max_norm), stream_ptr())
+
+    def _encode_tabular(self, name, enc, bm, ws, mi, renorm=True):
         """encoders.py:90-96: E[t] (max_norm-renormalised in place) + LN(Linear2(ReLU(Linear1(min(x, max)))))), the value
         part zeroed where x == padding_idx (-1).  The trunk's key-padding mask is the collator's attention_mask."""
         D, N, b = self.D, self.N, ws["b"]
@@ -408,7 +436,8 @@ class FusionEngine:
         amask = bm["attention_mask"]
         ws["padding"].view(b, N)[:, off:off + n].copy_(amask.to(torch.bool))
         emb = enc.token_encoder.embedding.weight
-        call("mca_embedding_renorm", ptr(emb.data), n, D, float(enc.token_encoder.max_norm), stream_ptr())
+        if renorm:
+            self._renorm_table(enc, n)
         call("mca_tab_value_fwd", ptr(vals), ptr(ve.linear1.weight.data), ptr(ve.linear1.bias.data), ptr(e["h1_b"]), ptr(e["mask"]),
              rows, D, float(ve.max_value), float(ve.padding_value), stream_ptr())
         self.gemm_nt(e["h1_b"], self.we[name]["w2"], e["y"], rows, D, D, bias=ve.linear2.bias)
@@ -466,17 +495,18 @@ class FusionEngine:
     # ------------------------------------------------------------------------------------------------
     # backward
     # ------------------------------------------------------------------------------------------------
-    def _on_side(self, fn, slot: int):
-        """Run fn() on the side stream, ordered after everything enqueued so far on the main stream."""
+    def _on_side(self, fn, slot: int, ws: dict):
+        """Run fn() on the workspace's side stream, ordered after everything enqueued so far on the current stream."""
         if not self.overlap_wgrad:
             fn()
             return
-        while len(self._side_events) <= slot:
-            self._side_events.append(torch.cuda.Event())
-        ev = self._side_events[slot]
+        side, events = ws["side"], ws["side_events"]
+        while len(events) <= slot:
+            events.append(torch.cuda.Event())
+        ev = events[slot]
         ev.record()
-        with torch.cuda.stream(self._side), hip.use_stream(self._side.cuda_stream):
-            self._side.wait_event(ev)
+        with torch.cuda.stream(side), hip.use_stream(side.cuda_stream):
+            side.wait_event(ev)
             fn()
 
     def _bucket_ready(self, idx):
@@ -487,12 +517,36 @@ class FusionEngine:
     def backward(self, ws, d_pooled, d_logit_scale=None, accumulate=False):
         """d_pooled: (b, R, D) fp32 gradient of the objective w.r.t. the pooled tokens.  Writes every parameter
         gradient into the flat gradient buffer."""
-        m, D, N, H, Ip, I, R, b, T = self.model, self.D, self.N, self.H, self.Ip, self.I, self.R, ws["b"], ws["T"]
         if not accumulate:
             self.gflat.zero_()
-        G = self.grad_of
         if d_logit_scale is not None:
-            G(m.loss.loss_fn.logit_scale).add_(d_logit_scale.reshape(()))
+            self.grad_of(self.model.loss.loss_fn.logit_scale).add_(d_logit_scale.reshape(()))
+        main = torch.cuda.current_stream()
+        if "parts" not in ws:
+            self._backward_part(ws, d_pooled, self._bucket_ready)
+            if self.overlap_wgrad:
+                main.wait_stream(ws["side"])                  # every weight gradient is in before clip / AdamW
+            return
+        # two half batches on two streams; every gradient accumulation is atomic, so both halves add into the same
+        # flat buffer.  A gradient bucket is complete when BOTH halves have produced it: half 0 marks it with an event,
+        # half 1 waits for that event and then hands the bucket to the data-parallel reducer.
+        h, (p0, p1), s1 = ws["b"] // 2, ws["parts"], ws["stream"]
+        ws["start"].record(main)
+        self._backward_part(p0, d_pooled[:h], lambda idx: p0["done"][idx].record())
+
+        def both_ready(idx):
+            torch.cuda.current_stream().wait_event(p0["done"][idx])
+            self._bucket_ready(idx)
+
+        with torch.cuda.stream(s1), hip.use_stream(s1.cuda_stream):
+            s1.wait_event(ws["start"])
+            self._backward_part(p1, d_pooled[h:], both_ready)
+        for s in (s1, p0["side"], p1["side"]):
+            main.wait_stream(s)
+
+    def _backward_part(self, ws, d_pooled, bucket_ready):
+        m, D, N, H, Ip, I, R, b, T = self.model, self.D, self.N, self.H, self.Ip, self.I, self.R, ws["b"], ws["T"]
+        G = self.grad_of
         dpool = d_pooled.reshape(b * R, D).contiguous()
         ap = m.attn_pool
         # Weight-gradient GEMMs (mca_gemm_tn_acc) only feed the optimizer: they are issued on a side stream, ordered after
@@ -502,7 +556,7 @@ class FusionEngine:
         slot = [0]
 
         def on_side(fn):
-            side(fn, slot[0]); slot[0] += 1
+            side(fn, slot[0], ws); slot[0] += 1
 
         # pooled = op @ Wo^T + return_tokens
         call("mca_reduce_rows", ptr(dpool), D, R * D, R, ptr(G(m.return_tokens)), D, b * R, D, stream_ptr())
@@ -517,7 +571,7 @@ class FusionEngine:
         call("mca_reduce_rows", ptr(ws["dqp32"]), D, R * D, R, ptr(ws["dqp_sum"]), D, b * R, D, stream_ptr())
         call("mca_f32_to_bf16", ptr(ws["dqp_sum"]), D, ptr(ws["dqp_b"]), D, R, D, 1.0, stream_ptr())
         self.gemm_nt(ws["dqp_b"], self.wp["qT"], ws["drt"], R, D, D)                 # d return_tokens via to_q
-        G(m.return_tokens).add_(ws["drt"])
+        call("mca_reduce_rows", ptr(ws["drt"]), D, R * D, R, ptr(G(m.return_tokens)), D, R, D, stream_ptr())
         on_side(lambda: (tn(ws["dqp_b"], ws["rt_b"], G(ap.to_q.weight), R, D, D),
                          tn(ws["dkvp"], ws["t_b"], G(ap.to_kv.weight), T, 2 * D, D)))
         dx, dx_other = ws["dxa"], ws["dxb"]
@@ -525,7 +579,7 @@ class FusionEngine:
         top = ws["layers"][self.L - 1]["dxo_b"] if self.L else ws["dx_b"]
         self.ln_bwd(dx, D, ws["x"][self.L], m.norm.gamma, ws["mf"], ws["rf"], T, D, G(m.norm.gamma), dx=dx_other, dx_bf16=top)
         dx, dx_other = dx_other, dx
-        on_side(lambda: self._bucket_ready(0))
+        on_side(lambda: bucket_ready(0))
         for bi, i in enumerate(reversed(range(self.L))):
             ly, w, a = m.layers[i], self.wl[i], ws["layers"][i]
             g = ly.norm.gamma
@@ -557,7 +611,7 @@ class FusionEngine:
             on_side(lambda dqkv=dqkv, a=a, gq=gq: tn(dqkv, a["xn_b"], gq, T, 3 * D, D))
             self.gemm_nt(dqkv, w["qkvT"], dx_other, T, D, 3 * D, residual=dx)          # d xn = dqkv @ Wqkv + d x1
             self.ln_bwd(dx_other, D, ws["x"][i], g, a["m1"], a["r1"], T, D, G(g), dx=dx, dx_bf16=below)  # dx = d x_in
-            on_side(lambda bi=bi: self._bucket_ready(bi + 1))
+            on_side(lambda bi=bi: bucket_ready(bi + 1))
         # dx = gradient w.r.t. the packed encoder output (b, N, D)
         if self.F:
             call("mca_reduce_rows", dx.data_ptr() + (N - self.F) * D * 4, D, N * D, self.F, ptr(G(m.fusion_tokens)), D,
@@ -583,9 +637,7 @@ class FusionEngine:
                 toks = ws["foreign"][name]
                 if toks.requires_grad:
                     torch.autograd.backward(toks, dx.view(b, N, D)[:, off:off + n].to(toks.dtype))
-        on_side(lambda: self._bucket_ready(len(self.bucket_bounds) - 1))
-        if self.overlap_wgrad:
-            torch.cuda.current_stream().wait_stream(self._side)          # every weight gradient is in before clip / AdamW
+        on_side(lambda: bucket_ready(len(self.bucket_bounds) - 1))
 
     def _backward_tabular(self, name, enc, ws, mi, dx):
         D, N, b = self.D, self.N, ws["b"]
@@ -599,7 +651,7 @@ class FusionEngine:
         self.ln_bwd(dx[off:], D, e["y"], ve.norm.weight, e["m2"], e["r2"], rows, D, G(ve.norm.weight), dbeta=G(ve.norm.bias),
                     rowmask=e["mask"], dx=e["dy"], dx_bf16=e["dy_b"], y_bstride=N * D, period=n)
         call("mca_reduce_rows", ptr(e["dy"]), D, D, 1, ptr(G(ve.linear2.bias)), D, rows, D, stream_ptr())
-        self._on_side(lambda: self.gemm_tn_acc(e["dy_b"], e["h1_b"], G(ve.linear2.weight), rows, D, D), 200 + mi)
+        self._on_side(lambda: self.gemm_tn_acc(e["dy_b"], e["h1_b"], G(ve.linear2.weight), rows, D, D), 200 + mi, ws)
         self.gemm_nt(e["dy_b"], self.we[name]["w2T"], e["dh1"], rows, D, D)
         call("mca_tab_value_bwd", ptr(e["dh1"]), D, ptr(e["h1_b"]), ptr(e["values"]), ptr(G(ve.linear1.weight)),
              ptr(G(ve.linear1.bias)), rows, D, float(ve.max_value), stream_ptr())
@@ -611,6 +663,31 @@ class FusionEngine:
         with hip.cached_stream():
             return self._model_forward(batch, no_loss)
 
+    def _forward_split(self, batch, b, need_grad):
+        """Micro-batch interleave: the two halves of the batch run encoders + trunk on two streams; they only meet in the
+        loss.  Per-sample results are identical to the unsplit pass (no kernel mixes samples before the loss)."""
+        m = self.model
+        ws = self.split_workspace(b)
+        h, s1, main = b // 2, ws["stream"], torch.cuda.current_stream()
+        for mi, name in enumerate(m.modality_types):           # in-place renorm of the shared tables: once, before the split
+            if isinstance(m.encoders[name], TabularEncoder):
+                self._renorm_table(m.encoders[name], self.st.token_dims[mi])
+        ws["start"].record(main)
+        masks = []
+        for pi, part in enumerate(ws["parts"]):
+            sub = {name: {k: (v[pi * h:(pi + 1) * h] if torch.is_tensor(v) and v.dim() and v.shape[0] == b else v)
+                          for k, v in batch[name].items()} for name in m.modality_types}
+            if pi == 0:
+                masks.append(self._encode(sub, part, need_grad, renorm=False))
+                self.forward_trunk(part)
+            else:
+                with torch.cuda.stream(s1), hip.use_stream(s1.cuda_stream):
+                    s1.wait_event(ws["start"])
+                    masks.append(self._encode(sub, part, need_grad, renorm=False))
+                    self.forward_trunk(part)
+        main.wait_stream(s1)
+        return ws, {name: torch.cat([masks[0][name], masks[1][name]]) for name in m.modality_types}
+
     def _model_forward(self, batch, no_loss=False):
         m = self.model
         first = batch[m.modality_types[0]]
@@ -621,9 +698,14 @@ class FusionEngine:
             if bad and bool(torch.stack(bad).any()):
                 raise Exception("Tokens are not finite")               # encoders.py:197-198
         self.refresh_weights()
-        ws = self.workspace(b)
-        sample_mask = self._encode(batch, ws, need_grad)
-        pooled = self.forward_trunk(ws).view(b, self.R, self.D)
+        native = all(isinstance(m.encoders[n], (EmbeddedSequenceEncoder, TabularEncoder)) for n in m.modality_types)
+        if self.micro_batches == 2 and native and b % 2 == 0 and b >= self.micro_batch_min:
+            ws, sample_mask = self._forward_split(batch, b, need_grad)
+            pooled = ws["pooled"].view(b, self.R, self.D)
+        else:
+            ws = self.workspace(b)
+            sample_mask = self._encode(batch, ws, need_grad)
+            pooled = self.forward_trunk(ws).view(b, self.R, self.D)
         slots = m.output_slots()
         if no_loss:
             out = {k: pooled[:, s] for k, s in slots.items()}
