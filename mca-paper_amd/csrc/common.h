@@ -47,7 +47,30 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
-extern int mca_knobs[8];      // A/B measurement knobs, set through mca_debug_set (defined in optim.hip)
+// GELU and its derivative from ONE exp and one rcp (fused GEMM epilogues, where erff + expf per element would make the
+// epilogue VALU-bound): erf by Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7, whose exp(-z^2) with z = x/sqrt(2) is the
+// Gaussian of the derivative as well.
+__device__ __forceinline__ void gelu_pair(float x, float& gelu, float& dgelu) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);          // exp(-x^2/2)
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f); p = fmaf(t, p, -0.284496736f); p = fmaf(t, p, 0.254829592f);
+  const float erf_abs = fmaf(-p * t, e, 1.f);
+  const float cdf = fmaf(copysignf(erf_abs, x), 0.5f, 0.5f);
+  gelu = x * cdf;
+  dgelu = fmaf(x * 0.3989422804014327f, e, cdf);
+}
+
+extern int mca_knobs[16];      // A/B measurement knobs, set through mca_debug_set (defined in optim.hip)
+
+// Timeline probe of a kernel's debug mode: s_memtime stamps of one wave in a per-file device buffer, read back by tools/
+// through mca_dbg_trace_read_<NAME> (exported, but not part of the ABI in include/mca_hip.h).
+#define MCA_TRACE_BUFFER(NAME)                                                                                     \
+  __device__ unsigned long long mca_trace_##NAME[1024];                                                            \
+  extern "C" int mca_dbg_trace_read_##NAME(unsigned long long* dst, int n) {                                       \
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mca_trace_##NAME), sizeof(unsigned long long) * (n > 1024 ? 1024 : n)) == hipSuccess ? 0 : -1; \
+  }
 
 static inline hipStream_t as_stream(mca_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? MCA_OK : MCA_E_LAUNCH; }

@@ -22,6 +22,15 @@
 #define BN 128
 #define BK 64
 
+static int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
+}
+
 // ---- XCD-aware bijective remap of a linear block id (guide §5 "XCD swizzle must be bijective") ----
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
@@ -44,8 +53,10 @@ __device__ __forceinline__ void geglu_bwd_piece(const float (&v)[8], const u16* 
 #pragma unroll
   for (int e = 0; e < 8; e++) {
     const float g = bf2f((u16)gv[e]), a = bf2f((u16)av[e]);
-    da[e] = (short)f2bf(v[e] * gelu_erf(g));
-    dgt[e] = (short)f2bf(v[e] * a * gelu_erf_grad(g));
+    float ge, dge;
+    gelu_pair(g, ge, dge);
+    da[e] = (short)f2bf(v[e] * ge);
+    dgt[e] = (short)f2bf(v[e] * a * dge);
   }
   *reinterpret_cast<bf16x8*>(dh + m * ldh + n) = da;
   *reinterpret_cast<bf16x8*>(dh + m * ldh + ip + n) = dgt;
@@ -55,26 +66,17 @@ __device__ __forceinline__ void geglu_bwd_piece(const float (&v)[8], const u16* 
 // accumulators are written lane = column / register = row, then every thread reads whole 16-byte pieces of rows,
 // adds bias / residual with 16-byte loads and stores 16 bytes: 4x (fp32) or 8x (bf16) fewer store instructions,
 // every global access a full 128-byte-line segment of a row.
-template <bool OUT_BF16, int RES, int EPI>
-__device__ __forceinline__ void nt_epilogue_lds(f32x16 (&acc)[2][2], float* __restrict__ cs, void* __restrict__ Cv, int64_t ldc,
-                                                const float* __restrict__ bias, const float* __restrict__ residual,
-                                                int64_t ldres, int64_t res_period, int M, int N, int m0, int n0, int wm, int wn,
-                                                int l31, int lh, int tid) {
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        cs[row * 128 + wn * 64 + j * 32 + l31] = acc[i][j][r];
-      }
-  __syncthreads();
+// Second half of the LDS epilogue: the fp32 C tile (ROWS x 128, row-major in cs) leaves as whole 16-byte row pieces, bias /
+// residual / GEGLU-backward fused; THREADS threads, every global access a full 128-byte-line segment of a row.
+template <bool OUT_BF16, int RES, int EPI, int ROWS, int THREADS>
+__device__ __forceinline__ void nt_epilogue_rows(const float* __restrict__ cs, void* __restrict__ Cv, int64_t ldc,
+                                                 const float* __restrict__ bias, const float* __restrict__ residual,
+                                                 int64_t ldres, int64_t res_period, int M, int N, int m0, int n0, int tid) {
   constexpr int EPT = OUT_BF16 ? 8 : 4;          // elements per thread per piece
   constexpr int PPR = 128 / EPT;                 // pieces per row
 #pragma unroll 4
-  for (int it = 0; it < (128 * PPR) / 256; it++) {
-    const int id = tid + 256 * it;
+  for (int it = 0; it < (ROWS * PPR) / THREADS; it++) {
+    const int id = tid + THREADS * it;
     const int row = id / PPR, c0 = (id % PPR) * EPT;
     const int m = m0 + row, n = n0 + c0;
     if (m >= M || n >= N) continue;
@@ -130,6 +132,24 @@ __device__ __forceinline__ void nt_epilogue_lds(f32x16 (&acc)[2][2], float* __re
   }
 }
 
+template <bool OUT_BF16, int RES, int EPI>
+__device__ __forceinline__ void nt_epilogue_lds(f32x16 (&acc)[2][2], float* __restrict__ cs, void* __restrict__ Cv, int64_t ldc,
+                                                const float* __restrict__ bias, const float* __restrict__ residual,
+                                                int64_t ldres, int64_t res_period, int M, int N, int m0, int n0, int wm, int wn,
+                                                int l31, int lh, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        cs[row * 128 + wn * 64 + j * 32 + l31] = acc[i][j][r];
+      }
+  __syncthreads();
+  nt_epilogue_rows<OUT_BF16, RES, EPI, 128, 256>(cs, Cv, ldc, bias, residual, ldres, res_period, M, N, m0, n0, tid);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // NT kernel with direct global->LDS staging (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.
 // The LDS destination of one wave-instruction is linear (wave base + lane*16 B), so the XOR swizzle is applied
@@ -157,6 +177,7 @@ __device__ __forceinline__ NtFragAddr nt_frag_addr(const u16* lds_base, int a_el
 }
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 #define NT_DSREAD(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+template <bool SWAP = false>          // SWAP: C^T = B.A^T (lane = row of C, registers = 4 consecutive columns)
 __device__ __forceinline__ void nt_compute_step(const NtFragAddr& f, unsigned stage_byte_off, f32x16 (&acc)[2][2]) {
   u32x4v fa[2][2], fb[2][2];          // [parity][i]
   const unsigned a0 = f.a[0] + stage_byte_off, a1 = f.a[1] + stage_byte_off;
@@ -167,8 +188,10 @@ __device__ __forceinline__ void nt_compute_step(const NtFragAddr& f, unsigned st
 #define NT_MFMA(PAR)                                                                                 \
   _Pragma("unroll") for (int i = 0; i < 2; i++)                                                      \
     _Pragma("unroll") for (int j = 0; j < 2; j++)                                                    \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&fa[PAR][i]), \
-                                                          *reinterpret_cast<const bf16x8*>(&fb[PAR][j]), acc[i][j], 0, 0, 0);
+      acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&fb[PAR][j]), \
+                                                                 *reinterpret_cast<const bf16x8*>(&fa[PAR][i]), acc[i][j], 0, 0, 0) \
+                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&fa[PAR][i]), \
+                                                                 *reinterpret_cast<const bf16x8*>(&fb[PAR][j]), acc[i][j], 0, 0, 0);
   NT_ISSUE(0, 0)
   NT_ISSUE(1, 1)
   asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
@@ -388,66 +411,286 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(
     }
     return;
   }
-  constexpr int EPT = OUT_BF16 ? 8 : 4;
-  constexpr int PPR = 128 / EPT;
-#pragma unroll 4
-  for (int it = 0; it < (BM2 * PPR) / 512; it++) {
-    const int id = tid + 512 * it;
-    const int row = id / PPR, c0 = (id % PPR) * EPT;
-    const int m = m0 + row, n = n0 + c0;
-    if (m >= M || n >= N) continue;
-    float v[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; e += 4) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(cs + row * 128 + c0 + e);
-      v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
-    }
-    const bool full = n + EPT <= N;
-    if (EPI == 1) {          // GEGLU backward: Cv = dh, residual = h (bf16), ldres = row stride of both, N = ip (multiple of 8)
-      if (OUT_BF16) geglu_bwd_piece(reinterpret_cast<const float(&)[8]>(v), reinterpret_cast<const u16*>(residual),
-                                    reinterpret_cast<u16*>(Cv), ldres, N, (int64_t)m, n);
-      continue;
-    }
-    if (bias) {
-#pragma unroll
-      for (int e = 0; e < EPT; e++) if (full || n + e < N) v[e] += bias[n + e];
-    }
-    if (RES != 0) {
-      const int64_t rr = RES == 2 ? (int64_t)(m % (int)res_period) : (int64_t)m;
-      const float* rp = residual + rr * ldres + n;
-      if (full && (((uintptr_t)rp) & 15) == 0) {
-#pragma unroll
-        for (int e = 0; e < EPT; e += 4) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(rp + e);
-          v[e] += t[0]; v[e + 1] += t[1]; v[e + 2] += t[2]; v[e + 3] += t[3];
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < EPT; e++) if (n + e < N) v[e] += rp[e];
-      }
-    }
-    if (OUT_BF16) {
-      u16* cp = reinterpret_cast<u16*>(Cv) + (int64_t)m * ldc + n;
-      if (full && (((uintptr_t)cp) & 15) == 0) {
-        uint4 pk;
-        pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4 % EPT], v[5 % EPT]); pk.w = pack2bf(v[6 % EPT], v[7 % EPT]);
-        *reinterpret_cast<uint4*>(cp) = pk;
-      } else {
-#pragma unroll
-        for (int e = 0; e < EPT; e++) if (n + e < N) cp[e] = f2bf(v[e]);
-      }
-    } else {
-      float* cp = reinterpret_cast<float*>(Cv) + (int64_t)m * ldc + n;
-      if (full && (((uintptr_t)cp) & 15) == 0) *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-      else {
-#pragma unroll
-        for (int e = 0; e < EPT; e++) if (n + e < N) cp[e] = v[e];
-      }
-    }
-  }
+  nt_epilogue_rows<OUT_BF16, RES, EPI, BM2, 512>(cs, Cv, ldc, bias, residual, ldres, res_period, M, N, m0, n0, tid);
 }
 #define NT256_LDS_BYTES (3 * (BM2 + BN) * 64 * 2)
 
+// ---------------------------------------------------------------------------------------------------------
+// PERSISTENT NT kernel (large M, N % 128 == 0): one 512-thread workgroup per CU walks 256x128 tiles.
+// Why: with K = 512 a tile is only 8 k-steps; in the one-tile-per-workgroup kernels every CU loads, computes and
+// stores in step with all the others, so HBM idles while the matrix pipes run and vice versa, and each tile pays
+// its first-load latency and the drain of its stores (a k-loop-less build of the QKV GEMM still took 108 of its 224 us).  Here
+//   * the global->LDS DMA of the NEXT tile's first two k-steps is issued before the epilogue of the current one
+//     (into stage slots 0 and 1),
+//   * the epilogue is wave-private (no workgroup barrier): each wave moves its 64x64 block through an 8 KiB scratch
+//     area (the free third stage slot + 16 KiB: 160 KiB of LDS in all) and leaves as whole 128-byte row segments;
+//     its global stores drain while the next tile's k-loop runs.
+// The MFMA operands are swapped (C^T = B.A^T) so that a lane holds 4 CONSECUTIVE columns of one row: the
+// accumulators go to the scratch area as 8/16-byte pieces instead of single elements.
+// All epilogue memory instructions are inline asm: (1) hipcc would put s_waitcnt vmcnt(0) in front of its own LDS
+// reads while an LDS-DMA is in flight, (2) the counted vmcnt waits of the next k-loop need the exact number of
+// younger stores (CDNA4: loads, stores and LDS-DMA retire in issue order).
+// vmcnt bookkeeping per wave and tile, in issue order: ... [DMA of the last k-step: 6] [NLD residual / h / bias loads]
+// (k-loop goes on: the last two steps wait vmcnt(6 + NLD) and vmcnt(NLD)) [DMA next tile k-step 0: 6] [DMA k-step 1: 6]
+// [NST stores]; k-step 0 of the next tile waits vmcnt(6 + NST), k-step 1 vmcnt(NST + 6) (the DMA of k-step 2 is issued
+// in between), later steps vmcnt(6).  Tiles that cross M (predicated stores: unknown count) drain with vmcnt(0).
+// ---------------------------------------------------------------------------------------------------------
+#define PS_GLOAD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(ptr) : "memory")
+// s_nop: a VMEM store of more than 64 bits needs a wait state before a VALU may overwrite its data VGPRs; hipcc
+// inserts it for its own stores but cannot see into inline asm
+#define PS_GSTORE(ptr, val) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(ptr), "v"(val) : "memory")
+#define PS_DSW128(addr, val) asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(val) : "memory")
+#define PS_DSW64(addr, val) asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(val) : "memory")
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+template <int N> __device__ __forceinline__ void ps_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#define NTPS_LDS_BYTES (3 * (BM2 + BN) * 64 * 2 + 16384)
+
+// timeline probe (knob 0 = 8): workgroup 0 / wave 0 writes s_memtime stamps, read back by tools/trace_persist.py
+MCA_TRACE_BUFFER(gemm)
+#define PS_STAMP() do { if (tracing && ti < 1024) mca_trace_gemm[ti++] = __builtin_amdgcn_s_memtime(); } while (0)
+
+// MODE 0: bf16 out;  1: fp32 out;  2: fp32 out + full-row fp32 residual;  3: fused GEGLU backward (bf16 out, see
+// mca_gemm_nt_geglu_bwd: C = dh, residual = h, ldres = row stride of both, N = ip)
+template <int MODE, bool BIAS>
+__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(
+    const u16* __restrict__ A, int64_t lda, const u16* __restrict__ B, int64_t ldb, void* __restrict__ Cv,
+    int64_t ldc, const float* __restrict__ bias, const float* __restrict__ residual, int64_t ldres,
+    int M, int N, int K, int tiles_n, int nwg, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) u16 lds2[];
+  constexpr int STAGE = (BM2 + BN) * 64;          // elements per stage: A tile then B tile
+  constexpr int NST = MODE == 0 ? 8 : 16;         // global stores per wave and tile
+  constexpr int NPRE = MODE >= 2 ? 16 : 1;
+  constexpr int NLD = (MODE >= 2 ? 16 : 0) + (BIAS ? (MODE == 0 ? 2 : 1) : 0);          // epilogue input loads per wave and tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int nkt = K / 64;
+  const NtFragAddr frag = nt_frag_addr(lds2, 0, BM2 * 64, wm, wn, l31, lh);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const u16*)lds2;
+  const unsigned scratch = lds_base + 2u * (unsigned)(STAGE * 2) + (unsigned)wave * 8192u;   // stage slot 2 and the 16 KiB after it
+
+  const u16* ga[4];
+  const u16* gb[2];
+  auto tile_ptrs = [&](int tile) {
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int m0 = tm * BM2, n0 = tn * BN;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int p = (i * 8 + wave) * 64 + lane, r = p >> 3, c = (p & 7) ^ gl_sw<64>(r);
+      int ra = m0 + r; if (ra > M - 1) ra = M - 1;
+      ga[i] = A + (int64_t)ra * lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int p = (i * 8 + wave) * 64 + lane, r = p >> 3, c = (p & 7) ^ gl_sw<64>(r);
+      gb[i] = B + (int64_t)(n0 + r) * ldb + c * 8;          // N % 128 == 0: no clamp
+    }
+  };
+  auto stage = [&](int k0, int st) {
+    u16* base = lds2 + st * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + (i * 8 + wave) * 512), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + BM2 * 64 + (i * 8 + wave) * 512), 16, 0, 0);
+  };
+
+  int v = blockIdx.x;                              // virtual block id: blockIdx.x + it * gridDim.x (same XCD every time)
+  if (v >= nwg) return;
+  const bool tracing = (dbg & 8) && blockIdx.x == 0 && tid == 0;
+  int ti = 0;
+  tile_ptrs(xcd_remap(v, nwg));
+  stage(0, 0);
+  stage(64, 1);
+  bool first = true;
+  while (v < nwg) {
+    const int tile = xcd_remap(v, nwg);
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int m0 = tm * BM2, n0 = tn * BN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    // ---------------- k-loop: three-stage ring, DMA two k-steps ahead (as gemm_nt_256_kernel) ----------------
+    const int mw = m0 + wm * 64, nw = n0 + wn * 64;          // this wave's 64x64 block
+    const bool edge = m0 + BM2 > M;
+    u32x4v pre[NPRE];                              // residual (fp32) / h (bf16 a | gate) pieces of this lane
+    u32x4v bvec[2];
+    // The epilogue's inputs (NLD loads per wave) are requested three k-steps before the end of the k-loop, right after the
+    // last DMA of this tile: they land under the last two k-steps.
+    auto preload = [&]() {
+      if (BIAS) {
+        // MODE 0: this lane's pieces cover columns nw + 8*(lane & 7) .. +7; fp32 modes: nw + 4*(lane & 15) .. +3
+        const float* bp = bias + nw + (MODE == 0 ? 8 * (lane & 7) : 4 * (lane & 15));
+        PS_GLOAD(bvec[0], bp);
+        if (MODE == 0) PS_GLOAD(bvec[1], bp + 4);
+      }
+      if (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            int m = mw + i * 32 + (lane >> 4) + 4 * u; if (m > M - 1) m = M - 1;
+            PS_GLOAD(pre[(i * 8 + u) % NPRE], residual + (int64_t)m * ldres + nw + 4 * (lane & 15));
+          }
+      }
+      if (MODE == 3) {
+        const u16* h = reinterpret_cast<const u16*>(residual);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            int m = mw + i * 32 + (lane >> 3) + 8 * u; if (m > M - 1) m = M - 1;
+            const u16* hp = h + (int64_t)m * ldres + nw + 8 * (lane & 7);
+            PS_GLOAD(pre[((i * 4 + u) * 2) % NPRE], hp);                  // a
+            PS_GLOAD(pre[((i * 4 + u) * 2 + 1) % NPRE], hp + N);          // gate
+          }
+      }
+    };
+    int st = 0;
+    PS_STAMP();
+    for (int kt = 0; kt < nkt; kt++) {
+      // stage kt has landed once only the operations issued after its DMA are outstanding (host guarantees nkt >= 5)
+      if (kt < 2) { if (first) ps_wait_vm<6>(); else ps_wait_vm<6 + NST>(); }
+      else if (kt == nkt - 2) ps_wait_vm<6 + NLD>();          // DMA of the last stage + the epilogue's loads
+      else if (kt == nkt - 1) ps_wait_vm<NLD>();
+      else ps_wait_vm<6>();
+      PS_STAMP();
+      __builtin_amdgcn_s_barrier();
+      PS_STAMP();
+      if (kt + 2 < nkt) { int s2 = st + 2; if (s2 >= 3) s2 -= 3; stage((kt + 2) * 64, s2); }
+      if (NLD > 0 && kt == nkt - 3) preload();
+      nt_compute_step<true>(frag, (unsigned)st * (unsigned)(STAGE * 2), acc);
+      st = st == 2 ? 0 : st + 1;
+      PS_STAMP();
+    }
+    __builtin_amdgcn_s_barrier();                  // every wave has read its last fragments: all three slots are free
+    PS_STAMP();
+    // ---------------- epilogue: acc[i][j][4q + e] = C[mw + 32i + l31][nw + 32j + 8q + 4lh + e] ----------------
+    // next tile's first two k-steps: in flight during the whole epilogue
+    const int vn = v + gridDim.x;
+    const bool has_next = vn < nwg;
+    if (has_next) {
+      tile_ptrs(xcd_remap(vn, nwg));
+      stage(0, 0);
+      stage(64, 1);
+    }
+    if (NLD > 0) { if (has_next) ps_wait_vm<12>(); else ps_wait_vm<0>(); }          // the epilogue's loads have landed (requested 3 k-steps ago)
+    PS_STAMP();
+    if (MODE == 0) {
+      // bf16 payload: 64 rows x 128 B; 16-byte chunk c of row r at chunk c ^ (r & 7)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            u32x2v pk;
+            pk[0] = pack2bf(acc[i][j][4 * q], acc[i][j][4 * q + 1]); pk[1] = pack2bf(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            const int row = i * 32 + l31, ch = j * 4 + q;
+            PS_DSW64(scratch + (unsigned)(row * 128 + ((ch ^ (row & 7)) << 4) + 8 * lh), pk);
+          }
+      u32x4v o[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int row = (lane >> 3) + 8 * u, ch = lane & 7;
+        NT_DSREAD(o[u], scratch + (unsigned)(row * 128 + ((ch ^ (row & 7)) << 4)));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int m = mw + (lane >> 3) + 8 * u;
+        if (BIAS) {          // the accumulators were rounded before the bias: add it and round again (bias GEMMs write fp32 in this model)
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 4; e++) { f[2 * e] = __uint_as_float(o[u][e] << 16); f[2 * e + 1] = __uint_as_float(o[u][e] & 0xffff0000u); }
+#pragma unroll
+          for (int e = 0; e < 8; e++) f[e] += __uint_as_float(bvec[e >> 2][e & 3]);
+#pragma unroll
+          for (int e = 0; e < 4; e++) o[u][e] = pack2bf(f[2 * e], f[2 * e + 1]);
+        }
+        u16* cp = reinterpret_cast<u16*>(Cv) + (int64_t)m * ldc + nw + 8 * (lane & 7);
+        if (m < M) PS_GSTORE(cp, o[u]);
+      }
+    } else {
+      // fp32 payload, one pass per row block i: 32 rows x 256 B; 16-byte chunk c of row r at chunk c ^ (r & 15)
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            u32x4v w;
+#pragma unroll
+            for (int e = 0; e < 4; e++) w[e] = __float_as_uint(acc[i][j][4 * q + e]);
+            const int ch = j * 8 + 2 * q + lh;
+            PS_DSW128(scratch + (unsigned)(l31 * 256 + ((ch ^ (l31 & 15)) << 4)), w);
+          }
+        if (MODE != 3) {
+          u32x4v o[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int row = (lane >> 4) + 4 * u, ch = lane & 15;
+            NT_DSREAD(o[u], scratch + (unsigned)(row * 256 + ((ch ^ (row & 15)) << 4)));
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int m = mw + i * 32 + (lane >> 4) + 4 * u;
+            u32x4v ov;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              float t = __uint_as_float(o[u][e]);
+              if (BIAS) t += __uint_as_float(bvec[0][e]);
+              if (MODE == 2) t += __uint_as_float(pre[(i * 8 + u) % NPRE][e]);
+              ov[e] = __float_as_uint(t);
+            }
+            float* cp = reinterpret_cast<float*>(Cv) + (int64_t)m * ldc + nw + 4 * (lane & 15);
+            if (m < M) PS_GSTORE(cp, ov);
+          }
+        } else {
+          // GEGLU backward: pieces of 8 columns (two adjacent 16-byte chunks of dg), h = [a | gate]
+          u32x4v o[4][2];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int row = (lane >> 3) + 8 * u, ch = 2 * (lane & 7);
+            NT_DSREAD(o[u][0], scratch + (unsigned)(row * 256 + ((ch ^ (row & 15)) << 4)));
+            NT_DSREAD(o[u][1], scratch + (unsigned)(row * 256 + (((ch + 1) ^ (row & 15)) << 4)));
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int m = mw + i * 32 + (lane >> 3) + 8 * u;
+            const u32x4v av = pre[((i * 4 + u) * 2) % NPRE], gv = pre[((i * 4 + u) * 2 + 1) % NPRE];
+            u32x4v da, dgt;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const float d0 = __uint_as_float(o[u][e >> 1][2 * (e & 1)]), d1 = __uint_as_float(o[u][e >> 1][2 * (e & 1) + 1]);
+              const float a0 = __uint_as_float(av[e] << 16), a1 = __uint_as_float(av[e] & 0xffff0000u);
+              const float g0 = __uint_as_float(gv[e] << 16), g1 = __uint_as_float(gv[e] & 0xffff0000u);
+              float ge0, dge0, ge1, dge1;
+              gelu_pair(g0, ge0, dge0); gelu_pair(g1, ge1, dge1);
+              da[e] = pack2bf(d0 * ge0, d1 * ge1);
+              dgt[e] = pack2bf(d0 * a0 * dge0, d1 * a1 * dge1);
+            }
+            u16* cp = reinterpret_cast<u16*>(Cv) + (int64_t)m * ldc + nw + 8 * (lane & 7);
+            if (m < M) { PS_GSTORE(cp, da); PS_GSTORE(cp + N, dgt); }
+          }
+        }
+      }
+    }
+    if (edge) ps_wait_vm<0>();
+    PS_STAMP();
+    first = false;
+    v = vn;
+  }
+}
 
 extern "C" int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
                            int out_bf16, const float* bias, const float* residual, int64_t ldres,
@@ -477,6 +720,31 @@ extern "C" int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, in
                        B, ldb, C, ldc, bias, residual, ldres, res_period, (int)M, (int)N, (int)K, tiles_n, nwg2);        \
   } while (0)
 #define NT_PICK_PF(OB, RS) do { if (big) NT_LAUNCH_256(OB, RS, 0); else NT_LAUNCH_G(OB, RS); } while (0)
+  // persistent kernel for bf16 / plain fp32 outputs (knob 7, A/B measurements: 1 = one-tile-per-workgroup kernels only,
+  // 3 = persistent kernel for fp32 + residual as well)
+  const bool c16 = (uintptr_t)C % 16 == 0 && ldc % (out_bf16 ? 8 : 4) == 0;
+  // (fp32 output + residual: HBM-bound, the lock-step kernel with its residual prefetch measures 10-16 % faster: MODE 2 of
+  // the persistent kernel is only used with knob 7 = 3)
+  const bool ps_res = res == 1 && !out_bf16 && ldres % 4 == 0 && (uintptr_t)residual % 16 == 0 && g_knob[7] == 3;
+  if (big && (g_knob[7] == 0 || g_knob[7] == 3) && N % BN == 0 && K >= 320 && c16 && (res == 0 || ps_res) && (!bias || (uintptr_t)bias % 16 == 0)) {
+    const int grid = nwg2 < num_cus() ? nwg2 : num_cus();
+#define NT_LAUNCH_PS(MODE, BI)                                                                                               \
+  do {                                                                                                                   \
+    static bool attr = false;                                                                                            \
+    if (!attr) {                                                                                                         \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_persist_kernel<MODE, BI>),                           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, NTPS_LDS_BYTES) != hipSuccess)                 \
+        return MCA_E_LAUNCH;                                                                                             \
+      attr = true;                                                                                                       \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((gemm_nt_persist_kernel<MODE, BI>), dim3(grid), dim3(512), NTPS_LDS_BYTES, as_stream(stream), A, lda, B, \
+                       ldb, C, ldc, bias, residual, ldres, (int)M, (int)N, (int)K, tiles_n, nwg2, g_knob[0]);            \
+  } while (0)
+    if (out_bf16) { if (bias) NT_LAUNCH_PS(0, true); else NT_LAUNCH_PS(0, false); }
+    else if (res == 0) { if (bias) NT_LAUNCH_PS(1, true); else NT_LAUNCH_PS(1, false); }
+    else { if (bias) NT_LAUNCH_PS(2, true); else NT_LAUNCH_PS(2, false); }
+    return launch_status();
+  }
   const bool pf = big && !out_bf16 && res == 1 && N % BN == 0 && K >= 512 && ldres % 4 == 0 && ldc % 4 == 0 &&
                   (uintptr_t)residual % 16 == 0 && (uintptr_t)C % 16 == 0 && (!bias || (uintptr_t)bias % 4 == 0) && g_knob[4] != 1;
   if (pf) { NT_LAUNCH_256(false, 1, 1); return launch_status(); }
@@ -504,12 +772,19 @@ extern "C" int mca_gemm_nt_geglu_bwd(const uint16_t* A, int64_t lda, const uint1
     static bool attr = false;
     if (!attr) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<true, 0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              NT256_LDS_BYTES) != hipSuccess)
+                              NT256_LDS_BYTES) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_persist_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              NTPS_LDS_BYTES) != hipSuccess)
         return MCA_E_LAUNCH;
       attr = true;
     }
-    hipLaunchKernelGGL((gemm_nt_256_kernel<true, 0, 0, 1>), dim3(nwg2), dim3(512), NT256_LDS_BYTES, as_stream(stream), A, lda, B, ldb, C,
-                       ldh, nullptr, hres, ldh, 0, (int)M, (int)N, (int)K, tiles_n, nwg2);
+    if (g_knob[7] != 1 && N % BN == 0 && K >= 320) {
+      const int grid = nwg2 < num_cus() ? nwg2 : num_cus();
+      hipLaunchKernelGGL((gemm_nt_persist_kernel<3, false>), dim3(grid), dim3(512), NTPS_LDS_BYTES, as_stream(stream), A, lda, B, ldb, C, ldh,
+                         nullptr, hres, ldh, (int)M, (int)N, (int)K, tiles_n, nwg2, g_knob[0]);
+    } else
+      hipLaunchKernelGGL((gemm_nt_256_kernel<true, 0, 0, 1>), dim3(nwg2), dim3(512), NT256_LDS_BYTES, as_stream(stream), A, lda, B, ldb, C,
+                         ldh, nullptr, hres, ldh, 0, (int)M, (int)N, (int)K, tiles_n, nwg2);
   } else {
     const int nwg = (int)((M + BM - 1) / BM) * tiles_n;
     hipLaunchKernelGGL((gemm_nt_glds_kernel<true, 0, 64, 1>), dim3(nwg), dim3(256), 0, as_stream(stream), A, lda, B, ldb, C, ldh, nullptr,

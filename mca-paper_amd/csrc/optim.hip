@@ -57,7 +57,7 @@ extern "C" int mca_adamw_step(float* p, const float* g, float* m, float* v, int6
   return launch_status();
 }
 
-int mca_knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-extern "C" int mca_debug_set(int key, int value) { if (key >= 0 && key < 8) mca_knobs[key] = value; return 0; }
+int mca_knobs[16] = {0};
+extern "C" int mca_debug_set(int key, int value) { if (key >= 0 && key < 16) mca_knobs[key] = value; return 0; }
 
 extern "C" const char* mca_version(void) { return "mca_hip 0.1 (gfx950)"; }

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmca_hip.so")
+LIB_PATH = os.environ.get("MCA_HIP_LIB") or os.path.join(_HERE, "libmca_hip.so")          # MCA_HIP_LIB: A/B against another build of the same ABI
 
 _ERR = {-1: "bad argument", -2: "misaligned pointer / leading dimension", -3: "unsupported size", -4: "launch failed"}
 

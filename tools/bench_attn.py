@@ -16,7 +16,7 @@ ws["do"].copy_(torch.randn_like(ws["do"].float()).bfloat16())
 def fwd(): eng._attn_fwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], a["lse"], eng.qmask_attn, eng.sched_attn_f, ws, b, N)
 def bwd():
     ws["dq32"].zero_()
-    eng._attn_bwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], ws["do"], a["lse"], ws["delta"], ws["dq32"], N*D, ws["dqkv"], D, 2*D, 3*D, eng.qmask_attn, eng.sched_attn_b, ws, b, N)
+    eng._attn_bwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], ws["do"], a["lse"], ws["delta"], ws["dq32"], N*D, a["dqkv"], D, 2*D, 3*D, eng.qmask_attn, eng.sched_attn_b, ws, b, N)
 def timeit(fn, n=10):
     for _ in range(3): fn()
     torch.cuda.synchronize()
