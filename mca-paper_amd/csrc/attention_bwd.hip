@@ -30,6 +30,10 @@ __device__ __forceinline__ int kt_off(int key, int c) { return key * 64 + ((c ^ 
 // [256 keys][32 q] dS^T image (64-byte rows)
 __device__ __forceinline__ int ds_off(int key, int c) { return key * 32 + ((c ^ ((key >> 1) & 3)) << 3); }
 
+// timeline probe (knob 6 bit 3): wave 0 of one workgroup writes s_memtime stamps, read back by tools/trace_attn_bwd.py
+MCA_TRACE_BUFFER(attn_bwd)
+#define AB_STAMP() do { if (tracing && ti < 1024) mca_trace_attn_bwd[ti++] = __builtin_amdgcn_s_memtime(); } while (0)
+
 __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int dbg) {
   extern __shared__ __attribute__((aligned(16))) u16 lds[];
   u16* Qs = lds;                               // 2 x 64 x 64
@@ -37,6 +41,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
   u16* Ds = Os + 2 * BQ * DH;                  // 2 x [2 sub-tiles] x 256 x 32  (dS^T)
   u16* Kimg = Ds + 2 * BKEYS * BQ;             // 256 x 64
   float* rowc = reinterpret_cast<float*>(Kimg + BKEYS * DH);      // [2][3][64]: lse, delta, qmask(bits)
+  // This key block's query-tile list, copied once and read with inline-asm LDS reads: a global load of the next entry at
+  // the top of every step carries s_waitcnt vmcnt(0), i.e. waits for the dQ atomics the previous step has just issued.
+  uint32_t* qlist = reinterpret_cast<uint32_t*>(rowc + 2 * 192);   // [MAX_QTILES]
 
   const int kbi = a.k_order[blockIdx.x];
   const int h = blockIdx.y, b = blockIdx.z;
@@ -101,18 +108,34 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
   };
 
   const int it_begin = a.k_ptr[kbi], it_end = a.k_ptr[kbi + 1];
+  const int n_it = it_end - it_begin;          // <= n_qtiles <= MAX_QTILES (checked by the host)
+  for (int i = tid; i < n_it; i += 512) qlist[i] = a.k_qt[it_begin + i];
   int buf = 0;
-  if (it_begin < it_end) { gload((int)(a.k_qt[it_begin] & 0x7fffffffu)); swrite(0); }
+  if (n_it > 0) { gload((int)(a.k_qt[it_begin] & 0x7fffffffu)); swrite(0); }
   __syncthreads();
+  const unsigned lds_qlist = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)qlist;
+  auto entry_issue = [&](int i, uint32_t& v) {          // uniform LDS read, result valid after the next lgkmcnt(0)
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(lds_qlist + 4u * (unsigned)i));
+  };
+  uint32_t e_cur_v = 0, e_nxt_v = 0;
+  if (n_it > 0) entry_issue(0, e_cur_v);
+  entry_issue(n_it > 1 ? 1 : 0, e_nxt_v);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  uint32_t e_cur = __builtin_amdgcn_readfirstlane(e_cur_v), e_nxt = __builtin_amdgcn_readfirstlane(e_nxt_v);
 
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1, g4 = lane >> 4;
   const int qb = wave & 1, db = wave >> 1;       // this wavefront's 16x16 block of the dQ tile
 
-  for (int it = it_begin; it < it_end; it++) {
-    const uint32_t ent = a.k_qt[it];
+  const bool tracing = (dbg & 8) && blockIdx.x == 2 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+  int ti = 0;
+  for (int it = 0; it < n_it; it++) {
+    AB_STAMP();
+    const uint32_t ent = e_cur;
     const int qt = (int)(ent & 0x7fffffffu);
     const bool full = (ent >> 31) != 0;
-    if (it + 1 < it_end) gload((int)(a.k_qt[it + 1] & 0x7fffffffu));
+    if (it + 1 < n_it) gload((int)(e_nxt & 0x7fffffffu));
+    uint32_t e_nn_v;
+    entry_issue(it + 2 < n_it ? it + 2 : it, e_nn_v);          // entry it+2: lands under this step's first LDS wait
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
     const u16* qs = Qs + buf * BQ * DH + sub * 32 * DH;
@@ -131,6 +154,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfrag, kf[st], s, 0, 0, 0);
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofrag, vf[st], dp, 0, 0, 0);
     }
+    AB_STAMP();
     // ---- P, dS.  Fast path: a structurally full tile whose 32 keys (this wavefront's) are all valid needs no mask.
     bf16x8 pb[2], sb[2];
     if (full && wave_keys_ok) {
@@ -165,6 +189,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
         }
       }
     }
+    AB_STAMP();
     // ---- dS^T to LDS: lane = key row, 4 consecutive q per store
 #pragma unroll
     for (int g = 0; g < 4; g++) {
@@ -191,10 +216,13 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
         dv[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot, pb[sp], dv[n], 0, 0, 0);
         dk[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, sb[sp], dk[n], 0, 0, 0);
       }
+    AB_STAMP();
 
     }
-    if (it + 1 < it_end) swrite(buf ^ 1);
+    if (it + 1 < n_it) swrite(buf ^ 1);
+    AB_STAMP();
     __syncthreads();
+    AB_STAMP();
 
     // ---- dQ tile (64 x 64) = dS (64 x 256) · K (256 x 64): per 32-row sub-tile this wavefront owns one 16x16 block,
     //      8 k-steps of 32 keys.  key carried by (lane group g4, read t, element e): 32ks + 16(g4>>1) + 8t + 4(g4&1) + e
@@ -223,6 +251,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
 #pragma unroll
         for (int sub = 0; sub < 2; sub++) dq[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[sub], bfr, dq[sub], 0, 0, 0);
       }
+      AB_STAMP();
       float* dqp = a.dq + (int64_t)b * a.dq_bstride + h * DH + db * 16 + (lane & 15);
 #pragma unroll
       for (int sub = 0; sub < 2; sub++)
@@ -233,7 +262,11 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
           if ((dbg & 1) && dq[sub][e] == 123.456f) dqp[0] = 1.f;
         }
     }
+    AB_STAMP();
     buf ^= 1;
+    e_cur = e_nxt;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (long done: the dQ product above has waited on younger reads)
+    e_nxt = __builtin_amdgcn_readfirstlane(e_nn_v);
   }
 
   // ---- epilogue: dK = scale * dK^T, dV = dV^T + dvmean (uniform rows spread over every key)
@@ -257,7 +290,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
   }
 }
 
-#define BWD_LDS_BYTES ((2 * BQ * DH * 2 + 2 * BKEYS * BQ + BKEYS * DH) * 2 + 2 * 192 * 4)
+#define MAX_QTILES 2048
+#define BWD_LDS_BYTES ((2 * BQ * DH * 2 + 2 * BKEYS * BQ + BKEYS * DH) * 2 + 2 * 192 * 4 + MAX_QTILES * 4)
 
 extern "C" int mca_attn_bwd(const mca_attn_bwd_args* a, mca_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->d_o || !a->lse || !a->delta || !a->dvmean || !a->dq || !a->dk || !a->dv ||
@@ -272,7 +306,7 @@ extern "C" int mca_attn_bwd(const mca_attn_bwd_args* a, mca_stream_t stream) {
   if ((uintptr_t)a->q % 16 || (uintptr_t)a->k % 16 || (uintptr_t)a->v % 16 || (uintptr_t)a->d_o % 16 ||
       (uintptr_t)a->dk % 8 || (uintptr_t)a->dv % 8)
     return MCA_E_ALIGN;
-  if (a->heads > 65535 || a->batch > 65535) return MCA_E_UNSUPPORTED;
+  if (a->heads > 65535 || a->batch > 65535 || a->n_qtiles > MAX_QTILES) return MCA_E_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
