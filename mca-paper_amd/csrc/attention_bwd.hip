@@ -90,21 +90,25 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
   const int srow = tid >> 3, sc = tid & 7;
   bf16x8 stage_q, stage_o;
   float stage_c = 0.f;
+  bool stage_oob = false;
+  // row constants: ONE unconditional load through a selected pointer (three predicated loads into the same register made
+  // hipcc wait vmcnt(0) between them, i.e. for the Q / dO loads just issued and every dQ atomic in flight)
+  const int cwhich = tid >> 6 < 2 ? tid >> 6 : 2, crow = tid & 63;
+  const float* cbase = cwhich == 0 ? lse_g : (cwhich == 1 ? delta_g : reinterpret_cast<const float*>(a.qmask));
   auto gload = [&](int qt) {
     int q = qt * BQ + srow; if (q > a.nq - 1) q = a.nq - 1;
     stage_q = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)q * a.q_ld + sc * 8);
     stage_o = *reinterpret_cast<const bf16x8*>(obase + (int64_t)q * a.o_ld + sc * 8);
-    if (tid < 192) {
-      const int which = tid >> 6, r = tid & 63, qq = qt * BQ + r;
-      if (which == 0) stage_c = qq < a.nq ? lse_g[qq] : INFINITY;          // rows past nq contribute nothing
-      else if (which == 1) stage_c = qq < a.nq ? delta_g[qq] : 0.f;
-      else stage_c = __uint_as_float(qq < a.nq ? a.qmask[qq] : 0u);
-    }
+    int qq = qt * BQ + crow;
+    stage_oob = qq >= a.nq;
+    if (qq > a.nq - 1) qq = a.nq - 1;
+    stage_c = cbase[qq];
   };
   auto swrite = [&](int buf) {
     *reinterpret_cast<bf16x8*>(Qs + buf * BQ * DH + qd_off(srow, sc)) = stage_q;
     *reinterpret_cast<bf16x8*>(Os + buf * BQ * DH + qd_off(srow, sc)) = stage_o;
-    if (tid < 192) rowc[buf * 192 + tid] = stage_c;
+    // rows past nq contribute nothing: lse = +inf (P = 0), delta = 0, qmask = 0
+    if (tid < 192) rowc[buf * 192 + tid] = stage_oob ? (cwhich == 0 ? INFINITY : 0.f) : stage_c;
   };
 
   const int it_begin = a.k_ptr[kbi], it_end = a.k_ptr[kbi + 1];
