@@ -49,6 +49,12 @@ int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
 int mca_gemm_nt_geglu_bwd(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* h,
                           uint16_t* dh, int64_t ldh, int64_t ip, int64_t M, int64_t K, mca_stream_t stream);
 
+/* Fused FF1 GEMM + GEGLU forward (model.py:35-38,49-54): h[M, 2*ip] = A[M,K]·W1[2*ip,K]^T (bf16, both halves kept for the
+ * backward) and g[M, ip] = h[:, :ip] * gelu(h[:, ip:]) in one pass (h is not read back).  ip % 64 == 0, ldh >= 2*ip,
+ * ldg >= ip, both % 8 == 0.                                                                                          */
+int mca_gemm_nt_geglu_fwd(const uint16_t* A, int64_t lda, const uint16_t* W1, int64_t ldb, uint16_t* h, int64_t ldh,
+                          uint16_t* g, int64_t ldg, int64_t ip, int64_t M, int64_t K, mca_stream_t stream);
+
 /* C[N,K] += A[R,N]^T · B[R,K]   (weight gradient: reduction over the R token rows; fp32 atomics
  * into C, which the caller zeroes once per step).  lda/ldb % 8 == 0; N and K are arbitrary but the
  * rows of A / B must be readable up to the next multiple of 8 columns (lda >= roundup8(N) etc.).  */

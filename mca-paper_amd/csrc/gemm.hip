@@ -450,7 +450,9 @@ MCA_TRACE_BUFFER(gemm)
 #define PS_STAMP() do { if (tracing && ti < 1024) mca_trace_gemm[ti++] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // MODE 0: bf16 out;  1: fp32 out;  2: fp32 out + full-row fp32 residual;  3: fused GEGLU backward (bf16 out, see
-// mca_gemm_nt_geglu_bwd: C = dh, residual = h, ldres = row stride of both, N = ip)
+// mca_gemm_nt_geglu_bwd: C = dh, residual = h, ldres = row stride of both, N = ip);  4: fused GEGLU forward (see
+// mca_gemm_nt_geglu_fwd: B = W1 [2*ip, K], a column tile = 64 "a" rows + the 64 "gate" rows of the same columns,
+// C = h [M, 2*ip] bf16, residual = g [M, ip] bf16 with row stride ldres, N = ip, tiles_n = ip / 64)
 template <int MODE, bool BIAS>
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(
     const u16* __restrict__ A, int64_t lda, const u16* __restrict__ B, int64_t ldb, void* __restrict__ Cv,
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(
     int M, int N, int K, int tiles_n, int nwg, int dbg) {
   extern __shared__ __attribute__((aligned(16))) u16 lds2[];
   constexpr int STAGE = (BM2 + BN) * 64;          // elements per stage: A tile then B tile
-  constexpr int NST = MODE == 0 ? 8 : 16;         // global stores per wave and tile
+  constexpr int NST = MODE == 0 ? 8 : (MODE == 4 ? 12 : 16);         // global stores per wave and tile
   constexpr int NPRE = MODE >= 2 ? 16 : 1;
   constexpr int NLD = (MODE >= 2 ? 16 : 0) + (BIAS ? (MODE == 0 ? 2 : 1) : 0);          // epilogue input loads per wave and tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -483,7 +485,9 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int p = (i * 8 + wave) * 64 + lane, r = p >> 3, c = (p & 7) ^ gl_sw<64>(r);
-      gb[i] = B + (int64_t)(n0 + r) * ldb + c * 8;          // N % 128 == 0: no clamp
+      // N % 128 == 0 (MODE 4: N % 64 == 0): no clamp.  MODE 4: tile rows 0..63 = "a" rows, 64..127 = "gate" rows
+      const int rb = MODE == 4 ? (r < 64 ? tn * 64 + r : N + tn * 64 + (r - 64)) : n0 + r;
+      gb[i] = B + (int64_t)rb * ldb + c * 8;
     }
   };
   auto stage = [&](int k0, int st) {
@@ -518,7 +522,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     // ---------------- k-loop: three-stage ring, DMA two k-steps ahead (as gemm_nt_256_kernel) ----------------
-    const int mw = m0 + wm * 64, nw = n0 + wn * 64;          // this wave's 64x64 block
+    // this wave's 64x64 block (MODE 4: columns of h: "a" part for wn = 0, "gate" part for wn = 1)
+    const int mw = m0 + wm * 64, nw = MODE == 4 ? (wn == 0 ? tn * 64 : N + tn * 64) : n0 + wn * 64;
     const bool edge = m0 + BM2 > M;
     u32x4v pre[NPRE];                              // residual (fp32) / h (bf16 a | gate) pieces of this lane
     u32x4v bvec[2];
@@ -583,7 +588,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(
     }
     if (NLD > 0) { if (has_next) ps_wait_vm<12>(); else ps_wait_vm<0>(); }          // the epilogue's loads have landed (requested 3 k-steps ago)
     PS_STAMP();
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 4) {
       // bf16 payload: 64 rows x 128 B; 16-byte chunk c of row r at chunk c ^ (r & 7)
 #pragma unroll
       for (int i = 0; i < 2; i++)
@@ -617,6 +622,36 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(
         }
         u16* cp = reinterpret_cast<u16*>(Cv) + (int64_t)m * ldc + nw + 8 * (lane & 7);
         if (m < M) PS_GSTORE(cp, o[u]);
+      }
+      if (MODE == 4) {
+        // g = a * gelu(gate): the partner wave (same rows, other column half) holds the other operand: both blocks are
+        // in the scratch areas now; wave wn takes rows 32*wn .. 32*wn + 31 of the pair's 64 rows
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const unsigned sa = lds_base + 2u * (unsigned)(STAGE * 2) + (unsigned)(wave & ~1) * 8192u, sg = sa + 8192u;
+        u32x4v av[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int row = 32 * wn + (lane >> 3) + 8 * u, ch = lane & 7;
+          NT_DSREAD(av[u], sa + (unsigned)(row * 128 + ((ch ^ (row & 7)) << 4)));
+          NT_DSREAD(gv[u], sg + (unsigned)(row * 128 + ((ch ^ (row & 7)) << 4)));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        u16* gout = const_cast<u16*>(reinterpret_cast<const u16*>(residual));
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int m = m0 + wm * 64 + 32 * wn + (lane >> 3) + 8 * u;
+          u32x4v gg;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float a0 = __uint_as_float(av[u][e] << 16), a1 = __uint_as_float(av[u][e] & 0xffff0000u);
+            const float g0 = __uint_as_float(gv[u][e] << 16), g1 = __uint_as_float(gv[u][e] & 0xffff0000u);
+            float ge0, ge1, unused;
+            gelu_pair(g0, ge0, unused); gelu_pair(g1, ge1, unused);
+            gg[e] = pack2bf(a0 * ge0, a1 * ge1);
+          }
+          u16* gp = gout + (int64_t)m * ldres + tn * 64 + 8 * (lane & 7);
+          if (m < M) PS_GSTORE(gp, gg);
+        }
       }
     } else {
       // fp32 payload, one pass per row block i: 32 rows x 256 B; 16-byte chunk c of row r at chunk c ^ (r & 15)
@@ -791,6 +826,37 @@ extern "C" int mca_gemm_nt_geglu_bwd(const uint16_t* A, int64_t lda, const uint1
                        hres, ldh, 0, (int)M, (int)N, (int)K, tiles_n, nwg);
   }
   return launch_status();
+}
+
+// h = A·W1^T (bf16, [a | gate]) and g = a * gelu(gate) in one pass (persistent kernel MODE 4); small or oddly shaped
+// problems take the plain GEMM followed by the element-wise kernel.
+extern "C" int mca_gemm_nt_geglu_fwd(const uint16_t* A, int64_t lda, const uint16_t* W1, int64_t ldb, uint16_t* h, int64_t ldh,
+                                     uint16_t* g, int64_t ldg, int64_t ip, int64_t M, int64_t K, mca_stream_t stream) {
+  if (!A || !W1 || !h || !g || M <= 0 || ip <= 0 || K <= 0) return MCA_E_BADARG;
+  if (K % 64 || lda % 8 || ldb % 8 || ldh % 8 || ldg % 8 || ip % 8 || (uintptr_t)A % 16 || (uintptr_t)W1 % 16 || (uintptr_t)h % 16 ||
+      (uintptr_t)g % 16)
+    return MCA_E_ALIGN;
+  if (lda < K || ldb < K || ldh < 2 * ip || ldg < ip) return MCA_E_BADARG;
+  if (M > (1LL << 30)) return MCA_E_UNSUPPORTED;
+  if (M >= 2048 && ip % 64 == 0 && K >= 320 && g_knob[7] != 1) {
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_persist_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              NTPS_LDS_BYTES) != hipSuccess)
+        return MCA_E_LAUNCH;
+      attr = true;
+    }
+    const int tiles_n = (int)(ip / 64);
+    const int nwg2 = (int)((M + BM2 - 1) / BM2) * tiles_n;
+    const int grid = nwg2 < num_cus() ? nwg2 : num_cus();
+    hipLaunchKernelGGL((gemm_nt_persist_kernel<4, false>), dim3(grid), dim3(512), NTPS_LDS_BYTES, as_stream(stream), A, lda, W1, ldb, h, ldh,
+                       nullptr, reinterpret_cast<const float*>(g), ldg, (int)M, (int)ip, (int)K, tiles_n, nwg2, g_knob[0]);
+    return launch_status();
+  }
+  if (ldg != ip || ldh != 2 * ip) return MCA_E_UNSUPPORTED;          // the element-wise kernel takes packed rows
+  const int rc = mca_gemm_nt(A, lda, W1, ldb, h, ldh, 1, nullptr, nullptr, 0, 0, M, 2 * ip, K, stream);
+  if (rc != MCA_OK) return rc;
+  return mca_geglu_fwd(h, g, M, (int)ip, stream);
 }
 
 // =====================================================================================================

@@ -460,8 +460,9 @@ class FusionEngine:
                            self.qmask_attn, self.sched_attn_f, ws, b, N)
             self.gemm_nt(a["o"], w["o"], a["x1"], T, D, D, residual=ws["xn"])
             self.ln_fwd(a["x1"], g, T, D, a["m2"], a["r2"], y=ws["x1n"], ldy=D, y_bf16=a["x1n_b"], cols_pad=D)
-            self.gemm_nt(a["x1n_b"], w["w1"], a["h"], T, 2 * Ip, D)
-            call("mca_geglu_fwd", ptr(a["h"]), ptr(a["g"]), T, Ip, stream_ptr())
+            # h = x1n @ W1^T and g = GEGLU(h) in one pass (h is kept for the backward, not read back here)
+            call("mca_gemm_nt_geglu_fwd", ptr(a["x1n_b"]), D, ptr(w["w1"]), D, ptr(a["h"]), 2 * Ip, ptr(a["g"]), Ip, Ip, T, D,
+                 stream_ptr(), flops=2.0 * T * 2 * Ip * D)
             self.gemm_nt(a["g"], w["w2"], xout, T, D, Ip, residual=ws["x1n"])
         xl = ws["x"][self.L]
         self.ln_fwd(xl, m.norm.gamma, T, D, ws["mf"], ws["rf"], y_bf16=ws["t_b"], cols_pad=D)

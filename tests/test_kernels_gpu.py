@@ -141,10 +141,25 @@ def test_geglu(H):
     assert rel(dh.float(), hr.grad) < 4e-3
 
 
-@pytest.mark.parametrize("rows", [500, 4100])
-def test_gemm_geglu_bwd_fused(H, rows):
+@pytest.mark.parametrize("rows,ip,D", [(500, 384, 128), (4100, 384, 128), (4100, 384, 512), (2304, 448, 320)])
+def test_gemm_geglu_fwd_fused(H, rows, ip, D):
+    """h = x @ W1^T (both halves, bf16) and g = a * gelu(gate) in one pass; the large-K cases run the persistent kernel
+    (tile columns = 64 "a" + 64 "gate" rows of W1), 4100 rows end in a partial 256-row tile."""
+    g = torch.Generator(device="cuda").manual_seed(43)
+    x = bf(torch.randn(rows, D, device="cuda", generator=g))
+    w1 = bf(torch.randn(2 * ip, D, device="cuda", generator=g) * (2.0 / D ** 0.5))
+    h = torch.zeros(rows, 2 * ip, device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros(rows, ip, device="cuda", dtype=torch.bfloat16)
+    H.call("mca_gemm_nt_geglu_fwd", x.data_ptr(), D, w1.data_ptr(), D, h.data_ptr(), 2 * ip, out.data_ptr(), ip, ip, rows, D, H.stream_ptr())
+    href = x.float() @ w1.float().t()
+    assert rel(h.float(), href) < 4e-3
+    hb = h.float()          # g is computed from the ROUNDED h, as the unfused pair of kernels does
+    assert rel(out.float(), torch.nn.functional.gelu(hb[:, ip:]) * hb[:, :ip]) < 4e-3
+
+
+@pytest.mark.parametrize("rows,ip,D", [(500, 384, 128), (4100, 384, 128), (4100, 384, 512), (2304, 640, 320)])
+def test_gemm_geglu_bwd_fused(H, rows, ip, D):
     g = torch.Generator(device="cuda").manual_seed(41)
-    ip, D = 384, 128
     h = bf(torch.randn(rows, 2 * ip, device="cuda", generator=g))
     dx = bf(torch.randn(rows, D, device="cuda", generator=g))
     w2T = bf(torch.randn(ip, D, device="cuda", generator=g) * 0.1)
