@@ -5,4 +5,4 @@ import importlib as _il
 _e = _il.import_module("mca-paper_amd.encoders")
 encoders_dict, collators, MultimodalCollator = _e.encoders_dict, _e.collators, _e.MultimodalCollator
 EmbeddedSequenceEncoder, TabularEncoder, PositionalEncoder = _e.EmbeddedSequenceEncoder, _e.TabularEncoder, _e.PositionalEncoder
-SequenceCollator, EmbeddedSequenceCollator = _e.SequenceCollator, _e.EmbeddedSequenceCollator
+SequenceCollator, EmbeddedSequenceCollator, MatrixCollator = _e.SequenceCollator, _e.EmbeddedSequenceCollator, _e.MatrixCollator

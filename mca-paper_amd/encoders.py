@@ -106,26 +106,39 @@ encoders_dict: Dict[str, type] = {
 # collators (host side; run in DataLoader workers)
 # ------------------------------------------------------------------------------------------------------
 class SequenceCollator:
-    """1-D sequences / dense tables padded to ``pad_len`` with ``pad_token``; ``attention_mask`` is int64 with
-    1 where the padded value equals pad_token (encoders.py:286-311).  A missing sample (None) becomes an
-    all-pad row."""
+    """1-D sequences / dense tables padded (or cropped) to ``pad_len`` with ``pad_token``; ``attention_mask`` is int64 with
+    1 where the padded value equals pad_token (encoders.py:286-311).  A missing sample (None) becomes an all-pad row.
+    ``other_col`` is accepted and ignored, as in the reference (its ``__call__`` rebuilds the input dict with the data
+    column only, so the second column never reaches the output).  One output buffer is filled in place."""
 
     def __init__(self, pad_token=0, pad_len=2048, data_col_name="indices", other_col="data", attn_mask=True, **kwargs):
         self.pad_token, self.pad_len, self.attn_mask = pad_token, pad_len, attn_mask
         self.data_col_name, self.other_col = data_col_name, other_col
 
+    def _fill(self, rows, fill):
+        # dtype of the stacked batch: promotion over the rows, a missing row counting as the float32 empty tensor the
+        # reference substitutes (an int index column with a missing sample therefore comes out float32)
+        dtype = None
+        for x in rows:
+            d = x.dtype if x is not None else torch.float32
+            dtype = d if dtype is None else torch.promote_types(dtype, d)
+        out = torch.full((len(rows), self.pad_len), fill, dtype=dtype or torch.float32)
+        for i, x in enumerate(rows):
+            if x is not None and x.numel():
+                n = min(x.shape[-1], self.pad_len)          # longer rows are cropped (the reference's negative F.pad does that)
+                out[i, :n] = x[..., :n]
+        return out
+
     def __call__(self, data):
-        rows = [x if x is not None else torch.empty([0]) for x in data[self.data_col_name]]
-        padded = [pad(x, (0, self.pad_len - x.shape[-1]), mode="constant", value=self.pad_token) for x in rows]
-        out = {self.data_col_name: torch.stack(padded)}
+        out = {self.data_col_name: self._fill(data[self.data_col_name], self.pad_token)}
         if self.attn_mask:
             out["attention_mask"] = (out[self.data_col_name] == self.pad_token).to(torch.long)
         return out
 
 
 class EmbeddedSequenceCollator:
-    """(len, emb) float sequences truncated / zero-padded to ``pad_len``; bool ``attention_mask`` True = pad
-    (encoders.py:314-343).  None -> empty (0, embedding_size) sequence -> fully padded row."""
+    """(len, emb) float sequences truncated / padded with ``fill_value`` to ``pad_len``; bool ``attention_mask`` True = pad
+    (encoders.py:314-343).  None -> fully padded row.  NaN / inf are cleaned (``nan_to_num``) when ``clean``."""
 
     def __init__(self, pad_token=-1, fill_value=0.0, pad_len=2048, embedding_size=512, data_col_name="values",
                  attn_mask=True, truncate=True, clean=True, **kwargs):
@@ -133,23 +146,49 @@ class EmbeddedSequenceCollator:
         self.data_col_name, self.attn_mask, self.truncate, self.clean = data_col_name, attn_mask, truncate, clean
 
     def __call__(self, data):
-        seqs = [x if x is not None else torch.empty([0, self.embedding_size]) for x in data[self.data_col_name]]
-        if self.truncate:
-            seqs = [x[: self.pad_len] for x in seqs]
+        seqs = data[self.data_col_name]
+        first = next((x for x in seqs if x is not None), None)
+        width = first.shape[-1] if first is not None else self.embedding_size
+        dtype = first.dtype if first is not None else torch.float32
+        tokens = torch.full((len(seqs), self.pad_len, width), self.fill_value, dtype=dtype)
+        mask = torch.ones(len(seqs), self.pad_len, dtype=torch.bool)
+        for i, x in enumerate(seqs):
+            if x is None:
+                continue
+            n = min(x.shape[0], self.pad_len)          # truncate=False crops as well: the reference's negative F.pad
+            tokens[i, :n] = x[:n]
+            mask[i, :n] = False
         if self.clean:
-            seqs = [x.nan_to_num() for x in seqs]
+            tokens = tokens.nan_to_num_()
         out = {}
         if self.attn_mask:
-            m = torch.ones(len(seqs), self.pad_len, dtype=torch.bool)
-            for i, x in enumerate(seqs):
-                m[i, : x.shape[0]] = False
-            out["attention_mask"] = m
-        out["tokens"] = torch.stack([pad(x, (0, 0, 0, self.pad_len - x.shape[-2]), mode="constant", value=self.fill_value)
-                                     for x in seqs])
+            out["attention_mask"] = mask
+        out["tokens"] = tokens
         return out
 
 
+class MatrixCollator:
+    """(rows, channels) float matrices padded along rows to ``pad_len`` with ``pad_token`` and cut to the first
+    ``max_channels`` columns when that is non-zero; a missing sample is a (max_channels, pad_len) block of pad_token,
+    as the reference builds it (encoders.py:346-364: note the transposed shape of the placeholder, kept)."""
+
+    def __init__(self, pad_token=-10000, pad_len=2048, attn_mask=True, max_channels=0, **kwargs):
+        self.pad_token, self.pad_len, self.max_channels = pad_token, pad_len, max_channels
+
+    def __call__(self, data):
+        mats = [torch.full((self.max_channels, self.pad_len), self.pad_token, dtype=torch.float) if x is None else x
+                for x in data["values"]]
+        outs = []
+        for x in mats:
+            n = min(x.shape[0], self.pad_len)
+            o = torch.full((self.pad_len, x.shape[1]), self.pad_token, dtype=x.dtype)
+            o[:n] = x[:n]
+            outs.append(o[:, : self.max_channels] if self.max_channels else o)
+        return {"values": torch.stack(outs)}
+
+
 collators: Dict[str, type] = {
+    "matrix": MatrixCollator,
     "sequence": SequenceCollator,
     "embedded_sequence": EmbeddedSequenceCollator,
 }

@@ -12,6 +12,8 @@ Fixtures
   tiny_<case>.pt : 3 modalities (2 embedded-sequence + 1 tabular), dim 32, 2 heads x 16, depth 2, 8 fusion
                    tokens, combos [3,2]; inputs, initial state_dict, every output, every gradient,
                    grad-norm, weights after 1 and 2 AdamW steps (lr 1e-3, clip 2.0).
+  collators.pt   : the reference's MultimodalCollator (sequence / embedded_sequence / matrix) on ragged samples with
+                   missing modalities: input samples and collated batch.
   cmu_<case>.pt  : CMU-shaped config (N=2538, D=512, L=5) at b=2 with weights from the build's own
                    deterministic initialiser; pooled embeddings, loss terms, per-parameter grad norms.
 """
@@ -234,15 +236,53 @@ def make_cmu(refmodel):
         print(f"cmu_{case}: loss {float(rec['loss']):.5f}")
 
 
+def make_collators(refenc):
+    """The reference's collators (encoders.py:286-403) on ragged samples with missing modalities, NaNs, over-long rows."""
+    g = torch.Generator().manual_seed(7)
+    cfg = {"seq": {"type": "embedded_sequence", "pad_len": 6, "embedding_size": 3, "data_col_name": "data"},
+           "tab": {"type": "sequence", "pad_len": 5, "data_col_name": "values", "pad_token": -10000, "other_col": "extra"},
+           "ids": {"type": "sequence", "pad_len": 7, "data_col_name": "indices", "pad_token": 0},
+           "mat": {"type": "matrix", "pad_len": 4, "max_channels": 3}}
+    def sample(i):
+        s = {}
+        n = int(torch.randint(0, 10, (1,), generator=g))
+        x = torch.randn(n, 3, generator=g)
+        if i == 2 and n: x[0, 0] = float("nan")
+        s["seq"] = {"data": None if i == 1 else x}
+        v = torch.randn(5, generator=g)
+        if i == 3: v[1] = -10000.0
+        s["tab"] = {"values": None if i == 4 else v, "extra": torch.arange(5.0)}
+        k = int(torch.randint(0, 8, (1,), generator=g))
+        s["ids"] = {"indices": None if i == 0 else torch.randint(1, 50, (k,), generator=g)}
+        r = int(torch.randint(1, 5, (1,), generator=g))
+        s["mat"] = {"values": torch.randn(r, 5, generator=g)}
+        s["labels"] = {"y": torch.tensor(float(i))}
+        return s
+    samples = [sample(i) for i in range(6)]
+    import copy
+    out = refenc.MultimodalCollator(copy.deepcopy(cfg), labels="labels")(copy.deepcopy(samples))
+    # a missing matrix sample only stacks when its placeholder shape (max_channels, pad_len) matches: square case
+    cfg_sq = {"mat": {"type": "matrix", "pad_len": 3, "max_channels": 3}}
+    samples_sq = [{"mat": {"values": torch.randn(2, 3, generator=g)}}, {"mat": {"values": None}}]
+    out_sq = refenc.MultimodalCollator(copy.deepcopy(cfg_sq))(copy.deepcopy(samples_sq))
+    torch.save({"config": cfg, "samples": samples, "out": {k: dict(v) for k, v in out.items()},
+                "config_sq": cfg_sq, "samples_sq": samples_sq, "out_sq": {k: dict(v) for k, v in out_sq.items()}},
+               os.path.join(GOLD, "collators.pt"))
+    print("wrote collators.pt")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--collators", action="store_true")
     ap.add_argument("--cmu", action="store_true")
     ap.add_argument("--init", action="store_true")
     ap.add_argument("--tiny", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     refmodel, refenc = import_reference()
-    if a.tiny or not (a.cmu or a.init):
+    if a.collators:
+        make_collators(refenc)
+    if a.tiny or not (a.cmu or a.init or a.collators):
         make_tiny(refmodel)
     if a.init:
         make_init_parity(refmodel)

@@ -140,6 +140,22 @@ def test_collators_layout(pkg):
     assert out["t"]["attention_mask"].tolist() == [[0] * 5, [1] * 5, [0, 1, 0, 0, 0]]
 
 
+def test_collators_match_reference_golden(pkg):
+    """tests/golden/collators.pt: output of the reference's own MultimodalCollator (oracle/make_goldens.py --collators) on
+    ragged samples with missing modalities, a NaN, an over-long sequence and a labels entry."""
+    import copy
+    gold = torch.load(os.path.join(REPO, "tests", "golden", "collators.pt"), weights_only=False)
+    for cfg_key, smp_key, out_key, labels in (("config", "samples", "out", "labels"), ("config_sq", "samples_sq", "out_sq", None)):
+        got = pkg.MultimodalCollator(copy.deepcopy(gold[cfg_key]), labels=labels)(copy.deepcopy(gold[smp_key]))
+        want = gold[out_key]
+        assert set(got) == set(want)
+        for mod in want:
+            assert set(got[mod]) == set(want[mod]), (mod, set(got[mod]), set(want[mod]))
+            for col, t in want[mod].items():
+                assert got[mod][col].dtype == t.dtype and got[mod][col].shape == t.shape, (mod, col)
+                assert torch.equal(got[mod][col], t), (mod, col)
+
+
 def test_c_abi_library_exports_every_declared_symbol():
     header = open(os.path.join(REPO, "include", "mca_hip.h")).read()
     declared = set(re.findall(r"\b(mca_[a-z0-9_]+)\s*\(", header))
