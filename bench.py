@@ -33,13 +33,14 @@ def pmc_traffic(kernel_key: str):
     MI355X_MICROARCH.md section HBM, + WRITE_SIZE; separate --pmc passes of this same command, see profiles/README.md).
     None when no PMC summary is committed for that kernel."""
     path = os.path.join(REPO, "profiles", "r01_hbm_traffic_pmc.json")
-    names = {"mca_gemm_nt": "gemm_nt_256_kernel", "mca_gemm_tn_acc": "gemm_tn_kernel", "mca_attn_fwd/layer": "attn_fwd_kernel",
-             "mca_attn_bwd/layer": "attn_bwd_kernel"}
+    names = {"mca_gemm_nt": "gemm_nt_", "mca_gemm_tn_acc": "gemm_tn_", "mca_attn_fwd/layer": "attn_fwd_kernel",
+             "mca_attn_bwd/layer": "attn_bwd_kernel", "mca_gemm_nt_geglu_fwd": "gemm_nt_persist_kernel<4",
+             "mca_gemm_nt_geglu_bwd": "gemm_nt_persist_kernel<3"}
     if not os.path.exists(path) or kernel_key not in names:
         return None
     tot_b, tot_n = 0.0, 0
     for k, v in json.load(open(path)).items():
-        if names[kernel_key] in k:
+        if names[kernel_key] in k and not (kernel_key == "mca_gemm_nt" and ("persist_kernel<3" in k or "persist_kernel<4" in k)):
             tot_b += (v["fetch_MB_x2_gfx950"] + v["write_MB_per_launch"]) * 1e6 * v["launches"]
             tot_n += v["launches"]
     return {"bytes_per_launch": round(tot_b / tot_n), "source": "profiles/r01_hbm_traffic_pmc.json"} if tot_n else None
@@ -126,7 +127,7 @@ def main():
             eng.overlap_wgrad, eng.micro_batches = False, 1
         step()
         eng.overlap_wgrad, eng.micro_batches = saved
-    timed = ("mca_attn_fwd", "mca_attn_bwd", "mca_gemm_nt", "mca_gemm_nt_geglu_bwd", "mca_gemm_tn_acc")
+    timed = ("mca_attn_fwd", "mca_attn_bwd", "mca_gemm_nt", "mca_gemm_nt_geglu_fwd", "mca_gemm_nt_geglu_bwd", "mca_gemm_tn_acc")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

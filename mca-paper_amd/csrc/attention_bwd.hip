@@ -45,8 +45,11 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
   // the top of every step carries s_waitcnt vmcnt(0), i.e. waits for the dQ atomics the previous step has just issued.
   uint32_t* qlist = reinterpret_cast<uint32_t*>(rowc + 2 * 192);   // [MAX_QTILES]
 
-  const int kbi = a.k_order[blockIdx.x];
-  const int h = blockIdx.y, b = blockIdx.z;
+  // XCD-aware order: the key blocks of one (sample, head) sweep the same Q / dO tiles: one XCD takes them all
+  const int lin0 = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+  const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y * gridDim.z));          // knob 9 = 16: launch order (A/B)
+  const int kbi = a.k_order[lin % (int)gridDim.x];
+  const int h = (lin / (int)gridDim.x) % (int)gridDim.y, b = lin / (int)(gridDim.x * gridDim.y);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int key0 = kbi * BKEYS;
@@ -318,7 +321,7 @@ extern "C" int mca_attn_bwd(const mca_attn_bwd_args* a, mca_stream_t stream) {
       return MCA_E_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(a->n_ktiles, a->heads, a->batch), dim3(512), BWD_LDS_BYTES, as_stream(stream), *a, mca_knobs[6]);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(a->n_ktiles, a->heads, a->batch), dim3(512), BWD_LDS_BYTES, as_stream(stream), *a, mca_knobs[6] | mca_knobs[9]);
   return launch_status();
 }
 

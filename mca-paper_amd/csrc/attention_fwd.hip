@@ -29,15 +29,19 @@ __device__ __forceinline__ int k_off(int r, int c) { return r * 64 + ((c ^ ((r >
 // fall into 4 distinct 64-byte bank quarters
 __device__ __forceinline__ int v_off(int r, int c) { return r * 64 + ((c ^ (((r >> 1) & 1) << 2)) << 3); }
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int dbg) {
   __shared__ __attribute__((aligned(16))) u16 lds[2 * 2 * AK * DH];   // K,V double-buffered: 32 KiB
   __shared__ __attribute__((aligned(16))) uint8_t kinfo[2][AK];
   __shared__ uint8_t flags_s[MAX_KTILES];       // this sample's key-tile flags (read from LDS: no vmcnt wait in the loop)
   u16* Ks = lds;
   u16* Vs = lds + 2 * AK * DH;
 
-  const int qt = a.q_order[blockIdx.x];
-  const int h = blockIdx.y, b = blockIdx.z;
+  // XCD-aware order: the query tiles of one (sample, head) read the same K / V, so they are given to one XCD (in launch
+  // order they were dealt round all eight and every L2 fetched every K / V: 1,128 MB per launch against 250 MB)
+  const int lin0 = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+  const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y * gridDim.z));          // knob 9 = 16: launch order (A/B)
+  const int qt = a.q_order[lin % (int)gridDim.x];
+  const int h = (lin / (int)gridDim.x) % (int)gridDim.y, b = lin / (int)(gridDim.x * gridDim.y);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int q0 = qt * AQ + wave * 32;
@@ -247,7 +251,7 @@ extern "C" int mca_attn_fwd(const mca_attn_fwd_args* a, mca_stream_t stream) {
       (uintptr_t)a->keyinfo % 4)
     return MCA_E_ALIGN;
   if (a->heads > 65535 || a->batch > 65535 || a->n_ktiles > MAX_KTILES) return MCA_E_UNSUPPORTED;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(a->n_qtiles, a->heads, a->batch), dim3(256), 0, as_stream(stream), *a);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(a->n_qtiles, a->heads, a->batch), dim3(256), 0, as_stream(stream), *a, mca_knobs[9]);
   return launch_status();
 }
 

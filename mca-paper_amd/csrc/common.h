@@ -62,6 +62,15 @@ __device__ __forceinline__ void gelu_pair(float x, float& gelu, float& dgelu) {
   dgelu = fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
+// ---- XCD-aware bijective remap of a linear workgroup id (guide section 5, "XCD swizzle must be bijective"): workgroup id i
+// runs on XCD i % 8; the remap gives every XCD a CONTIGUOUS range of the returned index, so workgroups that share operands
+// (neighbouring indices) share an L2
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + bid / 8;
+}
+
 extern int mca_knobs[16];      // A/B measurement knobs, set through mca_debug_set (defined in optim.hip)
 
 // Timeline probe of a kernel's debug mode: s_memtime stamps of one wave in a per-file device buffer, read back by tools/

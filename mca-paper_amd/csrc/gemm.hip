@@ -31,13 +31,6 @@ static int num_cus() {
   return n;
 }
 
-// ---- XCD-aware bijective remap of a linear block id (guide §5 "XCD swizzle must be bijective") ----
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + bid / 8;
-}
-
 // LDS image of a [128 rows][64 bf16] tile (128-byte rows): 16-byte chunk c of row r lives at chunk
 // c ^ ((r >> 1) & 7): a 16-lane group of ds_read_b128 (16 distinct rows, same logical chunk) then covers
 // all 64 banks exactly once.
@@ -1013,12 +1006,19 @@ __device__ __forceinline__ int tn_off256(int r, int c) { return r * 256 + ((c ^ 
 
 __global__ __launch_bounds__(512) void gemm_tn_256_kernel(const u16* __restrict__ A, int64_t lda,
                                                            const u16* __restrict__ B, int64_t ldb, float* __restrict__ C,
-                                                           int64_t ldc, int R, int N, int K, int tiles_k, int rows_per_split) {
+                                                           int64_t ldc, int R, int N, int K, int tiles_k, int rows_per_split, int dbg) {
   extern __shared__ __attribute__((aligned(16))) u16 ldst[];
   constexpr int STAGE = BR * (256 + 128);        // elements per stage
-  const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+  // XCD-aware order: the output tiles of ONE row split read the same rows of A and B, so they must share an L2.  The
+  // linear workgroup id (XCD = id % 8) is remapped so that each XCD owns a contiguous range of (split, tile) pairs;
+  // in launch order the tiles of a split were dealt round the eight XCDs and every XCD fetched every row (PMC: 905 MB
+  // fetched per launch against ~330 MB of operands; 318 MB with the remap).
+  const int lin0 = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+  const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y));          // knob 9 = 16: launch order (A/B)
+  const int tile_id = lin % (int)gridDim.x, split_id = lin / (int)gridDim.x;
+  const int tn = tile_id / tiles_k, tk = tile_id % tiles_k;
   const int n0 = tn * 256, k0 = tk * 128;
-  const int r_begin = blockIdx.y * rows_per_split;
+  const int r_begin = split_id * rows_per_split;
   int r_end = r_begin + rows_per_split; if (r_end > R) r_end = R;
   if (r_begin >= r_end) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1173,7 +1173,7 @@ extern "C" int mca_gemm_tn_acc(const uint16_t* A, int64_t lda, const uint16_t* B
       attr = true;
     }
     hipLaunchKernelGGL(gemm_tn_256_kernel, dim3(tiles, (unsigned)splits), dim3(512), TN256_LDS_BYTES, as_stream(stream), A, lda, B,
-                       ldb, C, ldc, (int)R, (int)N, (int)K, tiles_k, (int)rps);
+                       ldb, C, ldc, (int)R, (int)N, (int)K, tiles_k, (int)rps, g_knob[9]);
     return launch_status();
   }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, as_stream(stream), A, lda, B, ldb, C,

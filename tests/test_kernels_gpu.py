@@ -30,7 +30,8 @@ def bf(x):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (1000, 1536, 512), (129, 2816, 512), (16, 512, 512), (4060, 512, 1408)])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (1000, 1536, 512), (129, 2816, 512), (16, 512, 512), (4060, 512, 1408),
+                                   (4100, 1536, 320), (2600, 2816, 512)])          # last two: persistent kernel, grouped column tiles
 def test_gemm_nt(H, M, N, K):
     g = torch.Generator(device="cuda").manual_seed(1)
     A = bf(torch.randn(M, K, device="cuda", generator=g))
@@ -141,7 +142,7 @@ def test_geglu(H):
     assert rel(dh.float(), hr.grad) < 4e-3
 
 
-@pytest.mark.parametrize("rows,ip,D", [(500, 384, 128), (4100, 384, 128), (4100, 384, 512), (2304, 448, 320)])
+@pytest.mark.parametrize("rows,ip,D", [(500, 384, 128), (4100, 384, 128), (4100, 384, 512), (2304, 448, 320), (2100, 1408, 512)])
 def test_gemm_geglu_fwd_fused(H, rows, ip, D):
     """h = x @ W1^T (both halves, bf16) and g = a * gelu(gate) in one pass; the large-K cases run the persistent kernel
     (tile columns = 64 "a" + 64 "gate" rows of W1), 4100 rows end in a partial 256-row tile."""
@@ -157,7 +158,7 @@ def test_gemm_geglu_fwd_fused(H, rows, ip, D):
     assert rel(out.float(), torch.nn.functional.gelu(hb[:, ip:]) * hb[:, :ip]) < 4e-3
 
 
-@pytest.mark.parametrize("rows,ip,D", [(500, 384, 128), (4100, 384, 128), (4100, 384, 512), (2304, 640, 320)])
+@pytest.mark.parametrize("rows,ip,D", [(500, 384, 128), (4100, 384, 128), (4100, 384, 512), (2304, 640, 320), (2100, 1408, 512)])
 def test_gemm_geglu_bwd_fused(H, rows, ip, D):
     g = torch.Generator(device="cuda").manual_seed(41)
     h = bf(torch.randn(rows, 2 * ip, device="cuda", generator=g))
