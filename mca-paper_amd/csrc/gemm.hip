@@ -1143,19 +1143,166 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(const u16* __restrict_
 }
 #define TN256_LDS_BYTES (3 * BR * (256 + 128) * 2)
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient, 256(n) x 256(k) output tile: the k-loop of these GEMMs is bound by the L2 -> LDS path per CU
+// (DESIGN.md section 5), so the lever is bytes per flop: 32 KiB of operands per 32-row step feed 16 MFMAs per
+// wavefront, against 24 KiB for the same 16 MFMAs... per 2x the flops: 256x256 moves 2/3 of the bytes per flop of
+// 256x128.  8 wavefronts as 4 (n) x 2 (k), each 64 x 128 = 2 x 4 accumulators (128 VGPRs); FOUR LDS stages of
+// 32 rows (128 KiB), DMA three steps ahead; fragments by ds_read_b64_tr_b16 (12 per k16-step for 8 MFMAs).
+// ---------------------------------------------------------------------------------------------------------
+#define BR2 32
+#define TN2_STAGE (BR2 * 512)          // elements per stage: A image [32][256] then B image [32][256]
+#define TN2_LDS_BYTES (4 * TN2_STAGE * 2)
+__global__ __launch_bounds__(512) void gemm_tn_256x256_kernel(const u16* __restrict__ A, int64_t lda,
+                                                               const u16* __restrict__ B, int64_t ldb, float* __restrict__ C,
+                                                               int64_t ldc, int R, int N, int K, int tiles_k, int rows_per_split, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) u16 ldst[];
+  const int lin0 = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+  const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y));          // tiles of one split on one XCD
+  const int tile_id = lin % (int)gridDim.x, split_id = lin / (int)gridDim.x;
+  const int tn = tile_id / tiles_k, tk = tile_id % tiles_k;
+  const int n0 = tn * 256, k0 = tk * 256;
+  const int r_begin = split_id * rows_per_split;
+  int r_end = r_begin + rows_per_split; if (r_end > R) r_end = R;
+  if (r_begin >= r_end) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int lh = lane >> 5;
+  const u16* zero = reinterpret_cast<const u16*>(g_zero16);
+
+  // DMA: an operand image is 1024 chunks of 16 B = 16 wave-instructions, two per wave; position p -> row p >> 5, chunk
+  // position p & 31 holds logical chunk (p & 31) ^ ((row & 3) << 2)
+  int srow[2];
+  const u16* pa[2];
+  const u16* pb[2];
+  bool ca_ok[2], cb_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int p = (i * 8 + wave) * 64 + lane, r = p >> 5, c = (p & 31) ^ ((r & 3) << 2);
+    srow[i] = r;
+    ca_ok[i] = n0 + c * 8 < N; pa[i] = A + n0 + c * 8;
+    cb_ok[i] = k0 + c * 8 < K; pb[i] = B + k0 + c * 8;
+  }
+  auto stage = [&](int r0, int st) {
+    u16* base = ldst + st * TN2_STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int r = r0 + srow[i];
+      const u16* sa = (r < r_end && ca_ok[i]) ? pa[i] + (int64_t)r * lda : zero;
+      const u16* sb = (r < r_end && cb_ok[i]) ? pb[i] + (int64_t)r * ldb : zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                       (__attribute__((address_space(3))) void*)(base + (i * 8 + wave) * 512), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                       (__attribute__((address_space(3))) void*)(base + BR2 * 256 + (i * 8 + wave) * 512), 16, 0, 0);
+    }
+  };
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // transposed-read coordinates as in gemm_tn_256_kernel: lane supplies LDS row 8*lh + tq (+4 for read t = 1, +16 per
+  // k16-step), columns 16*tg + 4*tp .. +3 of its 32-column operand block
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  unsigned abase[2], bbase[4];
+  {
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) u16*)ldst;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int ca = wn * 64 + i * 32 + 16 * tg + 4 * tp;
+      abase[i] = lds0 + 2u * (unsigned)((8 * lh + tq) * 256 + (((ca >> 3) ^ (tq << 2)) << 3) + (ca & 7));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int cb = wk * 128 + j * 32 + 16 * tg + 4 * tp;
+      bbase[j] = lds0 + 2u * (unsigned)(BR2 * 256) + 2u * (unsigned)((8 * lh + tq) * 256 + (((cb >> 3) ^ (tq << 2)) << 3) + (cb & 7));
+    }
+  }
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#define TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+  const int nsteps = (r_end - r_begin + BR2 - 1) / BR2;
+  stage(r_begin, 0);
+  if (nsteps > 1) stage(r_begin + BR2, 1);
+  if (nsteps > 2) stage(r_begin + 2 * BR2, 2);
+  int st = 0;
+  for (int sp = 0; sp < nsteps; sp++) {
+    // stage sp has landed once only the (4 loads each of the) younger stages are outstanding
+    if (sp + 2 < nsteps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (sp + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (sp + 3 < nsteps) stage(r_begin + (sp + 3) * BR2, (st + 3) & 3);
+    const unsigned so = (unsigned)st * (unsigned)(TN2_STAGE * 2);
+    u32x2 fa[2][2][2], fb[2][4][2];          // [k16-step][block][t]
+#define TN2_ISSUE(KS)                                                                                   \
+    TR_READ(fa[KS][0][0], abase[0] + so, (KS) * 8192); TR_READ(fa[KS][0][1], abase[0] + so, (KS) * 8192 + 2048); \
+    TR_READ(fa[KS][1][0], abase[1] + so, (KS) * 8192); TR_READ(fa[KS][1][1], abase[1] + so, (KS) * 8192 + 2048); \
+    TR_READ(fb[KS][0][0], bbase[0] + so, (KS) * 8192); TR_READ(fb[KS][0][1], bbase[0] + so, (KS) * 8192 + 2048); \
+    TR_READ(fb[KS][1][0], bbase[1] + so, (KS) * 8192); TR_READ(fb[KS][1][1], bbase[1] + so, (KS) * 8192 + 2048); \
+    TR_READ(fb[KS][2][0], bbase[2] + so, (KS) * 8192); TR_READ(fb[KS][2][1], bbase[2] + so, (KS) * 8192 + 2048); \
+    TR_READ(fb[KS][3][0], bbase[3] + so, (KS) * 8192); TR_READ(fb[KS][3][1], bbase[3] + so, (KS) * 8192 + 2048);
+#define TN2_MFMA(KS)                                                                                    \
+    {                                                                                                   \
+      bf16x8 af[2], bfr[4];                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 2; i++) {                                                   \
+        const uint4 ua = make_uint4(fa[KS][i][0][0], fa[KS][i][0][1], fa[KS][i][1][0], fa[KS][i][1][1]); \
+        af[i] = *reinterpret_cast<const bf16x8*>(&ua);                                                  \
+      }                                                                                                 \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                   \
+        const uint4 ub = make_uint4(fb[KS][j][0][0], fb[KS][j][0][1], fb[KS][j][1][0], fb[KS][j][1][1]); \
+        bfr[j] = *reinterpret_cast<const bf16x8*>(&ub);                                                 \
+      }                                                                                                 \
+      _Pragma("unroll") for (int i = 0; i < 2; i++)                                                     \
+        _Pragma("unroll") for (int j = 0; j < 4; j++)                                                   \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);       \
+    }
+    TN2_ISSUE(0)
+    TN2_ISSUE(1)
+    asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    TN2_MFMA(0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    TN2_MFMA(1)
+    st = (st + 1) & 3;
+  }
+#undef TN2_ISSUE
+#undef TN2_MFMA
+#undef TR_READ
+  // C[n][k]: row n in registers, column k on the lane -> 128-byte contiguous atomic segments per row
+  const int l31 = lane & 31;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int k = k0 + wk * 128 + j * 32 + l31;
+    if (k >= K) continue;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n < N) atomicAdd(C + (int64_t)n * ldc + k, acc[i][j][r]);
+      }
+  }
+}
+
 extern "C" int mca_gemm_tn_acc(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,
                                int64_t R, int64_t N, int64_t K, mca_stream_t stream) {
   if (!A || !B || !C || R <= 0 || N <= 0 || K <= 0) return MCA_E_BADARG;
   if (lda % 8 || ldb % 8 || (uintptr_t)A % 16 || (uintptr_t)B % 16) return MCA_E_ALIGN;
   if (lda < (N + 7) / 8 * 8 || ldb < (K + 7) / 8 * 8 || ldc < K) return MCA_E_BADARG;
   if (R > (1LL << 30)) return MCA_E_UNSUPPORTED;
-  const bool big = N >= 512 && R >= 4096 && g_knob[5] != 1;          // knob 5 = 1 forces the 128x128 kernel
-  const int tiles_k = (int)((K + 127) / 128);
+  const bool big = N >= 512 && R >= 4096 && g_knob[5] != 1;          // knob 5 = 1 forces the 128x128 kernel, 2 the 256x128 one
+  // 256x256 tiles when the output has at least 8 of them (a 512x512 gradient has 4: the 256x128 kernel with half the
+  // splits, i.e. half the atomic bytes, measured 70 vs 93 us)
+  const bool huge = big && K >= 512 && g_knob[5] != 2 && ((N + 255) / 256) * ((K + 255) / 256) >= 8;
+  const int tiles_k = (int)(huge ? (K + 255) / 256 : (K + 127) / 128);
   const int tiles_n = big ? (int)((N + 255) / 256) : (int)((N + 127) / 128);
   const int tiles = tiles_n * tiles_k;
   // split the reduction: one (big: 1 WG/CU) or two (2 WGs/CU) full rounds of workgroups; every split adds N*K*4 bytes
   // of fp32 atomics; at least 4 steps of 64 rows each
   int64_t splits = big ? (tiles <= 16 ? 256 / tiles : 512 / tiles) : (tiles <= 32 ? 512 / tiles : 1024 / tiles);
+  if (huge) splits = 256 / tiles > 0 ? 256 / tiles : 1;
   if (g_knob[3] > 0) splits = g_knob[3];
   const int64_t max_splits = (R + 4 * BR - 1) / (4 * BR);
   if (splits > max_splits) splits = max_splits;
@@ -1164,6 +1311,18 @@ extern "C" int mca_gemm_tn_acc(const uint16_t* A, int64_t lda, const uint16_t* B
   int64_t rps = (R + splits - 1) / splits;
   rps = (rps + BR - 1) / BR * BR;
   splits = (R + rps - 1) / rps;
+  if (huge) {
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_256x256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              TN2_LDS_BYTES) != hipSuccess)
+        return MCA_E_LAUNCH;
+      attr = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_256x256_kernel, dim3(tiles, (unsigned)splits), dim3(512), TN2_LDS_BYTES, as_stream(stream), A, lda, B,
+                       ldb, C, ldc, (int)R, (int)N, (int)K, tiles_k, (int)rps, g_knob[9]);
+    return launch_status();
+  }
   if (big) {
     static bool attr = false;
     if (!attr) {
