@@ -35,7 +35,7 @@ def pmc_traffic(kernel_key: str):
     path = os.path.join(REPO, "profiles", "r01_hbm_traffic_pmc.json")
     names = {"mca_gemm_nt": "gemm_nt_", "mca_gemm_tn_acc": "gemm_tn_", "mca_attn_fwd/layer": "attn_fwd_kernel",
              "mca_attn_bwd/layer": "attn_bwd_kernel", "mca_gemm_nt_geglu_fwd": "gemm_nt_persist_kernel<4",
-             "mca_gemm_nt_geglu_bwd": "gemm_nt_persist_kernel<3"}
+             "mca_gemm_nt_geglu_bwd": "gemm_nt_persist_kernel<3", "mca_gemm_nt_lnres": "gemm_nt_256_kernel<false, 1, 1, 2>"}
     if not os.path.exists(path) or kernel_key not in names:
         return None
     tot_b, tot_n = 0.0, 0
@@ -127,7 +127,8 @@ def main():
             eng.overlap_wgrad, eng.micro_batches = False, 1
         step()
         eng.overlap_wgrad, eng.micro_batches = saved
-    timed = ("mca_attn_fwd", "mca_attn_bwd", "mca_gemm_nt", "mca_gemm_nt_geglu_fwd", "mca_gemm_nt_geglu_bwd", "mca_gemm_tn_acc")
+    timed = ("mca_attn_fwd", "mca_attn_bwd", "mca_gemm_nt", "mca_gemm_nt_lnres", "mca_gemm_nt_geglu_fwd", "mca_gemm_nt_geglu_bwd",
+             "mca_gemm_tn_acc")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

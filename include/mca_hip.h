@@ -44,6 +44,14 @@ int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
                 const float* bias, const float* residual, int64_t ldres, int64_t res_period,
                 int64_t M, int64_t N, int64_t K, mca_stream_t stream);
 
+/* C[M,N] (fp32) = A[M,K]·B[N,K]^T + LayerNorm(x)[M,N], the LayerNorm (model.py:24-31, beta = 0) recomputed in the epilogue
+ * as (x - mean[m]) * rstd[m] * gamma[n] from the saved pre-norm tensor and the statistics mca_layernorm_fwd wrote: the
+ * residual branches x = Attn(LN(x)) + LN(x), x = FF(LN(x)) + LN(x) of MCALayer.forward (model.py:117-122) without the normed
+ * fp32 tensor ever being stored.  M >= 2048, N % 128 == 0, K >= 512 (MCA_E_UNSUPPORTED otherwise: use mca_gemm_nt).      */
+int mca_gemm_nt_lnres(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,
+                      const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
+                      int64_t M, int64_t N, int64_t K, mca_stream_t stream);
+
 /* Fused data-gradient GEMM + GEGLU backward (model.py:35-54 autograd): dg = A[M,K]·B[ip,K]^T is never stored;
  * dh[:, n] = dg*gelu(gate), dh[:, ip+n] = dg*a*gelu'(gate) with h = [a | gate].  h, dh: bf16 [M, 2*ip], row stride ldh. */
 int mca_gemm_nt_geglu_bwd(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* h,

@@ -288,11 +288,16 @@ __device__ __forceinline__ void wait_vmcnt(int n) {          // s_waitcnt needs 
 // 16 float4 per thread) is fetched into registers two pieces per k-step during the first 8 k-steps, so the epilogue
 // does not start with a 128 KiB read.  vmcnt counts DMA and residual loads together, in issue order: the wait in
 // front of step kt lets everything issued after stage kt's DMA stay in flight.
+// EPI = 2 (with PF = 1): the residual is LayerNorm(x) RECOMPUTED from the layer's saved pre-norm tensor x (= `residual`)
+// and its row statistics: (x - ln_mean[m]) * ln_rstd[m] * ln_gamma[n] — the normed fp32 tensor is then never written
+// by the LayerNorm kernel nor read here (same bytes read, 166 MB less written per LayerNorm at b = 32).  The 256 rows'
+// statistics wait in 2 KiB of LDS behind the three stages.
 template <bool OUT_BF16, int RES, int PF, int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_256_kernel(
     const u16* __restrict__ A, int64_t lda, const u16* __restrict__ B, int64_t ldb, void* __restrict__ Cv,
     int64_t ldc, const float* __restrict__ bias, const float* __restrict__ residual, int64_t ldres,
-    int64_t res_period, int M, int N, int K, int tiles_n, int nwg) {
+    int64_t res_period, int M, int N, int K, int tiles_n, int nwg, const float* __restrict__ ln_mean = nullptr,
+    const float* __restrict__ ln_rstd = nullptr, const float* __restrict__ ln_gamma = nullptr) {
   extern __shared__ __attribute__((aligned(16))) u16 lds2[];
   constexpr int STAGE = (BM2 + BN) * 64;          // elements per stage: A tile then B tile
   const int tile = xcd_remap(blockIdx.x, nwg);
@@ -343,8 +348,15 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(
     const int m = m0 + row;
     return m < M ? *reinterpret_cast<const f32x4*>(residual + (int64_t)m * ldres + n0 + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
   };
+  float* lnstat = reinterpret_cast<float*>(lds2 + 3 * STAGE);          // EPI == 2: [256] mean, [256] rstd
+  float ln_val = 0.f;
+  if (EPI == 2) {          // issued before the DMA so that its (compiler-counted) wait leaves the DMA in flight
+    int m = m0 + (tid & 255); if (m > M - 1) m = M - 1;
+    ln_val = tid < 256 ? ln_mean[m] : ln_rstd[m];
+  }
   stage(0, 0);
   if (nkt > 1) stage(64, 1);
+  if (EPI == 2) lnstat[tid] = ln_val;          // visible to every wave after the k-loop's barriers
   int st = 0;
 #define NT256_STEP(KT, WAITN)                                                                  \
   {                                                                                            \
@@ -390,13 +402,28 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(
   __syncthreads();
   if (PF) {
     // fast epilogue: residual already in registers, whole 128-column tile valid, 16-byte stores
+    float lnstat_r[PF ? 16 : 1][2];
+    f32x4 lng = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (EPI == 2) {
+      lng = *reinterpret_cast<const f32x4*>(ln_gamma + n0 + (tid & 31) * 4);
+#pragma unroll
+      for (int it = 0; it < 16; it++) {
+        const int row = (tid + 512 * it) >> 5;
+        lnstat_r[it % (PF ? 16 : 1)][0] = lnstat[row]; lnstat_r[it % (PF ? 16 : 1)][1] = lnstat[256 + row];
+      }
+    }
 #pragma unroll
     for (int it = 0; it < 16; it++) {
       const int id = tid + 512 * it, row = id >> 5, c0 = (id & 31) * 4;
       const int m = m0 + row;
       if (m < M) {
         f32x4 v = *reinterpret_cast<const f32x4*>(cs + row * 128 + c0);
-        const f32x4 r = rres[it % (PF ? 16 : 1)];
+        f32x4 r = rres[it % (PF ? 16 : 1)];
+        if (EPI == 2) {
+          const float mu = lnstat_r[it % (PF ? 16 : 1)][0], rs = lnstat_r[it % (PF ? 16 : 1)][1];
+#pragma unroll
+          for (int e = 0; e < 4; e++) r[e] = (r[e] - mu) * rs * lng[e];
+        }
         v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
         if (bias) { v[0] += bias[n0 + c0]; v[1] += bias[n0 + c0 + 1]; v[2] += bias[n0 + c0 + 2]; v[3] += bias[n0 + c0 + 3]; }
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cv) + (int64_t)m * ldc + n0 + c0) = v;
@@ -407,6 +434,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(
   nt_epilogue_rows<OUT_BF16, RES, EPI, BM2, 512>(cs, Cv, ldc, bias, residual, ldres, res_period, M, N, m0, n0, tid);
 }
 #define NT256_LDS_BYTES (3 * (BM2 + BN) * 64 * 2)
+#define NT256LN_LDS_BYTES (NT256_LDS_BYTES + 2048)
 
 // ---------------------------------------------------------------------------------------------------------
 // PERSISTENT NT kernel (large M, N % 128 == 0): one 512-thread workgroup per CU walks 256x128 tiles.
@@ -781,6 +809,31 @@ extern "C" int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, in
   return launch_status();
 }
 
+
+// C[M,N] (fp32) = A·B^T + LayerNorm(x) with the LayerNorm recomputed in the epilogue from x and its saved statistics.
+extern "C" int mca_gemm_nt_lnres(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,
+                                 const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
+                                 int64_t M, int64_t N, int64_t K, mca_stream_t stream) {
+  if (!A || !B || !C || !x || !mean || !rstd || !gamma || M <= 0 || N <= 0 || K <= 0) return MCA_E_BADARG;
+  if (K % 64 || lda % 8 || ldb % 8 || ldc % 4 || ldx % 4 || (uintptr_t)A % 16 || (uintptr_t)B % 16 || (uintptr_t)C % 16 ||
+      (uintptr_t)x % 16 || (uintptr_t)gamma % 16)
+    return MCA_E_ALIGN;
+  if (lda < K || ldb < K || ldc < N || ldx < N) return MCA_E_BADARG;
+  // the fused form exists for the large-M residual-prefetch kernel only; callers keep the two-kernel form otherwise
+  if (M < 2048 || M > (1LL << 30) || N % BN || K < 512) return MCA_E_UNSUPPORTED;
+  const int tiles_n = (int)(N / BN);
+  const int nwg2 = (int)((M + BM2 - 1) / BM2) * tiles_n;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<false, 1, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            NT256LN_LDS_BYTES) != hipSuccess)
+      return MCA_E_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_256_kernel<false, 1, 1, 2>), dim3(nwg2), dim3(512), NT256LN_LDS_BYTES, as_stream(stream), A, lda, B, ldb,
+                     (void*)C, ldc, (const float*)nullptr, x, ldx, (int64_t)0, (int)M, (int)N, (int)K, tiles_n, nwg2, mean, rstd, gamma);
+  return launch_status();
+}
 
 // dh = GEGLU'(h) applied to dg = A·B^T without materialising dg (fused epilogue).  A[M,K] (= d x_out, bf16), B[ip,K] (= W2^T
 // copy), h / dh [M, 2*ip] bf16.

@@ -81,6 +81,7 @@ class FusionEngine:
         self.gather_hook: Optional[Callable] = None                          # DP: pooled/present all-gather
         self.check_finite = True
         self.fuse_geglu_bwd = True
+        self.fuse_ln_residual = True                # residual LayerNorm recomputed in the GEMM epilogue (large batches)
         # weight-gradient GEMMs on a side stream, concurrent with the backward chain
         self.overlap_wgrad = os.environ.get("MCA_OVERLAP_WGRAD", "1") != "0"
         # micro-batch interleave (opt-in, MCA_MICRO_BATCHES=2): batches of at least micro_batch_min samples run as two
@@ -450,20 +451,31 @@ class FusionEngine:
         m, D, N, H, Ip, R, b, T = self.model, self.D, self.N, self.H, self.Ip, self.R, ws["b"], ws["T"]
         call("mca_build_keyinfo", ptr(ws["padding"]), ptr(self.kgroup), ptr(ws["keyinfo"]), ptr(ws["kflags"]), b, N,
              self.nk_pad, stream_ptr())
+        # T >= 2048: the residual LayerNorm(x) is recomputed inside the out-proj / FF2 GEMM epilogues from x and the saved row
+        # statistics (mca_gemm_nt_lnres): the LayerNorm kernels then write the bf16 GEMM operand only
+        ln_in_gemm = self.fuse_ln_residual and T >= 2048 and D % 128 == 0 and D >= 512 and Ip >= 512
         for i, ly in enumerate(m.layers):
             w, a = self.wl[i], ws["layers"][i]
             xin, xout = ws["x"][i], ws["x"][i + 1]
             g = ly.norm.gamma
-            self.ln_fwd(xin, g, T, D, a["m1"], a["r1"], y=ws["xn"], ldy=D, y_bf16=a["xn_b"], cols_pad=D)
+            self.ln_fwd(xin, g, T, D, a["m1"], a["r1"], y=None if ln_in_gemm else ws["xn"], ldy=D, y_bf16=a["xn_b"], cols_pad=D)
             self.gemm_nt(a["xn_b"], w["qkv"], a["qkv"], T, 3 * D, D)
             self._attn_fwd(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], a["lse"],
                            self.qmask_attn, self.sched_attn_f, ws, b, N)
-            self.gemm_nt(a["o"], w["o"], a["x1"], T, D, D, residual=ws["xn"])
-            self.ln_fwd(a["x1"], g, T, D, a["m2"], a["r2"], y=ws["x1n"], ldy=D, y_bf16=a["x1n_b"], cols_pad=D)
+            if ln_in_gemm:
+                call("mca_gemm_nt_lnres", ptr(a["o"]), D, ptr(w["o"]), D, ptr(a["x1"]), D, ptr(xin), D, ptr(a["m1"]), ptr(a["r1"]),
+                     ptr(g.data), T, D, D, stream_ptr(), flops=2.0 * T * D * D)
+            else:
+                self.gemm_nt(a["o"], w["o"], a["x1"], T, D, D, residual=ws["xn"])
+            self.ln_fwd(a["x1"], g, T, D, a["m2"], a["r2"], y=None if ln_in_gemm else ws["x1n"], ldy=D, y_bf16=a["x1n_b"], cols_pad=D)
             # h = x1n @ W1^T and g = GEGLU(h) in one pass (h is kept for the backward, not read back here)
             call("mca_gemm_nt_geglu_fwd", ptr(a["x1n_b"]), D, ptr(w["w1"]), D, ptr(a["h"]), 2 * Ip, ptr(a["g"]), Ip, Ip, T, D,
                  stream_ptr(), flops=2.0 * T * 2 * Ip * D)
-            self.gemm_nt(a["g"], w["w2"], xout, T, D, Ip, residual=ws["x1n"])
+            if ln_in_gemm:
+                call("mca_gemm_nt_lnres", ptr(a["g"]), Ip, ptr(w["w2"]), Ip, ptr(xout), D, ptr(a["x1"]), D, ptr(a["m2"]), ptr(a["r2"]),
+                     ptr(g.data), T, D, Ip, stream_ptr(), flops=2.0 * T * D * Ip)
+            else:
+                self.gemm_nt(a["g"], w["w2"], xout, T, D, Ip, residual=ws["x1n"])
         xl = ws["x"][self.L]
         self.ln_fwd(xl, m.norm.gamma, T, D, ws["mf"], ws["rf"], y_bf16=ws["t_b"], cols_pad=D)
         self.gemm_nt(ws["t_b"], self.wp["kv"], ws["kvp"], T, 2 * D, D)

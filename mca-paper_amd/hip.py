@@ -67,6 +67,7 @@ SIGNATURES = {
     "mca_debug_set": (_I, [_I, _I]),
     "mca_gemm_nt": (_I, [_P, _I64, _P, _I64, _P, _I64, _I, _P, _P, _I64, _I64, _I64, _I64, _I64, _P]),
     "mca_gemm_nt_geglu_bwd": (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P]),
+    "mca_gemm_nt_lnres": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _P]),
     "mca_gemm_nt_geglu_fwd": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P]),
     "mca_gemm_tn_acc": (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P]),
     "mca_layernorm_fwd": (_I, [_P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _I, _P, _P, _I64, _I, _F, _P]),

@@ -55,6 +55,28 @@ def test_gemm_nt(H, M, N, K):
         assert rel(C32, ref + r2.repeat(M // per, 1)) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(2304, 512, 512), (4100, 512, 1408), (2100, 256, 576)])
+def test_gemm_nt_lnres(H, M, N, K):
+    """C = A B^T + LayerNorm(x), the LayerNorm recomputed in the epilogue from x and the statistics the LN kernel saved."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    A = bf(torch.randn(M, K, device="cuda", generator=g))
+    B = bf(torch.randn(N, K, device="cuda", generator=g) * 0.1)
+    x = torch.randn(M, N, device="cuda", generator=g) * 3 + 0.5
+    gamma = torch.randn(N, device="cuda", generator=g)
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    xn_b = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    H.call("mca_layernorm_fwd", x.data_ptr(), N, gamma.data_ptr(), None, None, None, 0, None, 0, 0, xn_b.data_ptr(), N, N,
+           mean.data_ptr(), rstd.data_ptr(), M, N, 1e-5, H.stream_ptr())
+    C = torch.empty(M, N, device="cuda")
+    H.call("mca_gemm_nt_lnres", A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), N, x.data_ptr(), N, mean.data_ptr(), rstd.data_ptr(),
+           gamma.data_ptr(), M, N, K, H.stream_ptr())
+    ref = A.float() @ B.float().t() + torch.nn.functional.layer_norm(x, (N,), gamma, None, 1e-5)
+    assert rel(C, ref) < 2e-6
+    # unsupported shapes are refused (the caller keeps the two-kernel form)
+    assert H.lib().mca_gemm_nt_lnres(A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), N, x.data_ptr(), N, mean.data_ptr(), rstd.data_ptr(),
+                                     gamma.data_ptr(), 100, N, K, H.stream_ptr()) == -3
+
+
 @pytest.mark.parametrize("R,N,K,lda,ldb", [(1000, 512, 512, 512, 512), (777, 1365, 512, 2816, 512), (2048, 512, 1365, 512, 1408),
                                            (16, 512, 512, 512, 512), (500, 128, 74, 128, 128), (5000, 1024, 512, 1536, 512)])
 def test_gemm_tn_acc(H, R, N, K, lda, ldb):
