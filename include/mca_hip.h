@@ -138,6 +138,17 @@ int mca_tab_value_bwd(const float* dh1, int64_t ld, const uint16_t* h1, const fl
 /* ---------------------------------------------------------------------------------------------
  * Block-masked fused attention (model.py:73-105 as used by MCALayer :119 and attn_pool :472-473)
  * --------------------------------------------------------------------------------------------- */
+/* Packing of the per-modality attention masks (model.py:455-466; encoders.py:196-214 for the row masks): ONE launch
+ * instead of ~8 small tensor ops per modality.  For every modality i < n_mod, mask i is (b, n_i) of 1-byte (bool) or
+ * 8-byte (int64) elements, non-zero = padded:
+ *   padding[s, offset_i + j] = mask_i[s, j] != 0;   rowmask_i[s*n_i + j] = the same (dense copy, skipped when NULL);
+ *   present[s] bit i = any token of modality i valid in sample s (MCA.forward's modality_sample_mask);
+ *   padding[s, n_tokens - n_fusion ...] = 0 (fusion tokens are never padded).                                        */
+#define MCA_MAX_MODALITIES 16
+typedef struct { const void* mask; uint8_t* rowmask; int32_t elem_bytes, n, offset, pad_; } mca_mask_desc;
+typedef struct { mca_mask_desc m[MCA_MAX_MODALITIES]; int32_t n_mod, batch, n_tokens, n_fusion; } mca_pack_masks_args;
+int mca_pack_masks(const mca_pack_masks_args* args, uint8_t* padding, int32_t* present, mca_stream_t stream);
+
 /* keyinfo[b, nk_pad] = padded ? 31 : kgroup[j]; entries >= nk are 31.
  * ktile_flags[b, n_ktiles] = 0 no valid key in the 64-key tile, 1 mixed, 2 all valid.
  * padding: u8 (b, nk), 1 = padded key (model.py:465-466).                                       */

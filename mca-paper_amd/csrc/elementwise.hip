@@ -487,3 +487,50 @@ extern "C" int mca_tab_value_bwd(const float* dh1, int64_t ld, const uint16_t* h
                      dw1, db1, rows, cols, max_value, rpb);
   return launch_status();
 }
+
+
+// =====================================================================================================
+// mask packing: one workgroup per sample walks the modalities (see include/mca_hip.h)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void pack_masks_kernel(mca_pack_masks_args a, uint8_t* __restrict__ padding, int32_t* __restrict__ present) {
+  __shared__ int any_valid[MCA_MAX_MODALITIES];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  if (tid < MCA_MAX_MODALITIES) any_valid[tid] = 0;
+  __syncthreads();
+  uint8_t* prow = padding + (int64_t)s * a.n_tokens;
+  for (int i = 0; i < a.n_mod; i++) {
+    const mca_mask_desc d = a.m[i];
+    bool valid = false;
+    for (int j = tid; j < d.n; j += 256) {
+      const int64_t idx = (int64_t)s * d.n + j;
+      const bool pad = d.elem_bytes == 8 ? reinterpret_cast<const int64_t*>(d.mask)[idx] != 0 : reinterpret_cast<const uint8_t*>(d.mask)[idx] != 0;
+      prow[d.offset + j] = pad ? 1 : 0;
+      if (d.rowmask) d.rowmask[idx] = pad ? 1 : 0;
+      valid |= !pad;
+    }
+    if (__any(valid) && (tid & 63) == 0) any_valid[i] = 1;          // benign race: every writer stores 1
+  }
+  for (int j = a.n_tokens - a.n_fusion + tid; j < a.n_tokens; j += 256) prow[j] = 0;
+  __syncthreads();
+  if (tid == 0) {
+    int bits = 0;
+    for (int i = 0; i < a.n_mod; i++) bits |= any_valid[i] << i;
+    present[s] = bits;
+  }
+}
+
+extern "C" int mca_pack_masks(const mca_pack_masks_args* args, uint8_t* padding, int32_t* present, mca_stream_t stream) {
+  if (!args || !padding || !present) return MCA_E_BADARG;
+  if (args->n_mod <= 0 || args->n_mod > MCA_MAX_MODALITIES || args->batch <= 0 || args->n_tokens <= 0 || args->n_fusion < 0) return MCA_E_BADARG;
+  int64_t tot = args->n_fusion;
+  for (int i = 0; i < args->n_mod; i++) {
+    const mca_mask_desc& d = args->m[i];
+    if (!d.mask || d.n <= 0 || d.offset < 0 || (d.elem_bytes != 1 && d.elem_bytes != 8)) return MCA_E_BADARG;
+    if (d.elem_bytes == 8 && (uintptr_t)d.mask % 8) return MCA_E_ALIGN;
+    if ((int64_t)d.offset + d.n > args->n_tokens) return MCA_E_BADARG;
+    tot += d.n;
+  }
+  if (tot > args->n_tokens) return MCA_E_BADARG;
+  hipLaunchKernelGGL(pack_masks_kernel, dim3(args->batch), dim3(256), 0, as_stream(stream), *args, padding, present);
+  return launch_status();
+}

@@ -597,6 +597,12 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(
       PS_STAMP();
     }
     __builtin_amdgcn_s_barrier();                  // every wave has read its last fragments: all three slots are free
+    // The fp32 epilogues hand the accumulators straight to inline-asm ds_write_b128: hipcc does not know the asm reads
+    // MFMA results and inserts no wait states (it does for its own v_cvt_pk in the bf16 modes).  The last four MFMAs were
+    // issued just before the barrier and take 4 x 32 cycles; without a next tile nothing else sits in between (a
+    // one-tile-per-workgroup launch returned stale accumulators once in a few runs).
+    if (MODE != 0 && MODE != 4)
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     PS_STAMP();
     // ---------------- epilogue: acc[i][j][4q + e] = C[mw + 32i + l31][nw + 32j + 8q + 4lh + e] ----------------
     // next tile's first two k-steps: in flight during the whole epilogue

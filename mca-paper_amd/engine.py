@@ -81,6 +81,7 @@ class FusionEngine:
         self.gather_hook: Optional[Callable] = None                          # DP: pooled/present all-gather
         self.check_finite = True
         self.fuse_geglu_bwd = True
+        self._mod_shifts = torch.arange(len(model.modality_types), dtype=torch.int32, device=self.device)
         self.fuse_ln_residual = True                # residual LayerNorm recomputed in the GEMM epilogue (large batches)
         # weight-gradient GEMMs on a side stream, concurrent with the backward chain
         self.overlap_wgrad = os.environ.get("MCA_OVERLAP_WGRAD", "1") != "0"
@@ -254,6 +255,8 @@ class FusionEngine:
         ws["vmean"], ws["dvmean"], ws["delta"], ws["delta_p"] = f32(b, D), f32(b, D), f32(b, H, N), f32(b, H, R)
         ws["keyinfo"], ws["kflags"] = u8(b, self.nk_pad), u8(b, (N + 63) // 64)
         ws["padding"] = u8(b, N)
+        ws["present"] = torch.zeros(b, dtype=torch.int32, device=dev)
+        ws["present_native"] = torch.zeros(b, dtype=torch.int32, device=dev)
         # backward
         ws["dxa"], ws["dxb"], ws["dx_b"] = f32(T, D), f32(T, D), bf(T, D)
         ws["dg"], ws["do"], ws["dq32"] = bf(T, Ip), bf(T, D), f32(T, D)
@@ -369,17 +372,51 @@ class FusionEngine:
     # forward
     # ------------------------------------------------------------------------------------------------
     def _encode(self, batch, ws, need_grad: bool, renorm: bool = True):
-        """encoders + packing (model.py:455-466): writes ws['x'][0] (b, N, D) and ws['padding'] (b, N)."""
+        """encoders + packing (model.py:455-466): writes ws['x'][0] (b, N, D), ws['padding'] (b, N) and ws['present'] (b,)
+        int32 (bit i = modality i has a valid token in that sample); returns modality_sample_mask {name: (b,) bool}."""
         m, D, N, b = self.model, self.D, self.N, ws["b"]
         x0 = ws["x"][0]
-        sample_mask = {}
         ws["foreign"] = {}
+        # ---- masks of every native modality in ONE launch: padding, the encoders' row masks, presence bits
+        pk = hip.PackMasksArgs()
+        keep = []                         # keeps converted mask tensors alive until the launch is enqueued
+        native_idx = []
+        for mi, name in enumerate(m.modality_types):
+            enc = m.encoders[name]
+            if not isinstance(enc, (EmbeddedSequenceEncoder, TabularEncoder)):
+                continue
+            n, off = self.st.token_dims[mi], self.offsets[mi]
+            am = batch[name]["attention_mask"]
+            if am.dtype == torch.bool or am.dtype == torch.uint8:
+                eb = 1
+            elif am.dtype == torch.int64:
+                eb = 8
+            else:
+                am, eb = am.to(torch.bool), 1
+            if not am.is_contiguous():
+                am = am.contiguous()
+            if am.shape != (b, n):
+                raise AssertionError(f"{name}: attention_mask {tuple(am.shape)} != {(b, n)}")
+            keep.append(am)
+            d = pk.m[len(native_idx)]
+            d.mask, d.elem_bytes, d.n, d.offset = am.data_ptr(), eb, n, off
+            d.rowmask = ws["enc"][name]["mask"].data_ptr() if isinstance(enc, EmbeddedSequenceEncoder) else None
+            native_idx.append(mi)
+        foreign = len(native_idx) != len(m.modality_types)
+        if native_idx:
+            pk.n_mod, pk.batch, pk.n_tokens, pk.n_fusion = len(native_idx), b, N, (0 if foreign else self.F)
+            call("mca_pack_masks", C.byref(pk), ptr(ws["padding"]), ptr(ws["present_native"]), stream_ptr())
+        present = ws["present"]
+        if not foreign:
+            present = ws["present_native"]          # bit k = k-th modality: the native list IS the modality list
+        else:
+            present.zero_()
+            for k, mi in enumerate(native_idx):
+                present |= ((ws["present_native"] >> k) & 1) << mi
         for mi, name in enumerate(m.modality_types):
             enc = m.encoders[name]
             n, off = self.st.token_dims[mi], self.offsets[mi]
             bm = batch[name]
-            pad_view = ws["padding"].view(b, N)[:, off:off + n]
-            x0_view = x0.view(b, N, D)[:, off:off + n]
             if isinstance(enc, EmbeddedSequenceEncoder):
                 e = ws["enc"][name]
                 toks = bm["tokens"]
@@ -387,9 +424,6 @@ class FusionEngine:
                     toks = toks.float().contiguous()
                 if toks.shape != (b, n, enc.input_size):
                     raise AssertionError(f"{name}: tokens {tuple(toks.shape)} != {(b, n, enc.input_size)}")
-                mask = bm["attention_mask"].to(torch.bool)
-                e["mask"].copy_(mask.reshape(-1))
-                pad_view.copy_(mask)
                 e["tokens"] = toks
                 te = enc.token_encoder
                 rows = b * n
@@ -400,22 +434,24 @@ class FusionEngine:
                 pe = enc.positional_encoder.pe
                 self.ln_fwd(e["y"], te[2].weight, rows, D, e["m2"], e["r2"], beta=te[2].bias, rowmask=e["mask"], add=pe,
                             period=n, y=x0[off:], ldy=D, y_bstride=N * D)
-                sample_mask[name] = ~mask.all(dim=1)
             elif isinstance(enc, TabularEncoder):
-                sample_mask[name] = self._encode_tabular(name, enc, bm, ws, mi, renorm)
+                self._encode_tabular(name, enc, bm, ws, mi, renorm)
             else:
                 # user-registered torch encoder: run it with autograd and feed its tokens to the native trunk
                 with torch.enable_grad() if need_grad else torch.no_grad():
                     toks, amask = enc(bm)
                 ws["foreign"][name] = toks
-                x0_view.copy_(toks.detach().float())
-                pad_view.copy_(amask.to(torch.bool))
-                sample_mask[name] = (amask == 0).sum(dim=1) != 0
+                x0.view(b, N, D)[:, off:off + n].copy_(toks.detach().float())
+                ws["padding"].view(b, N)[:, off:off + n].copy_(amask.to(torch.bool))
+                present |= ((amask == 0).sum(dim=1) != 0).to(torch.int32) << mi
         if self.F:
             call("mca_bcast_rows", ptr(m.fusion_tokens.data), D, x0.data_ptr() + (N - self.F) * D * 4, D, N * D, self.F,
                  b * self.F, D, stream_ptr())
-            ws["padding"].view(b, N)[:, N - self.F:] = 0
-        return sample_mask
+            if foreign:
+                ws["padding"].view(b, N)[:, N - self.F:] = 0
+        ws["present_cur"] = present
+        bits = ((present[:, None] >> self._mod_shifts) & 1).to(torch.bool)          # (b, M): one small op for every modality
+        return {name: bits[:, mi] for mi, name in enumerate(m.modality_types)}
 
     def _renorm_table(self, enc, n):
         emb = enc.token_encoder.embedding.weight
@@ -434,8 +470,6 @@ class FusionEngine:
         if vals.shape != (b, n):
             raise AssertionError(f"{vals.shape[1]} - {n}")                  # encoders.py:93
         e["values"] = vals
-        amask = bm["attention_mask"]
-        ws["padding"].view(b, N)[:, off:off + n].copy_(amask.to(torch.bool))
         emb = enc.token_encoder.embedding.weight
         if renorm:
             self._renorm_table(enc, n)
@@ -444,7 +478,6 @@ class FusionEngine:
         self.gemm_nt(e["h1_b"], self.we[name]["w2"], e["y"], rows, D, D, bias=ve.linear2.bias)
         self.ln_fwd(e["y"], ve.norm.weight, rows, D, e["m2"], e["r2"], beta=ve.norm.bias, rowmask=e["mask"], add=emb.data,
                     period=n, y=ws["x"][0][off:], ldy=D, y_bstride=N * D)
-        return (amask == 0).sum(dim=1) != 0
 
     def forward_trunk(self, ws):
         """fusion layers + final norm + attentive pooling -> ws['pooled'] (b*R, D)."""
@@ -699,6 +732,7 @@ class FusionEngine:
                     masks.append(self._encode(sub, part, need_grad, renorm=False))
                     self.forward_trunk(part)
         main.wait_stream(s1)
+        ws["present_cur"] = torch.cat([part["present_cur"] for part in ws["parts"]])
         return ws, {name: torch.cat([masks[0][name], masks[1][name]]) for name in m.modality_types}
 
     def _model_forward(self, batch, no_loss=False):
@@ -727,9 +761,7 @@ class FusionEngine:
         # in-place clamp of the temperature parameter (utils/contrastive_loss_with_temperature.py:187)
         ls = m.loss.loss_fn
         ls.logit_scale.data.clamp_(ls.logit_scale_min, ls.logit_scale_max)
-        present = torch.zeros(b, dtype=torch.int32, device=self.device)
-        for mi, name in enumerate(m.modality_types):
-            present |= sample_mask[name].to(torch.int32) << mi
+        present = ws["present_cur"]
         if need_grad:
             pooled_out, terms, loss = _MCAStep.apply(self, ws, pooled, present, *self.param_order)
         else:

@@ -31,6 +31,19 @@ class CastDesc(C.Structure):
                 ("ldd", C.c_int64), ("rows_pad", C.c_int64), ("cols_pad", C.c_int64), ("transpose", C.c_int32), ("pad_", C.c_int32)]
 
 
+MAX_MODALITIES = 16
+
+
+class MaskDesc(C.Structure):
+    _fields_ = [("mask", C.c_void_p), ("rowmask", C.c_void_p), ("elem_bytes", C.c_int32), ("n", C.c_int32), ("offset", C.c_int32),
+                ("pad_", C.c_int32)]
+
+
+class PackMasksArgs(C.Structure):
+    _fields_ = [("m", MaskDesc * MAX_MODALITIES), ("n_mod", C.c_int32), ("batch", C.c_int32), ("n_tokens", C.c_int32),
+                ("n_fusion", C.c_int32)]
+
+
 class AttnFwdArgs(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("q_bstride", C.c_int64), ("q_ld", C.c_int64),
@@ -82,6 +95,7 @@ SIGNATURES = {
     "mca_embedding_renorm": (_I, [_P, _I64, _I, _F, _P]),
     "mca_tab_value_fwd": (_I, [_P, _P, _P, _P, _P, _I64, _I, _F, _F, _P]),
     "mca_tab_value_bwd": (_I, [_P, _I64, _P, _P, _P, _P, _I64, _I, _F, _P]),
+    "mca_pack_masks": (_I, [_P, _P, _P, _P]),
     "mca_build_keyinfo": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "mca_attn_vmean": (_I, [_P, _I64, _I64, _P, _I, _I, _I, _P]),
     "mca_attn_fwd": (_I, [C.POINTER(AttnFwdArgs), _P]),

@@ -194,6 +194,34 @@ def test_gemm_geglu_bwd_fused(H, rows, ip, D):
     assert rel(dh.float(), hr.grad) < 4e-3
 
 
+def test_pack_masks(H):
+    """padding / row masks / presence bits of every modality in one launch (bool and int64 masks, a fully padded sample)."""
+    g = torch.Generator(device="cuda").manual_seed(12)
+    b, dims, F = 5, [70, 45, 30], 8
+    N = sum(dims) + F
+    masks = [torch.rand(b, n, device="cuda", generator=g) < 0.4 for n in dims]
+    masks[1][2] = True                                      # modality 1 entirely padded in sample 2
+    masks[2] = masks[2].to(torch.int64) * 7                 # int64 mask, any non-zero value = padded
+    rowm = [torch.full((b * n,), 9, device="cuda", dtype=torch.uint8) for n in dims]
+    pk = H.PackMasksArgs()
+    off = 0
+    for i, (mk, n) in enumerate(zip(masks, dims)):
+        d = pk.m[i]
+        d.mask, d.elem_bytes, d.n, d.offset = mk.data_ptr(), mk.element_size(), n, off
+        d.rowmask = rowm[i].data_ptr() if i != 2 else None
+        off += n
+    pk.n_mod, pk.batch, pk.n_tokens, pk.n_fusion = 3, b, N, F
+    padding = torch.full((b, N), 5, device="cuda", dtype=torch.uint8)
+    present = torch.full((b,), -1, device="cuda", dtype=torch.int32)
+    H.call("mca_pack_masks", C.byref(pk), padding.data_ptr(), present.data_ptr(), H.stream_ptr())
+    want = torch.cat([(mk != 0) for mk in masks] + [torch.zeros(b, F, dtype=torch.bool, device="cuda")], 1).to(torch.uint8)
+    assert torch.equal(padding, want)
+    assert torch.equal(rowm[0], (masks[0] != 0).reshape(-1).to(torch.uint8)) and torch.equal(rowm[1], masks[1].reshape(-1).to(torch.uint8))
+    assert (rowm[2] == 9).all()                             # NULL row mask: untouched
+    bits = sum(((mk == 0).any(1).to(torch.int32) << i) for i, mk in enumerate(masks))
+    assert torch.equal(present, bits) and int(present[2]) & 2 == 0
+
+
 # ------------------------------------------------------------------------------------- data movement
 def test_cast_bcast_reduce(H):
     g = torch.Generator(device="cuda").manual_seed(5)
