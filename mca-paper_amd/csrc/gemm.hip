@@ -482,8 +482,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(
   extern __shared__ __attribute__((aligned(16))) u16 lds2[];
   constexpr int STAGE = (BM2 + BN) * 64;          // elements per stage: A tile then B tile
   constexpr int NST = MODE == 0 ? 8 : (MODE == 4 ? 12 : 16);         // global stores per wave and tile
-  constexpr int NPRE = MODE >= 2 ? 16 : 1;
-  constexpr int NLD = (MODE >= 2 ? 16 : 0) + (BIAS ? (MODE == 0 ? 2 : 1) : 0);          // epilogue input loads per wave and tile
+  constexpr int NPRE = (MODE == 2 || MODE == 3) ? 16 : 1;
+  constexpr int NLD = ((MODE == 2 || MODE == 3) ? 16 : 0) + (BIAS ? (MODE == 0 ? 2 : 1) : 0);          // epilogue input loads per wave and tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
