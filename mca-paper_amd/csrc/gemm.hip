@@ -345,8 +345,11 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(
   f32x4 rres[PF ? 16 : 1];
   auto res_issue = [&](int it) -> f32x4 {          // piece `it` of this thread's share of the residual tile
     const int id = tid + 512 * it, row = id >> 5, c0 = (id & 31) * 4;
-    const int m = m0 + row;
-    return m < M ? *reinterpret_cast<const f32x4*>(residual + (int64_t)m * ldres + n0 + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // rows past M are CLAMPED, not skipped: the counted vmcnt waits below assume that every wave issues every one of
+    // these loads (a tile crossing M used to skip them and then waited for too few of its DMA loads: a rare stale-LDS
+    // race in the last 64 rows of the out-proj / FF2 / data-gradient GEMMs, caught by the bit-exactness test)
+    int m = m0 + row; if (m > M - 1) m = M - 1;
+    return *reinterpret_cast<const f32x4*>(residual + (int64_t)m * ldres + n0 + c0);
   };
   float* lnstat = reinterpret_cast<float*>(lds2 + 3 * STAGE);          // EPI == 2: [256] mean, [256] rstd
   float ln_val = 0.f;
