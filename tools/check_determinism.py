@@ -6,10 +6,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 P = importlib.import_module("mca-paper_amd"); H = importlib.import_module("mca-paper_amd.hip")
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 NIT = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-cfg = P.config.cmu_model_config(batch_size=b)
+kind = sys.argv[3] if len(sys.argv) > 3 else "cmu"
+cfg = {"cmu": lambda: P.config.cmu_model_config(batch_size=b), "mma": lambda: P.config.cmu_model_config(batch_size=b, zorro=True),
+       "long": lambda: P.config.cmu_model_config(batch_size=b, long_seq=True), "tcga": lambda: P.config.tcga_model_config(batch_size=b)}[kind]()
 torch.manual_seed(43)
 model = P.MCA(**cfg).cuda(); eng = model.engine; eng.check_finite = False
-batch = P.data.synthetic_batch(cfg, b, seed=1234, lengths="full", device="cuda")
+batch = P.data.synthetic_batch(cfg, b, seed=1234, lengths="full", device="cuda")          # no dropped modality: no atomically summed uniform rows
 def snapshot(clone):
     ws = eng.workspace(b)
     snap = {"x0": ws["x"][0]}
