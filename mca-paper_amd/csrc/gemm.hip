@@ -31,6 +31,23 @@ static int num_cus() {
   return n;
 }
 
+// Persistent kernel: tile index -> (row tile tm, column tile tn).  Row tiles are taken in groups of PS_PANELS: index =
+// (group, tn, tm in group), so the 32 workgroups of an XCD (contiguous indices, xcd_remap) work on PS_PANELS activation
+// panels x 8 weight tiles at a time (1 MiB + 1 MiB of the 4 MiB L2) and a panel group stays resident while the column
+// tiles sweep past it; in row-major tile order all 22 column tiles of FF1 (2.9 MiB of weights) are live at once and the
+// activation panels are re-fetched 9 times (PMC FETCH_SIZE x 2: 756 MB per launch against 86 MB of operands; 436 MB
+// with the groups; step -0.36 ms in-process; 4, 8 and 16 panels per group measure the same, 2 is worse).
+#define PS_PANELS 4
+__device__ __forceinline__ void ps_tile_decode(int tile, int tiles_m, int tiles_n, int flat, int& tm, int& tn) {
+  if (flat == 1) { tm = tile / tiles_n; tn = tile % tiles_n; return; }
+  const int P = flat > 1 ? flat : PS_PANELS;
+  const int per_group = P * tiles_n;
+  const int g = tile / per_group;
+  const int gh = (g + 1) * P <= tiles_m ? P : tiles_m - g * P;          // panels in this (last) group
+  const int rem = tile - g * per_group;
+  tn = rem / gh; tm = g * P + rem % gh;
+}
+
 // LDS image of a [128 rows][64 bf16] tile (128-byte rows): 16-byte chunk c of row r lives at chunk
 // c ^ ((r >> 1) & 7): a 16-lane group of ds_read_b128 (16 distinct rows, same logical chunk) then covers
 // all 64 banks exactly once.
@@ -497,8 +514,11 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(
 
   const u16* ga[4];
   const u16* gb[2];
+  const int tiles_m = nwg / tiles_n;
+  const int flat_order = (dbg >> 5) & 31;          // knob 0 = 32: row-major tile order; 32*P: P panels per group (A/B)
   auto tile_ptrs = [&](int tile) {
-    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    int tm, tn;
+    ps_tile_decode(tile, tiles_m, tiles_n, flat_order, tm, tn);
     const int m0 = tm * BM2, n0 = tn * BN;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -536,7 +556,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(
   bool first = true;
   while (v < nwg) {
     const int tile = xcd_remap(v, nwg);
-    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    int tm, tn;
+    ps_tile_decode(tile, tiles_m, tiles_n, flat_order, tm, tn);
     const int m0 = tm * BM2, n0 = tn * BN;
     f32x16 acc[2][2];
 #pragma unroll

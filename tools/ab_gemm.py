@@ -3,6 +3,7 @@ import importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 H = importlib.import_module("mca-paper_amd.hip"); H.lib()
 knob = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+VA, VB = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1, 0)          # the two knob values compared
 M = 32 * 2538
 def timeit(fn, n=10):
     for _ in range(2): fn()
@@ -14,9 +15,9 @@ def timeit(fn, n=10):
     return s.elapsed_time(e) / n
 def ab(make_fn, rounds=5):
     """interleaved rounds of the two knob values; returns {value: (median ms, min ms)}"""
-    res = {1: [], 0: []}
+    res = {VA: [], VB: []}
     for _ in range(rounds):
-        for v in (1, 0):
+        for v in (VA, VB):
             H.lib().mca_debug_set(knob, v)
             res[v].append(timeit(make_fn()))
     return {v: (sorted(r)[len(r) // 2], min(r)) for v, r in res.items()}
@@ -34,7 +35,7 @@ for nm, N, K, obf, res in shapes:
     C = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16 if obf else torch.float32)
     mk = lambda: (lambda: H.call("mca_gemm_nt", A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), N, int(obf), None, H.ptr(R), N, 0, M, N, K, H.stream_ptr()))
     t = ab(mk)
-    for v in (1, 0):
+    for v in (VA, VB):
         H.lib().mca_debug_set(knob, v); C.zero_(); mk()(); torch.cuda.synchronize()
         err = max(float((C[:4096].float() - ref).abs().max()), float((C[-300:].float() - ref_tail).abs().max())) / float(ref.abs().max())
         row += f" | knob={v}: med {t[v][0]*1e3:7.1f} min {t[v][1]*1e3:7.1f} us {2.0*M*N*K/t[v][0]/1e9:6.1f} TF err {err:.1e}"
@@ -47,7 +48,7 @@ row = f"{'geglu-bwd fused':20s} N={N:5d} K={K:5d}"
 dh = torch.zeros(M, 2 * N, device="cuda", dtype=torch.bfloat16)
 mk = lambda: (lambda: H.call("mca_gemm_nt_geglu_bwd", A.data_ptr(), K, B.data_ptr(), K, h.data_ptr(), dh.data_ptr(), 2 * N, N, M, K, H.stream_ptr()))
 t = ab(mk)
-for v in (1, 0):
+for v in (VA, VB):
     H.lib().mca_debug_set(knob, v); dh.zero_(); mk()(); torch.cuda.synchronize(); outs.append(dh.clone())
     row += f" | knob={v}: med {t[v][0]*1e3:7.1f} min {t[v][1]*1e3:7.1f} us {2.0*M*N*K/t[v][0]/1e9:6.1f} TF"
 # reference from the unfused formula in fp32
