@@ -194,6 +194,28 @@ def test_gemm_geglu_bwd_fused(H, rows, ip, D):
     assert rel(dh.float(), hr.grad) < 4e-3
 
 
+def test_cast_pad_multi(H):
+    """One launch refreshing several bf16 weight copies (plain and transposed, zero-padded) = the per-tensor kernel."""
+    g = torch.Generator(device="cuda").manual_seed(13)
+    cases = [(100, 74, 128, 128, 0), (100, 74, 128, 128, 1), (1365, 512, 1408, 512, 0), (1365, 512, 512, 1408, 1), (512, 512, 512, 512, 1),
+             (3, 5, 64, 64, 1)]
+    srcs = [torch.randn(r, c, device="cuda", generator=g) for r, c, _, _, _ in cases]
+    want, got, descs = [], [], (H.CastDesc * len(cases))()
+    for i, ((r, c, rp, cp, tr), src) in enumerate(zip(cases, srcs)):
+        w = torch.full((rp, cp), 3.0, device="cuda", dtype=torch.bfloat16)
+        H.call("mca_cast_pad_bf16", src.data_ptr(), c, r, c, w.data_ptr(), cp, rp, cp, tr, H.stream_ptr())
+        want.append(w)
+        o = torch.full((rp, cp), 5.0, device="cuda", dtype=torch.bfloat16)
+        got.append(o)
+        d = descs[i]
+        d.src, d.dst, d.lds, d.rows, d.cols, d.ldd, d.rows_pad, d.cols_pad, d.transpose = src.data_ptr(), o.data_ptr(), c, r, c, cp, rp, cp, tr
+    dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).cuda()
+    H.call("mca_cast_pad_bf16_multi", dev.data_ptr(), len(cases), H.stream_ptr())
+    torch.cuda.synchronize()
+    for i, (w, o) in enumerate(zip(want, got)):
+        assert torch.equal(w, o), cases[i]
+
+
 def test_pack_masks(H):
     """padding / row masks / presence bits of every modality in one launch (bool and int64 masks, a fully padded sample)."""
     g = torch.Generator(device="cuda").manual_seed(12)
