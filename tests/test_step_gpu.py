@@ -276,7 +276,8 @@ def test_forward_bitwise_deterministic_at_cmu_size(P, b):
                 assert torch.equal(x, y), f"tensor {i} differs between two forwards of the same inputs"
 
 
-def test_full_size_gradients_new_vs_conservative_kernels(P):
+@pytest.mark.parametrize("kind,b", [("cmu", 32), ("mma", 32), ("tcga", 16)])
+def test_full_size_gradients_new_vs_conservative_kernels(P, kind, b):
     """Whole-chip cross-check of the pipelined kernels (b = 32, every CU busy): one forward + backward with the production
     kernels (persistent / fused GEMMs, 256x256 weight-gradient tiles, XCD-remapped order) against the same step with the
     conservative ones (one tile per workgroup, unfused GEGLU / LayerNorm residual, 256x128 weight gradients, launch order).
@@ -284,8 +285,8 @@ def test_full_size_gradients_new_vs_conservative_kernels(P):
     shows as percent-level error on the tensors fed by the broken kernel."""
     hipm = importlib.import_module("mca-paper_amd.hip")
     data = importlib.import_module("mca-paper_amd.data")
-    b = 32
-    cfg = P.config.cmu_model_config(batch_size=b)
+    cfg = {"cmu": lambda: P.config.cmu_model_config(batch_size=b), "mma": lambda: P.config.cmu_model_config(batch_size=b, zorro=True),
+           "tcga": lambda: P.config.tcga_model_config(batch_size=b)}[kind]()
     batch = data.synthetic_batch(cfg, b, seed=1234, lengths="uniform", p_drop=0.2, device="cuda")
 
     def run(conservative):
@@ -309,7 +310,7 @@ def test_full_size_gradients_new_vs_conservative_kernels(P):
         for key in (7, 5, 9):
             hipm.lib().mca_debug_set(key, 0)
     # dropped modalities give rows with no valid key: their output is mean(V), summed with fp32 atomics (order-dependent)
-    assert abs(l_new - l_new2) <= 1e-5 * abs(l_new)
+    assert abs(l_new - l_new2) <= 5e-5 * abs(l_new)
     assert abs(l_new - l_old) <= 2e-3 * abs(l_old)           # bf16 rounding placement differs (fused vs unfused epilogues)
     # The two paths round in different places (fused FF1+GEGLU epilogue, fp32 vs bf16 dg): pooled embeddings differ by a few
     # 1e-4 and the temperature-14 contrastive softmax turns that into a uniform ~1-3 % on every gradient (measured:
