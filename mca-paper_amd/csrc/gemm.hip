@@ -3,17 +3,22 @@
 //   mca_gemm_nt     C[M,N]  = A[M,K] · B[N,K]^T      both operands K-contiguous (Linear forward with
 //                                                     x[M,K], W[N,K]; data-gradient with the transposed
 //                                                     bf16 weight copy)
+//   mca_gemm_nt_lnres / _geglu_fwd / _geglu_bwd       the same GEMM with a fused epilogue (residual LayerNorm
+//                                                     recomputed; FF1 + GEGLU; W2 data gradient + GEGLU')
 //   mca_gemm_tn_acc C[N,K] += A[R,N]^T · B[R,K]      both operands reduction-major (weight gradient:
 //                                                     dW = dY^T · X), operands fetched from LDS with the
 //                                                     gfx950 transposed read ds_read_b64_tr_b16
 //
-// Tile 128x128x64, 256 threads = 4 wavefronts (2x2), each wavefront a 64x64 sub-tile as 2x2
-// v_mfma_f32_32x32x16_bf16 accumulators.  NT: operand tiles go global -> LDS directly
-// (global_load_lds_dwordx4, double-buffered) with the XOR swizzle on the source address and on the fragment
-// reads (16-byte reads bank-conflict free); the C tile leaves through LDS as whole 16-byte row pieces with
-// bias / residual fused.  TN: register-staged tiles, transposed LDS reads, fp32 atomics.  Workgroup ids are
-// remapped so that the blocks sharing an XCD (ids congruent mod 8) walk neighbouring tiles and reuse the
-// A panel from that XCD's L2.
+// Kernels (all v_mfma_f32_32x32x16_bf16, operands global -> LDS by global_load_lds_dwordx4 with the XOR swizzle
+// applied to the source address and again on the fragment reads, counted s_waitcnt vmcnt so the DMA stays in flight
+// across the raw s_barrier of a k-step):
+//   gemm_nt_persist_kernel   256x128 tiles walked by one workgroup per CU; next tile's DMA under a wave-private,
+//                            all-asm epilogue; bf16 / plain fp32 outputs and the two GEGLU fusions (M >= 2048)
+//   gemm_nt_256_kernel       256x128x64, three stages, one tile per workgroup; fp32 + residual outputs (residual tile
+//                            prefetched into registers; optional LayerNorm recompute), fallback for odd shapes
+//   gemm_nt_glds_kernel      128x128x64, two stages: small M
+//   gemm_tn_256x256_kernel / gemm_tn_256_kernel / gemm_tn_kernel   weight gradient, split over rows + fp32 atomics
+// Workgroup ids are remapped (xcd_remap) so that workgroups sharing operands sit on one XCD / L2.
 #include "common.h"
 
 #define g_knob mca_knobs     // A/B measurement knobs (mca_debug_set, optim.hip)
