@@ -783,6 +783,188 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// PERSISTENT NT kernel with 256 x 256 tiles (bf16 output, N % 256 == 0): the k-loop of these GEMMs is bound by the
+// L2 -> LDS path per CU, and a 256x256 tile moves 2/3 of the operand bytes per flop of a 256x128 one.  8 wavefronts as
+// 4 (m) x 2 (n), each 64 x 128 = 2 x 4 accumulators (128 VGPRs, operands swapped: lane = row); k-steps of 32 so that FOUR
+// stages of 32 KiB fit (DMA three steps ahead); the next tile's first three stages are issued before the epilogue, which
+// uses the fourth slot + 32 KiB as 8 KiB of scratch per wave (two passes of 32 rows x 256 B).  vmcnt per wave: 4 loads per
+// stage, 16 stores per tile.
+// ---------------------------------------------------------------------------------------------------------
+#define P2_STAGE (512 * 32)          // elements per stage: A image [256][32] then B image [256][32]
+#define P2_LDS_BYTES (4 * P2_STAGE * 2 + 32768)
+// GEGLU = true: fused FF1 + GEGLU forward (see mca_gemm_nt_geglu_fwd): B = W1 [2*N, K] with N = ip, a column tile = 128 "a"
+// rows + the 128 "gate" rows of the same columns (wave column wn = 0 holds a, wn = 1 gate), C = h [M, 2*N], G = g [M, N].
+template <bool GEGLU>
+__global__ __launch_bounds__(512) void gemm_nt_persist256_kernel(
+    const u16* __restrict__ A, int64_t lda, const u16* __restrict__ B, int64_t ldb, u16* __restrict__ C, int64_t ldc,
+    u16* __restrict__ G, int64_t ldg, int M, int N, int K, int tiles_n, int nwg, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) u16 lds2[];
+  constexpr int NST = GEGLU ? 24 : 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int nkt = K / 32;
+  const int tiles_m = nwg / tiles_n;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const u16*)lds2;
+  const unsigned scratch = lds_base + 3u * (unsigned)(P2_STAGE * 2) + (unsigned)wave * 8192u;          // slot 3 and the 32 KiB after it
+
+  // fragment byte addresses inside a stage: row R (64-byte rows), k16-step ks: R*64 + ((lh ^ sw(R)) << 4) ^ (32*ks)
+  unsigned fa_addr[2], fb_addr[4];
+#pragma unroll
+  for (int i = 0; i < 2; i++) { const int r = wm * 64 + i * 32 + l31; fa_addr[i] = lds_base + (unsigned)(r * 64 + ((lh ^ gl_sw<32>(r)) << 4)); }
+#pragma unroll
+  for (int j = 0; j < 4; j++) { const int r = wn * 128 + j * 32 + l31; fb_addr[j] = lds_base + 256u * 64u + (unsigned)(r * 64 + ((lh ^ gl_sw<32>(r)) << 4)); }
+
+  const u16* ga[2];
+  const u16* gb[2];
+  auto tile_ptrs = [&](int tile) {
+    int tm, tn;
+    ps_tile_decode(tile, tiles_m, tiles_n, 0, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int p = (i * 8 + wave) * 64 + lane, r = p >> 2, c = (p & 3) ^ gl_sw<32>(r);
+      int ra = m0 + r; if (ra > M - 1) ra = M - 1;
+      ga[i] = A + (int64_t)ra * lda + c * 8;
+      // N % 256 == 0 (GEGLU: N % 128 == 0): no clamp.  GEGLU: tile rows 0..127 = "a" rows, 128..255 = "gate" rows
+      const int rb = GEGLU ? (r < 128 ? tn * 128 + r : N + tn * 128 + (r - 128)) : n0 + r;
+      gb[i] = B + (int64_t)rb * ldb + c * 8;
+    }
+  };
+  auto stage = [&](int k0, int st) {
+    u16* base = lds2 + st * P2_STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + (i * 8 + wave) * 512), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + 256 * 32 + (i * 8 + wave) * 512), 16, 0, 0);
+    }
+  };
+
+  int v = blockIdx.x;
+  if (v >= nwg) return;
+  tile_ptrs(xcd_remap(v, nwg));
+  stage(0, 0); stage(32, 1); stage(64, 2);
+  bool first = true;
+  while (v < nwg) {
+    const int tile = xcd_remap(v, nwg);
+    int tm, tn;
+    ps_tile_decode(tile, tiles_m, tiles_n, 0, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    for (int kt = 0; kt < nkt; kt++) {
+      // stage kt has landed once only the operations issued after its DMA are outstanding (host: nkt >= 6)
+      if (kt < 3) { if (first) ps_wait_vm<8>(); else ps_wait_vm<8 + NST>(); }
+      else if (kt + 2 < nkt) ps_wait_vm<8>();
+      else if (kt + 1 < nkt) ps_wait_vm<4>();
+      else ps_wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + 3 < nkt) stage((kt + 3) * 32, (kt + 3) & 3);
+      const unsigned so = (unsigned)(kt & 3) * (unsigned)(P2_STAGE * 2);
+      u32x4v fa[2][2], fb[2][4];          // [k16-step][block]
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) NT_DSREAD(fa[ks][i], (fa_addr[i] + so) ^ (32u * ks));
+#pragma unroll
+        for (int j = 0; j < 4; j++) NT_DSREAD(fb[ks][j], (fb_addr[j] + so) ^ (32u * ks));
+      }
+      asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&fb[0][j]),
+                                                              *reinterpret_cast<const bf16x8*>(&fa[0][i]), acc[i][j], 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&fb[1][j]),
+                                                              *reinterpret_cast<const bf16x8*>(&fa[1][i]), acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_barrier();                  // every wave has read its last fragments: all four slots are free
+    // ---------------- epilogue: acc[i][j][4q + e] = C[mw + 32i + l31][nw + 32j + 8q + 4lh + e] ----------------
+    const int mw = m0 + wm * 64, nw = GEGLU ? (wn == 0 ? tn * 128 : N + tn * 128) : n0 + wn * 128;
+    const bool edge = m0 + 256 > M;
+    const int vn = v + gridDim.x;
+    const bool has_next = vn < nwg;
+    if (has_next) {
+      tile_ptrs(xcd_remap(vn, nwg));
+      stage(0, 0); stage(32, 1); stage(64, 2);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      // bf16 payload of row block i: 32 rows x 256 B; 16-byte chunk c of row r at chunk c ^ (r & 15)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          u32x2v pk;
+          pk[0] = pack2bf(acc[i][j][4 * q], acc[i][j][4 * q + 1]); pk[1] = pack2bf(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+          const int ch = j * 4 + q;
+          PS_DSW64(scratch + (unsigned)(l31 * 256 + ((ch ^ (l31 & 15)) << 4) + 8 * lh), pk);
+        }
+      u32x4v o[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int row = (lane >> 4) + 4 * u, ch = lane & 15;
+        NT_DSREAD(o[u], scratch + (unsigned)(row * 256 + ((ch ^ (row & 15)) << 4)));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int m = mw + i * 32 + (lane >> 4) + 4 * u;
+        u16* cp = C + (int64_t)m * ldc + nw + 8 * (lane & 15);
+        if (m < M) PS_GSTORE(cp, o[u]);
+      }
+      if (GEGLU) {
+        // g = a * gelu(gate): the partner wave (same rows, other column half) holds the other operand; both row blocks are
+        // in the scratch areas now.  Wave wn takes rows 16*wn .. 16*wn + 15 of the pair's 32 rows.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const unsigned sa = lds_base + 3u * (unsigned)(P2_STAGE * 2) + (unsigned)(wave & ~1) * 8192u, sg = sa + 8192u;
+        u32x4v av[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int row = 16 * wn + (lane >> 4) + 4 * u, ch = lane & 15;
+          NT_DSREAD(av[u], sa + (unsigned)(row * 256 + ((ch ^ (row & 15)) << 4)));
+          NT_DSREAD(gv[u], sg + (unsigned)(row * 256 + ((ch ^ (row & 15)) << 4)));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int m = m0 + wm * 64 + i * 32 + 16 * wn + (lane >> 4) + 4 * u;
+          u32x4v gg;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float a0 = __uint_as_float(av[u][e] << 16), a1 = __uint_as_float(av[u][e] & 0xffff0000u);
+            const float g0 = __uint_as_float(gv[u][e] << 16), g1 = __uint_as_float(gv[u][e] & 0xffff0000u);
+            float ge0, ge1, unused;
+            gelu_pair(g0, ge0, unused); gelu_pair(g1, ge1, unused);
+            gg[e] = pack2bf(a0 * ge0, a1 * ge1);
+          }
+          u16* gp = G + (int64_t)m * ldg + tn * 128 + 8 * (lane & 15);
+          if (m < M) PS_GSTORE(gp, gg);
+        }
+        if (i == 0) asm volatile("s_barrier" ::: "memory");          // the partner has read this row block: scratch may be overwritten
+      }
+    }
+    if (edge) ps_wait_vm<0>();
+    first = false;
+    v = vn;
+  }
+}
+
 extern "C" int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
                            int out_bf16, const float* bias, const float* residual, int64_t ldres,
                            int64_t res_period, int64_t M, int64_t N, int64_t K, mca_stream_t stream) {
@@ -817,6 +999,21 @@ extern "C" int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, in
   // (fp32 output + residual: HBM-bound, the lock-step kernel with its residual prefetch measures 10-16 % faster: MODE 2 of
   // the persistent kernel is only used with knob 7 = 3)
   const bool ps_res = res == 1 && !out_bf16 && ldres % 4 == 0 && (uintptr_t)residual % 16 == 0 && g_knob[7] == 3;
+  // bf16 output, N % 256 == 0: 256x256 tiles (knob 10 = 1: keep the 256x128 persistent kernel, A/B)
+  if (big && g_knob[7] == 0 && g_knob[10] != 1 && out_bf16 && res == 0 && !bias && N % 256 == 0 && K >= 192 && K % 32 == 0 && c16) {
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_persist256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              P2_LDS_BYTES) != hipSuccess)
+        return MCA_E_LAUNCH;
+      attr = true;
+    }
+    const int tn2 = (int)(N / 256), nw2 = (int)((M + 255) / 256) * tn2;
+    const int grid = nw2 < num_cus() ? nw2 : num_cus();
+    hipLaunchKernelGGL(gemm_nt_persist256_kernel<false>, dim3(grid), dim3(512), P2_LDS_BYTES, as_stream(stream), A, lda, B, ldb,
+                       reinterpret_cast<u16*>(C), ldc, (u16*)nullptr, (int64_t)0, (int)M, (int)N, (int)K, tn2, nw2, g_knob[0]);
+    return launch_status();
+  }
   if (big && (g_knob[7] == 0 || g_knob[7] == 3) && N % BN == 0 && K >= 320 && c16 && (res == 0 || ps_res) && (!bias || (uintptr_t)bias % 16 == 0)) {
     const int grid = nwg2 < num_cus() ? nwg2 : num_cus();
 #define NT_LAUNCH_PS(MODE, BI)                                                                                               \
@@ -919,6 +1116,20 @@ extern "C" int mca_gemm_nt_geglu_fwd(const uint16_t* A, int64_t lda, const uint1
     return MCA_E_ALIGN;
   if (lda < K || ldb < K || ldh < 2 * ip || ldg < ip) return MCA_E_BADARG;
   if (M > (1LL << 30)) return MCA_E_UNSUPPORTED;
+  if (M >= 2048 && ip % 128 == 0 && K >= 192 && g_knob[7] != 1 && g_knob[10] != 1) {
+    static bool attr2 = false;
+    if (!attr2) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_persist256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              P2_LDS_BYTES) != hipSuccess)
+        return MCA_E_LAUNCH;
+      attr2 = true;
+    }
+    const int tn2 = (int)(ip / 128), nw2 = (int)((M + 255) / 256) * tn2;
+    const int grid = nw2 < num_cus() ? nw2 : num_cus();
+    hipLaunchKernelGGL(gemm_nt_persist256_kernel<true>, dim3(grid), dim3(512), P2_LDS_BYTES, as_stream(stream), A, lda, W1, ldb, h, ldh, g,
+                       ldg, (int)M, (int)ip, (int)K, tn2, nw2, g_knob[0]);
+    return launch_status();
+  }
   if (M >= 2048 && ip % 64 == 0 && K >= 320 && g_knob[7] != 1) {
     static bool attr = false;
     if (!attr) {

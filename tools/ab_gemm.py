@@ -23,7 +23,7 @@ def ab(make_fn, rounds=5):
     return {v: (sorted(r)[len(r) // 2], min(r)) for v, r in res.items()}
 shapes = [("qkv  bf16", 1536, 512, True, False), ("out  f32+res", 512, 512, False, True), ("ff1  bf16", 2816, 512, True, False),
           ("ff2  f32+res", 512, 1408, False, True), ("dgrad ff1 f32+res", 512, 2816, False, True),
-          ("dgrad qkv f32+res", 512, 1536, False, True), ("plain f32", 512, 512, False, False), ("K=64 bf16", 1536, 64, True, False),
+          ("dgrad qkv f32+res", 512, 1536, False, True), ("plain f32", 512, 512, False, False), ("oT dgrad bf16", 512, 512, True, False), ("bf16 N=1024", 1024, 512, True, False), ("K=64 bf16", 1536, 64, True, False),
           ("K=128 bf16", 1536, 128, True, False), ("K=192 f32", 512, 192, False, False), ("big-K bf16", 2048, 4096, True, False)]
 torch.manual_seed(0)
 for nm, N, K, obf, res in shapes:
