@@ -34,13 +34,13 @@ def pmc_traffic(kernel_key: str):
     None when no PMC summary is committed for that kernel."""
     path = os.path.join(REPO, "profiles", "r01_hbm_traffic_pmc.json")
     names = {"mca_gemm_nt": "gemm_nt_", "mca_gemm_tn_acc": "gemm_tn_", "mca_attn_fwd/layer": "attn_fwd_kernel",
-             "mca_attn_bwd/layer": "attn_bwd_kernel", "mca_gemm_nt_geglu_fwd": "gemm_nt_persist_kernel<4",
+             "mca_attn_bwd/layer": "attn_bwd_kernel", "mca_gemm_nt_geglu_fwd": "gemm_nt_persist256_kernel<true>",
              "mca_gemm_nt_geglu_bwd": "gemm_nt_persist_kernel<3", "mca_gemm_nt_lnres": "gemm_nt_256_kernel<false, 1, 1, 2>"}
     if not os.path.exists(path) or kernel_key not in names:
         return None
     tot_b, tot_n = 0.0, 0
     for k, v in json.load(open(path)).items():
-        if names[kernel_key] in k and not (kernel_key == "mca_gemm_nt" and ("persist_kernel<3" in k or "persist_kernel<4" in k)):
+        if names[kernel_key] in k and not (kernel_key == "mca_gemm_nt" and ("persist_kernel<3" in k or "persist256_kernel<true>" in k or "1, 1, 2>" in k)):
             tot_b += (v["fetch_MB_x2_gfx950"] + v["write_MB_per_launch"]) * 1e6 * v["launches"]
             tot_n += v["launches"]
     return {"bytes_per_launch": round(tot_b / tot_n), "source": "profiles/r01_hbm_traffic_pmc.json"} if tot_n else None
