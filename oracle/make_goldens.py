@@ -14,6 +14,7 @@ Fixtures
                    grad-norm, weights after 1 and 2 AdamW steps (lr 1e-3, clip 2.0).
   collators.pt   : the reference's MultimodalCollator (sequence / embedded_sequence / matrix) on ragged samples with
                    missing modalities: input samples and collated batch.
+  tcga_b2.pt     : TCGA_config1-shaped config (4 tabular modalities, N=2548, 60 loss terms) at b=2, same recipe as cmu_*.
   cmu_<case>.pt  : CMU-shaped config (N=2538, D=512, L=5) at b=2 with weights from the build's own
                    deterministic initialiser; pooled embeddings, loss terms, per-parameter grad norms.
 """
@@ -236,6 +237,39 @@ def make_cmu(refmodel):
         print(f"cmu_{case}: loss {float(rec['loss']):.5f}")
 
 
+def make_tcga(refmodel):
+    """TCGA_config1-shaped run (4 TabularEncoder modalities, N = 2548, 60 loss terms) at b=2 through the reference."""
+    import importlib
+    sys.path.insert(0, REPO)
+    pkg = importlib.import_module("mca-paper_amd")
+    cfg = pkg.config.tcga_model_config(batch_size=2)
+    torch.manual_seed(43)
+    real_save = torch.save
+    torch.save = lambda *a, **k: None
+    try:
+        model = refmodel.MCA(**cfg)
+        sd = pkg.params.init_state_dict(cfg, seed=43)
+        missing = model.load_state_dict(sd, strict=False)
+        assert not missing.unexpected_keys, missing
+        batch = pkg.data.synthetic_batch(cfg, batch_size=2, seed=77, p_drop=0.25)
+        out = model(batch)
+        out["loss"].backward()
+    finally:
+        torch.save = real_save
+    names = list(cfg["encoder_configs"].keys())
+    rec = {
+        "case": "tcga", "seed": 43, "data_seed": 77, "p_drop": 0.25,
+        "pooled": torch.stack([out[n] for n in names] + [out[k] for k in model.fusion_combos], 1).detach(),
+        "losses": {k: v.detach() for k, v in out["losses"].items()},
+        "loss": out["loss"].detach(),
+        "sample_mask": {k: v for k, v in out["modality_sample_mask"].items()},
+        "grad_norms": {n: float(p.grad.norm()) for n, p in model.named_parameters()},
+        "grad_slices": {n: p.grad.flatten()[:64].clone() for n, p in model.named_parameters()},
+    }
+    torch.save(rec, os.path.join(GOLD, "tcga_b2.pt"))
+    print(f"tcga: loss {float(rec['loss']):.5f}, {len(rec['losses'])} terms, pooled {tuple(rec['pooled'].shape)}")
+
+
 def make_collators(refenc):
     """The reference's collators (encoders.py:286-403) on ragged samples with missing modalities, NaNs, over-long rows."""
     g = torch.Generator().manual_seed(7)
@@ -274,6 +308,7 @@ def make_collators(refenc):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--collators", action="store_true")
+    ap.add_argument("--tcga", action="store_true")
     ap.add_argument("--cmu", action="store_true")
     ap.add_argument("--init", action="store_true")
     ap.add_argument("--tiny", action="store_true")
@@ -282,7 +317,9 @@ if __name__ == "__main__":
     refmodel, refenc = import_reference()
     if a.collators:
         make_collators(refenc)
-    if a.tiny or not (a.cmu or a.init or a.collators):
+    if a.tcga:
+        make_tcga(refmodel)
+    if a.tiny or not (a.cmu or a.init or a.collators or a.tcga):
         make_tiny(refmodel)
     if a.init:
         make_init_parity(refmodel)
