@@ -24,30 +24,37 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
+TRACE_OUT = os.path.join(HERE, "libmca_hip_trace.so")
+
+
+def build(force: bool = False, verbose: bool = True, trace: bool = False) -> str:
+    """trace=True: a second library (libmca_hip_trace.so, same ABI) whose attention kernels carry the s_memtime stamps read by
+    tools/trace_attn_*.py (load it with MCA_HIP_LIB); the stamps pin the instruction order, so the product build has none."""
+    out_path = TRACE_OUT if trace else OUT
+    if not trace and not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    bdir = os.path.join(HERE, "build_trace" if trace else "build")
+    os.makedirs(bdir, exist_ok=True)
     for src in SOURCES:
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        obj = os.path.join(bdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, *EXTRA.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *(["-DMCA_TRACE_BUILD"] if trace else []), *EXTRA.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out_path]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
     if verbose:
-        print(f"built {OUT}")
-    return OUT
+        print(f"built {out_path}")
+    return out_path
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, trace="--trace" in sys.argv)

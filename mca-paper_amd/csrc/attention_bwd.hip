@@ -8,7 +8,7 @@
 // the KEY on the MFMA lane (cdna guide, Appendix B "Attention backward"):
 //     S[q][key]   = Q · K^T           A = Q rows (LDS, ds_read_b128),  B = K fragments (registers)
 //     dP[q][key]  = dO · V^T          A = dO rows (LDS),               B = V fragments (registers)
-//     P = exp2(c·S − lse),  dS = P ∘ (dP − delta)
+//     P = exp2(c·S − lse),  dS = P ∘ (dP − delta)     (−lse/c and −delta are the accumulators' start values)
 //     dV^T[d][key] += dO^T · P        A = dO^T (ds_read_b64_tr_b16 of the same LDS image), B = P accumulators
 //     dK^T[d][key] += Q^T · dS        A = Q^T  (transposed reads),                         B = dS accumulators
 //     dQ[q][d]     += dS · K          dS crosses LDS once (transposed image), 16x16x32 MFMA, each wavefront
@@ -32,7 +32,11 @@ __device__ __forceinline__ int ds_off(int key, int c) { return key * 32 + ((c ^ 
 
 // timeline probe (knob 6 bit 3): wave 0 of one workgroup writes s_memtime stamps, read back by tools/trace_attn_bwd.py
 MCA_TRACE_BUFFER(attn_bwd)
+#ifdef MCA_TRACE_BUILD      // the stamps pin the instruction order, so the production build carries none (build.py: trace=True)
 #define AB_STAMP() do { if (tracing && ti < 1024) mca_trace_attn_bwd[ti++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AB_STAMP() do { } while (0)
+#endif
 
 __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int dbg) {
   extern __shared__ __attribute__((aligned(16))) u16 lds[];
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
   const int key0 = kbi * BKEYS;
   const int mykey = key0 + wave * 32 + l31;
   int keyc = mykey; if (keyc > a.nk - 1) keyc = a.nk - 1;
-  const float c2 = a.scale * 1.4426950408889634f;
+  const float c2 = a.scale * 1.4426950408889634f, inv_c2 = 1.f / c2;
 
   const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
   const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
@@ -111,7 +115,12 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
     *reinterpret_cast<bf16x8*>(Qs + buf * BQ * DH + qd_off(srow, sc)) = stage_q;
     *reinterpret_cast<bf16x8*>(Os + buf * BQ * DH + qd_off(srow, sc)) = stage_o;
     // rows past nq contribute nothing: lse = +inf (P = 0), delta = 0, qmask = 0
-    if (tid < 192) rowc[buf * 192 + tid] = stage_oob ? (cwhich == 0 ? INFINITY : 0.f) : stage_c;
+    // stored as the accumulator start values: -lse / c2 (so that exp2(c2 * acc) = P; +inf lse -> -inf -> P = 0), -delta
+    if (tid < 192) {
+      float v = stage_oob ? (cwhich == 0 ? INFINITY : 0.f) : stage_c;
+      if (cwhich == 0) v = -v * inv_c2; else if (cwhich == 1) v = -v;
+      rowc[buf * 192 + tid] = v;
+    }
   };
 
   const int it_begin = a.k_ptr[kbi], it_end = a.k_ptr[kbi + 1];
@@ -151,9 +160,18 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
     u16* ds = Ds + buf * BKEYS * BQ + sub * BKEYS * 32;
 
     // ---- S and dP (rows = q in registers, column = key on the lane)
+    // The accumulators start from the row constants (-lse / c2 and -delta, stored that way by swrite): the products come out
+    // as S - lse / c2 and dP - delta, and the LDS latency of the constants hides behind the fragment reads instead of
+    // standing in the middle of the exp / multiply phase.  (Computing S / dP of both sub-tiles first, so that the MFMAs of
+    // the second run under the exp phase of the first, needs 32 more registers than the 256 a wavefront has here: 55 spills.)
     f32x16 s, dp;
 #pragma unroll
-    for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+    for (int g = 0; g < 4; g++) {
+      const f32x4 lse4 = *reinterpret_cast<const f32x4*>(rc + 8 * g + 4 * lh);
+      const f32x4 del4 = *reinterpret_cast<const f32x4*>(rc + 64 + 8 * g + 4 * lh);
+#pragma unroll
+      for (int e = 0; e < 4; e++) { s[4 * g + e] = lse4[e]; dp[4 * g + e] = del4[e]; }
+    }
 #pragma unroll
     for (int st = 0; st < 4; st++) {
       const bf16x8 qfrag = *reinterpret_cast<const bf16x8*>(qs + qd_off(l31, 2 * st + lh));
@@ -166,31 +184,23 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
     bf16x8 pb[2], sb[2];
     if (full && wave_keys_ok) {
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(rc + 8 * g + 4 * lh);
-        const f32x4 del4 = *reinterpret_cast<const f32x4*>(rc + 64 + 8 * g + 4 * lh);
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const int r = 4 * g + e;
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse4[e]));
-          const float dsv = p * (dp[r] - del4[e]);
-          pb[r >> 3][r & 7] = (short)f2bf(p);
-          sb[r >> 3][r & 7] = (short)f2bf(dsv);
-        }
+      for (int r = 0; r < 16; r++) {
+        const float p = __builtin_amdgcn_exp2f(s[r] * c2);
+        const float dsv = p * dp[r];
+        pb[r >> 3][r & 7] = (short)f2bf(p);
+        sb[r >> 3][r & 7] = (short)f2bf(dsv);
       }
     } else {
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(rc + 8 * g + 4 * lh);
-        const f32x4 del4 = *reinterpret_cast<const f32x4*>(rc + 64 + 8 * g + 4 * lh);
         const f32x4 qm4 = *reinterpret_cast<const f32x4*>(rc + 128 + 8 * g + 4 * lh);
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int r = 4 * g + e;
           const uint32_t qsel = full ? 0xffffffffu : __float_as_uint(qm4[e]);
-          float p = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse4[e]));
+          float p = __builtin_amdgcn_exp2f(s[r] * c2);
           p = (qsel & keybit) ? p : 0.f;
-          const float dsv = p * (dp[r] - del4[e]);
+          const float dsv = p * dp[r];
           pb[r >> 3][r & 7] = (short)f2bf(p);
           sb[r >> 3][r & 7] = (short)f2bf(dsv);
         }
@@ -329,42 +339,67 @@ extern "C" int mca_attn_bwd(const mca_attn_bwd_args* a, mca_stream_t stream) {
 // delta[b,h,q] = sum_d dO[q,h,d] * O[q,h,d];  dvmean[b, h*64+d] = (1/nk) sum over uniform rows (lse = +inf) of dO
 // one wavefront per (b, q) row: lane covers 8 contiguous columns of the 512-wide row -> head = lane / 8
 // =====================================================================================================
+#define PREP_ROWS 32
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restrict__ o, const u16* __restrict__ d_o,
                                                              int64_t bstride, int64_t ld, const float* __restrict__ lse,
                                                              float* __restrict__ delta, float* __restrict__ dvmean,
-                                                             int heads, int nq, float inv_nk, int rows_per_block) {
-  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                             int heads, int nq, float inv_nk) {
+  // lse / delta are (b, head, q): a row touches them at a stride of nq floats per head.  They cross LDS so that the global
+  // accesses are 128-byte runs along q (one row at a time they were 4-byte accesses in 8 different lines per row).
+  __shared__ float lse_s[8][PREP_ROWS], del_s[8][PREP_ROWS];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cols = heads * DH;
-  const int q_begin = blockIdx.x * rows_per_block;
-  int q_end = q_begin + rows_per_block; if (q_end > nq) q_end = nq;
+  const int q_begin = blockIdx.x * PREP_ROWS;
+  int q_end = q_begin + PREP_ROWS; if (q_end > nq) q_end = nq;
   for (int c0 = 0; c0 < cols; c0 += 512) {
+    const int h0 = c0 / DH;
+    {
+      const int hh = tid / PREP_ROWS, r = tid % PREP_ROWS;          // 8 heads x 32 rows = 256 threads
+      if (h0 + hh < heads && q_begin + r < q_end) lse_s[hh][r] = lse[((int64_t)b * heads + h0 + hh) * nq + q_begin + r];
+    }
+    __syncthreads();
     const int c = c0 + lane * 8;
-    const int hh = c / DH;
+    const int hl = lane >> 3;          // head of this lane inside the 512-column slab
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool any = false;
-    for (int q = q_begin + wave; q < q_end; q += 4) {
+    // all PREP_ROWS / 4 rows of this wavefront are requested before any is used (a row at a time the loop is latency-bound)
+    bf16x8 ovs[PREP_ROWS / 4], dvs[PREP_ROWS / 4];
+#pragma unroll
+    for (int k = 0; k < PREP_ROWS / 4; k++) {
+      int q = q_begin + wave + 4 * k; if (q > nq - 1) q = nq - 1;
+      const int cc = c < cols ? c : 0;
+      ovs[k] = *reinterpret_cast<const bf16x8*>(o + (int64_t)b * bstride + (int64_t)q * ld + cc);
+      dvs[k] = *reinterpret_cast<const bf16x8*>(d_o + (int64_t)b * bstride + (int64_t)q * ld + cc);
+    }
+#pragma unroll
+    for (int k = 0; k < PREP_ROWS / 4; k++) {
+      const int q = q_begin + wave + 4 * k;
+      if (q >= q_end) break;
       float part = 0.f;
-      bool uni = false;
       if (c < cols) {
-        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(o + (int64_t)b * bstride + (int64_t)q * ld + c);
-        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(d_o + (int64_t)b * bstride + (int64_t)q * ld + c);
-        uni = lse[((int64_t)b * heads + hh) * nq + q] == INFINITY;
+        const bool uni = lse_s[hl][q - q_begin] == INFINITY;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          const float dvj = bf2f((u16)dv[j]);
-          part += dvj * bf2f((u16)ov[j]);
+          const float dvj = bf2f((u16)dvs[k][j]);
+          part += dvj * bf2f((u16)ovs[k][j]);
           if (uni) { acc[j] += dvj; any = true; }
         }
       }
       // 8 lanes per head
       part += __shfl_xor(part, 1, WAVE); part += __shfl_xor(part, 2, WAVE); part += __shfl_xor(part, 4, WAVE);
-      if (c < cols && (lane & 7) == 0) delta[((int64_t)b * heads + hh) * nq + q] = part;
+      if ((lane & 7) == 0) del_s[hl][q - q_begin] = part;
+    }
+    __syncthreads();
+    {
+      const int hh = tid / PREP_ROWS, r = tid % PREP_ROWS;
+      if (h0 + hh < heads && q_begin + r < q_end) delta[((int64_t)b * heads + h0 + hh) * nq + q_begin + r] = del_s[hh][r];
     }
     if (any && c < cols) {
 #pragma unroll
       for (int j = 0; j < 8; j++)
         if (acc[j] != 0.f) atomicAdd(dvmean + (int64_t)b * cols + c + j, acc[j] * inv_nk);
     }
+    __syncthreads();
   }
 }
 extern "C" int mca_attn_bwd_prep(const uint16_t* o, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld,
@@ -373,8 +408,7 @@ extern "C" int mca_attn_bwd_prep(const uint16_t* o, const uint16_t* d_o, int64_t
   if (!o || !d_o || !lse || !delta || !dvmean || batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0) return MCA_E_BADARG;
   if (o_ld % 8 || o_bstride % 8 || (uintptr_t)o % 16 || (uintptr_t)d_o % 16) return MCA_E_ALIGN;
   if (hipMemsetAsync(dvmean, 0, (size_t)batch * heads * DH * sizeof(float), as_stream(stream)) != hipSuccess) return MCA_E_LAUNCH;
-  const int rpb = 32;
-  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((nq + rpb - 1) / rpb, batch), dim3(256), 0, as_stream(stream), o, d_o,
-                     o_bstride, o_ld, lse, delta, dvmean, heads, nq, 1.f / (float)nk, rpb);
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((nq + PREP_ROWS - 1) / PREP_ROWS, batch), dim3(256), 0, as_stream(stream), o, d_o,
+                     o_bstride, o_ld, lse, delta, dvmean, heads, nq, 1.f / (float)nk);
   return launch_status();
 }

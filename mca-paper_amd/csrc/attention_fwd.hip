@@ -23,6 +23,13 @@
 #define DH 64       // head dim (fixed)
 #define MAX_KTILES 512
 
+MCA_TRACE_BUFFER(attn_fwd)      // knob 8 = 8: s_memtime stamps of one wavefront (tools/trace_attn_fwd.py)
+#ifdef MCA_TRACE_BUILD      // the stamps pin the instruction order, so the production build carries none (build.py: trace=True)
+#define FW_STAMP() do { if (tracing && ti < 1017) mca_trace_attn_fwd[ti++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FW_STAMP() do { } while (0)
+#endif
+
 // K tile image: [64 keys][64 d] bf16, 128-byte rows, chunk c (16 B) of row r at c ^ ((r>>1)&7)
 __device__ __forceinline__ int k_off(int r, int c) { return r * 64 + ((c ^ ((r >> 1) & 7)) << 3); }
 // V tile image: same shape, chunk c of row r at c ^ (4*((r>>1)&1)): the 4 rows of a transposed 4x16 read
@@ -127,7 +134,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
   __syncthreads();
 
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  const bool tracing = (dbg & 8) && lin0 == 8 * 3 && tid == 0;
+  int ti = 0;
+  const uint64_t rt0 = tracing ? __builtin_amdgcn_s_memrealtime() : 0, cy0 = tracing ? __builtin_readcyclecounter() : 0;
   while (it < it_end) {
+    FW_STAMP();
     const uint32_t ent = a.q_kt[it];
     const int kt = (int)(ent & 0x7fffffffu);
     const bool need_mask = (ent >> 31) == 0 || (flags_s[kt] != 2);
@@ -148,6 +159,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[kb], 0, 0, 0);
       }
     }
+    FW_STAMP();
     // ---- masking (structure boundary / padded keys / keys past nk)
     if (need_mask) {
 #pragma unroll
@@ -163,6 +175,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
           }
         }
     }
+    FW_STAMP();
     // ---- online softmax (log2 domain), lane = query
     float mx = -INFINITY;
 #pragma unroll
@@ -185,6 +198,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
           rs += p;
           pb[kb][sp][j] = (short)f2bf(p);
         }
+    FW_STAMP();
     rs += __shfl_xor(rs, 32, WAVE);
     l_run = l_run * alpha + rs;
     m_run = m_new;
@@ -212,12 +226,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
           o[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kb][sp], o[n], 0, 0, 0);
         }
 
+    FW_STAMP();
     if (nit < it_end) swrite(buf ^ 1);
+    FW_STAMP();
     __syncthreads();
+    FW_STAMP();
     buf ^= 1;
     it = nit;
   }
 
+#ifdef MCA_TRACE_BUILD
+  if (tracing) {      // shader clock of this launch: cycles per 100 MHz tick
+    mca_trace_attn_fwd[1020] = __builtin_amdgcn_s_memrealtime() - rt0; mca_trace_attn_fwd[1021] = __builtin_readcyclecounter() - cy0;
+  }
+#endif
   // ---- epilogue
   const bool uniform = !(l_run > 0.f);
   const float inv = uniform ? 0.f : 1.f / l_run;
@@ -251,7 +273,7 @@ extern "C" int mca_attn_fwd(const mca_attn_fwd_args* a, mca_stream_t stream) {
       (uintptr_t)a->keyinfo % 4)
     return MCA_E_ALIGN;
   if (a->heads > 65535 || a->batch > 65535 || a->n_ktiles > MAX_KTILES) return MCA_E_UNSUPPORTED;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(a->n_qtiles, a->heads, a->batch), dim3(256), 0, as_stream(stream), *a, mca_knobs[9]);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(a->n_qtiles, a->heads, a->batch), dim3(256), 0, as_stream(stream), *a, mca_knobs[9] | mca_knobs[8]);
   return launch_status();
 }
 

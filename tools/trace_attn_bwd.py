@@ -1,5 +1,7 @@
 """Per-phase cycle anatomy of one wavefront of the backward attention kernel (s_memtime stamps, knob 6 = 8)."""
 import ctypes as C, importlib, os, sys, statistics as st, torch
+# needs the trace build: python mca-paper_amd/build.py --trace; it is picked up here through MCA_HIP_LIB
+os.environ.setdefault("MCA_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mca-paper_amd", "libmca_hip_trace.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 P = importlib.import_module("mca-paper_amd"); H = importlib.import_module("mca-paper_amd.hip")
 b = 32

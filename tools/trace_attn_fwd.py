@@ -1,5 +1,7 @@
 """Per-phase cycle anatomy of one wavefront of the forward attention kernel (s_memtime stamps, knob 8 = 8)."""
 import ctypes as C, importlib, os, sys, torch
+# needs the trace build: python mca-paper_amd/build.py --trace; it is picked up here through MCA_HIP_LIB
+os.environ.setdefault("MCA_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mca-paper_amd", "libmca_hip_trace.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 P = importlib.import_module("mca-paper_amd"); H = importlib.import_module("mca-paper_amd.hip")
 b = 32
@@ -30,3 +32,4 @@ print(f"{len(rows)} key tiles traced (workgroup 3 of head 0 / sample 0, wave 0)"
 for r in rows[:24]: print("  " + "  ".join(f"{n}={v}" for n, v in zip(names, r[:6])) + f"   | iteration {r[6]}")
 import statistics as st
 print("median per phase:", {n: st.median(r[k] for r in rows) for k, n in enumerate(names)}, "iteration", st.median(r[6] for r in rows))
+print(f"workgroup loop: {t[1021]} cycles in {t[1020]} ticks of 100 MHz -> shader clock {t[1021] / max(t[1020], 1) * 100:.0f} MHz")
