@@ -69,6 +69,19 @@ int mca_gemm_nt_geglu_fwd(const uint16_t* A, int64_t lda, const uint16_t* W1, in
 int mca_gemm_tn_acc(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
                     float* C, int64_t ldc, int64_t R, int64_t N, int64_t K, mca_stream_t stream);
 
+/* Several weight gradients over the same R token rows in one launch: C_i[N_i,K_i] += A_i[R,N_i]^T · B_i[R,K_i] for
+ * i < n <= MCA_TN_MAX_GROUP (the four nn.Linear weight gradients of an MCALayer backward, model.py:109-131: to_q/to_kv,
+ * to_out, feedforward[0] (two halves) and feedforward[2]).  Same operand rules as mca_gemm_tn_acc per member; members may
+ * not alias each other's C.  Groups the kernel does not suit run as n single launches (same results).              */
+#define MCA_TN_MAX_GROUP 8
+typedef struct mca_tn_desc {
+  const uint16_t* A; int64_t lda;
+  const uint16_t* B; int64_t ldb;
+  float* C; int64_t ldc;
+  int64_t N, K;
+} mca_tn_desc;
+int mca_gemm_tn_acc_group(const mca_tn_desc* d, int n, int64_t R, mca_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm (model.py:24-31; nn.LayerNorm in encoders.py:51,189,192)
  * --------------------------------------------------------------------------------------------- */

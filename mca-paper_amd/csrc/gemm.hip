@@ -1452,17 +1452,10 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(const u16* __restrict_
 #define BR2 32
 #define TN2_STAGE (BR2 * 512)          // elements per stage: A image [32][256] then B image [32][256]
 #define TN2_LDS_BYTES (4 * TN2_STAGE * 2)
-__global__ __launch_bounds__(512) void gemm_tn_256x256_kernel(const u16* __restrict__ A, int64_t lda,
-                                                               const u16* __restrict__ B, int64_t ldb, float* __restrict__ C,
-                                                               int64_t ldc, int R, int N, int K, int tiles_k, int rows_per_split, int dbg) {
-  extern __shared__ __attribute__((aligned(16))) u16 ldst[];
-  const int lin0 = (int)(blockIdx.x + gridDim.x * blockIdx.y);
-  const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y));          // tiles of one split on one XCD
-  const int tile_id = lin % (int)gridDim.x, split_id = lin / (int)gridDim.x;
-  const int tn = tile_id / tiles_k, tk = tile_id % tiles_k;
+__device__ __forceinline__ void tn_256x256_tile(const u16* __restrict__ A, int64_t lda, const u16* __restrict__ B, int64_t ldb,
+                                                float* __restrict__ C, int64_t ldc, int N, int K, int tn, int tk, int r_begin,
+                                                int r_end, u16* ldst) {
   const int n0 = tn * 256, k0 = tk * 256;
-  const int r_begin = split_id * rows_per_split;
-  int r_end = r_begin + rows_per_split; if (r_end > R) r_end = R;
   if (r_begin >= r_end) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
@@ -1585,6 +1578,45 @@ __global__ __launch_bounds__(512) void gemm_tn_256x256_kernel(const u16* __restr
   }
 }
 
+__global__ __launch_bounds__(512) void gemm_tn_256x256_kernel(const u16* __restrict__ A, int64_t lda,
+                                                               const u16* __restrict__ B, int64_t ldb, float* __restrict__ C,
+                                                               int64_t ldc, int R, int N, int K, int tiles_k, int rows_per_split, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) u16 ldst[];
+  const int lin0 = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+  const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y));          // tiles of one split on one XCD
+  const int tile_id = lin % (int)gridDim.x, split_id = lin / (int)gridDim.x;
+  const int r_begin = split_id * rows_per_split;
+  int r_end = r_begin + rows_per_split; if (r_end > R) r_end = R;
+  tn_256x256_tile(A, lda, B, ldb, C, ldc, N, K, tile_id / tiles_k, tile_id % tiles_k, r_begin, r_end, ldst);
+}
+
+// Several weight gradients over the SAME token rows in one launch (the four of a transformer layer): the launch then has
+// 48 tiles instead of 12, so a full round of workgroups needs 5 row splits instead of 21 and the fp32 atomic traffic (every
+// split adds the whole gradient once; a quarter to a third of the single launches' time) drops four-fold.
+struct tn_group {
+  const u16* A[MCA_TN_MAX_GROUP];
+  const u16* B[MCA_TN_MAX_GROUP];
+  float* C[MCA_TN_MAX_GROUP];
+  int64_t lda[MCA_TN_MAX_GROUP], ldb[MCA_TN_MAX_GROUP], ldc[MCA_TN_MAX_GROUP];
+  int N[MCA_TN_MAX_GROUP], K[MCA_TN_MAX_GROUP], tiles_k[MCA_TN_MAX_GROUP];
+  int first_tile[MCA_TN_MAX_GROUP + 1];
+  int n, R, rows_per_split;
+};
+__global__ __launch_bounds__(512) void gemm_tn_256x256_group_kernel(tn_group g, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) u16 ldst[];
+  const int lin0 = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+  const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y));          // tiles of one split on one XCD
+  const int tile_all = lin % (int)gridDim.x, split_id = lin / (int)gridDim.x;
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < MCA_TN_MAX_GROUP; i++) if (i < g.n && tile_all >= g.first_tile[i]) p = i;
+  const int tile_id = tile_all - g.first_tile[p];
+  const int r_begin = split_id * g.rows_per_split;
+  int r_end = r_begin + g.rows_per_split; if (r_end > g.R) r_end = g.R;
+  tn_256x256_tile(g.A[p], g.lda[p], g.B[p], g.ldb[p], g.C[p], g.ldc[p], g.N[p], g.K[p], tile_id / g.tiles_k[p], tile_id % g.tiles_k[p],
+                  r_begin, r_end, ldst);
+}
+
 extern "C" int mca_gemm_tn_acc(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,
                                int64_t R, int64_t N, int64_t K, mca_stream_t stream) {
   if (!A || !B || !C || R <= 0 || N <= 0 || K <= 0) return MCA_E_BADARG;
@@ -1636,5 +1668,55 @@ extern "C" int mca_gemm_tn_acc(const uint16_t* A, int64_t lda, const uint16_t* B
   }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, as_stream(stream), A, lda, B, ldb, C,
                      ldc, (int)R, (int)N, (int)K, tiles_k, (int)rps, g_knob[2]);
+  return launch_status();
+}
+
+extern "C" int mca_gemm_tn_acc_group(const mca_tn_desc* d, int n, int64_t R, mca_stream_t stream) {
+  if (!d || n <= 0 || n > MCA_TN_MAX_GROUP || R <= 0) return MCA_E_BADARG;
+  if (R > (1LL << 30)) return MCA_E_UNSUPPORTED;
+  // The grouped kernel is the 256x256-tile one: members it does not suit (or a group too small to fill the chip) go
+  // through the single-problem entry point, one launch each.
+  tn_group g;
+  int tiles = 0;
+  bool ok = g_knob[11] != 1 && R >= 4096;          // knob 11 = 1: always one launch per member (A/B)
+  for (int i = 0; i < n && ok; i++) {
+    if (!d[i].A || !d[i].B || !d[i].C || d[i].N <= 0 || d[i].K <= 0) return MCA_E_BADARG;
+    if (d[i].lda % 8 || d[i].ldb % 8 || (uintptr_t)d[i].A % 16 || (uintptr_t)d[i].B % 16) return MCA_E_ALIGN;
+    if (d[i].lda < (d[i].N + 7) / 8 * 8 || d[i].ldb < (d[i].K + 7) / 8 * 8 || d[i].ldc < d[i].K) return MCA_E_BADARG;
+    if (d[i].N < 256 || d[i].K < 256 || d[i].N > (1 << 24) || d[i].K > (1 << 24)) { ok = false; break; }
+    g.A[i] = d[i].A; g.B[i] = d[i].B; g.C[i] = d[i].C;
+    g.lda[i] = d[i].lda; g.ldb[i] = d[i].ldb; g.ldc[i] = d[i].ldc;
+    g.N[i] = (int)d[i].N; g.K[i] = (int)d[i].K;
+    g.tiles_k[i] = (int)((d[i].K + 255) / 256);
+    g.first_tile[i] = tiles;
+    tiles += (int)((d[i].N + 255) / 256) * g.tiles_k[i];
+  }
+  if (!ok || n == 1 || tiles < 16 || tiles > 65535) {
+    for (int i = 0; i < n; i++) {
+      const int rc = mca_gemm_tn_acc(d[i].A, d[i].lda, d[i].B, d[i].ldb, d[i].C, d[i].ldc, R, d[i].N, d[i].K, stream);
+      if (rc != MCA_OK) return rc;
+    }
+    return MCA_OK;
+  }
+  for (int i = n; i <= MCA_TN_MAX_GROUP; i++) g.first_tile[i] = tiles;
+  g.n = n; g.R = (int)R;
+  // one full round of workgroups (1 per CU): splits = CUs / tiles, at least 4 steps of 32 rows each
+  int64_t splits = num_cus() / tiles > 0 ? num_cus() / tiles : 1;
+  if (g_knob[3] > 0) splits = g_knob[3];
+  const int64_t max_splits = (R + 4 * BR2 - 1) / (4 * BR2);
+  if (splits > max_splits) splits = max_splits;
+  int64_t rps = (R + splits - 1) / splits;
+  rps = (rps + BR2 - 1) / BR2 * BR2;
+  splits = (R + rps - 1) / rps;
+  g.rows_per_split = (int)rps;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_256x256_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            TN2_LDS_BYTES) != hipSuccess)
+      return MCA_E_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_256x256_group_kernel, dim3(tiles, (unsigned)splits), dim3(512), TN2_LDS_BYTES, as_stream(stream), g,
+                     g_knob[9]);
   return launch_status();
 }

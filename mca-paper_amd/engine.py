@@ -85,6 +85,7 @@ class FusionEngine:
         self.fuse_ln_residual = True                # residual LayerNorm recomputed in the GEMM epilogue (large batches)
         # weight-gradient GEMMs on a side stream, concurrent with the backward chain
         self.overlap_wgrad = os.environ.get("MCA_OVERLAP_WGRAD", "1") != "0"
+        self.group_wgrad = os.environ.get("MCA_GROUP_WGRAD", "1") != "0"      # one weight-gradient launch per layer
         # micro-batch interleave (opt-in, MCA_MICRO_BATCHES=2): batches of at least micro_batch_min samples run as two
         # halves on two streams.  Measured on CMU b=32: 26.3 vs 26.7 ms/step when the host runs ahead, no gain when it
         # does not (tools/ab_step.py 102 1 2, tools/diag_switch.py) - kept off by default.
@@ -311,6 +312,16 @@ class FusionEngine:
         """Cgrad[N,K] += A[R,N]^T B[R,K]"""
         call("mca_gemm_tn_acc", ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(Cgrad), Cgrad.stride(0), R, N, K, stream_ptr(),
              flops=2.0 * R * N * K)
+
+    @staticmethod
+    def gemm_tn_acc_group(members, R):
+        """members: [(A, B, Cgrad, N, K)]: Cgrad[N,K] += A[R,N]^T B[R,K] for every member, one launch (mca_gemm_tn_acc_group)"""
+        arr = (hip.TnDesc * len(members))()
+        fl = 0.0
+        for d, (A, B, Cg, N, K) in zip(arr, members):
+            d.A, d.lda, d.B, d.ldb, d.C, d.ldc, d.N, d.K = ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(Cg), Cg.stride(0), N, K
+            fl += 2.0 * R * N * K
+        call("mca_gemm_tn_acc_group", C.byref(arr), len(members), R, stream_ptr(), flops=fl)
 
     @staticmethod
     def ln_fwd(x, gamma, rows, cols, mean, rstd, beta=None, rowmask=None, add=None, period=0, y=None, ldy=0, y_bstride=0,
@@ -632,7 +643,11 @@ class FusionEngine:
             dxo, dx1, dh, dqkv = a["dxo_b"], a["dx1_b"], a["dh"], a["dqkv"]
             below = ws["layers"][i - 1]["dxo_b"] if i > 0 else ws["dx_b"]
             # x_out = g @ W2^T + x1n            (dx = d x_out fp32, dxo = its bf16 copy)
-            on_side(lambda dxo=dxo, a=a, ly=ly: tn(dxo, a["g"], G(ly.ff.feedforward[2].weight), T, D, I))
+            # The four weight gradients of the layer reduce over the same T rows: grouped into one launch after the layer's
+            # attention backward (48 tiles -> 5 row splits instead of 21 per gradient: a quarter of the fp32 atomic traffic).
+            grouped = self.group_wgrad and T >= 4096
+            if not grouped:
+                on_side(lambda dxo=dxo, a=a, ly=ly: tn(dxo, a["g"], G(ly.ff.feedforward[2].weight), T, D, I))
             if self.fuse_geglu_bwd:
                 # dh = GEGLU'(h) * (dx @ W2): the (T, Ip) intermediate dg is never written (fused GEMM epilogue)
                 call("mca_gemm_nt_geglu_bwd", ptr(dxo), D, ptr(w["w2T"]), D, ptr(a["h"]), ptr(dh), 2 * Ip, Ip, T, D,
@@ -641,7 +656,8 @@ class FusionEngine:
                 self.gemm_nt(dxo, w["w2T"], ws["dg"], T, Ip, D)
                 call("mca_geglu_bwd", ptr(ws["dg"]), ptr(a["h"]), ptr(dh), T, Ip, stream_ptr())
             gw1 = G(ly.ff.feedforward[0].weight)
-            on_side(lambda dh=dh, a=a, gw1=gw1: (tn(dh, a["x1n_b"], gw1, T, I, D), tn(dh[:, Ip:], a["x1n_b"], gw1[I:], T, I, D)))
+            if not grouped:
+                on_side(lambda dh=dh, a=a, gw1=gw1: (tn(dh, a["x1n_b"], gw1, T, I, D), tn(dh[:, Ip:], a["x1n_b"], gw1[I:], T, I, D)))
             self.gemm_nt(dh, w["w1T"], dx_other, T, D, 2 * Ip, residual=dx)            # d x1n = dh @ W1 + dx
             self.ln_bwd(dx_other, D, a["x1"], g, a["m2"], a["r2"], T, D, G(g), dx=dx, dx_bf16=dx1)   # dx = d x1
             # x1 = o @ Wo^T + xn
@@ -654,7 +670,13 @@ class FusionEngine:
             # to_q.weight and to_kv.weight are adjacent in the flat gradient buffer: one (3D, D) weight-gradient GEMM
             gq = G(ly.attn.to_q.weight)
             assert G(ly.attn.to_kv.weight).data_ptr() == gq.data_ptr() + D * D * 4
-            on_side(lambda dqkv=dqkv, a=a, gq=gq: tn(dqkv, a["xn_b"], gq, T, 3 * D, D))
+            if grouped:
+                gw2 = G(ly.ff.feedforward[2].weight)
+                on_side(lambda dqkv=dqkv, dh=dh, dxo=dxo, a=a, gq=gq, gw1=gw1, gw2=gw2: self.gemm_tn_acc_group(
+                    [(dqkv, a["xn_b"], gq, 3 * D, D), (dh, a["x1n_b"], gw1, I, D), (dh[:, Ip:], a["x1n_b"], gw1[I:], I, D),
+                     (dxo, a["g"], gw2, D, I)], T))
+            else:
+                on_side(lambda dqkv=dqkv, a=a, gq=gq: tn(dqkv, a["xn_b"], gq, T, 3 * D, D))
             self.gemm_nt(dqkv, w["qkvT"], dx_other, T, D, 3 * D, residual=dx)          # d xn = dqkv @ Wqkv + d x1
             self.ln_bwd(dx_other, D, ws["x"][i], g, a["m1"], a["r1"], T, D, G(g), dx=dx, dx_bf16=below)  # dx = d x_in
             on_side(lambda bi=bi: bucket_ready(bi + 1))

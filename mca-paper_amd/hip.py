@@ -34,6 +34,11 @@ class CastDesc(C.Structure):
 MAX_MODALITIES = 16
 
 
+class TnDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("C", C.c_void_p), ("ldc", C.c_int64),
+                ("N", C.c_int64), ("K", C.c_int64)]
+
+
 class MaskDesc(C.Structure):
     _fields_ = [("mask", C.c_void_p), ("rowmask", C.c_void_p), ("elem_bytes", C.c_int32), ("n", C.c_int32), ("offset", C.c_int32),
                 ("pad_", C.c_int32)]
@@ -83,6 +88,7 @@ SIGNATURES = {
     "mca_gemm_nt_lnres": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _P]),
     "mca_gemm_nt_geglu_fwd": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P]),
     "mca_gemm_tn_acc": (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P]),
+    "mca_gemm_tn_acc_group": (_I, [_P, _I, _I64, _P]),
     "mca_layernorm_fwd": (_I, [_P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _I, _P, _P, _I64, _I, _F, _P]),
     "mca_layernorm_bwd": (_I, [_P, _I64, _I64, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I, _P]),
     "mca_geglu_fwd": (_I, [_P, _P, _I64, _I, _P]),

@@ -89,6 +89,30 @@ def test_gemm_tn_acc(H, R, N, K, lda, ldb):
     assert rel(Cg, ref) < 2e-5
 
 
+@pytest.mark.parametrize("R,members", [
+    (8192, [(1536, 512, 1536, 512), (1365, 512, 2816, 512), (1365, 512, 2816, 512), (512, 1365, 512, 1408)]),   # a layer's four
+    (4100, [(512, 512, 512, 512), (300, 700, 304, 704), (1024, 256, 1024, 256), (256, 256, 256, 256), (515, 260, 520, 264)]),
+    (5000, [(512, 512, 512, 512), (100, 512, 104, 512)]),          # a member the grouped kernel does not take -> single launches
+    (300, [(512, 512, 512, 512), (512, 256, 512, 256)]),           # too few rows -> single launches
+])
+def test_gemm_tn_acc_group(H, R, members):
+    """mca_gemm_tn_acc_group == the single-problem results, member by member (incl. column offsets into a shared operand)"""
+    g = torch.Generator(device="cuda").manual_seed(12)
+    arr = (H.TnDesc * len(members))()
+    keep, refs = [], []
+    for d, (N, K, lda, ldb) in zip(arr, members):
+        A = bf(torch.randn(R, lda, device="cuda", generator=g))
+        B = bf(torch.randn(R, ldb, device="cuda", generator=g))
+        Cg = torch.randn(N, K, device="cuda", generator=g)
+        refs.append(Cg + A[:, :N].float().t() @ B[:, :K].float())
+        d.A, d.lda, d.B, d.ldb, d.C, d.ldc, d.N, d.K = A.data_ptr(), lda, B.data_ptr(), ldb, Cg.data_ptr(), K, N, K
+        keep.append((A, B, Cg))
+    H.call("mca_gemm_tn_acc_group", C.byref(arr), len(members), R, H.stream_ptr())
+    torch.cuda.synchronize()
+    for (A, B, Cg), ref in zip(keep, refs):
+        assert rel(Cg, ref) < 2e-5
+
+
 # ------------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("rows,cols,affine,masked", [(1000, 512, False, False), (333, 74, True, True), (64, 713, True, True),
                                                       (90, 128, True, True)])
