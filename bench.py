@@ -33,7 +33,7 @@ def pmc_traffic(kernel_key: str):
     MI355X_MICROARCH.md section HBM, + WRITE_SIZE; separate --pmc passes of this same command, see profiles/README.md).
     None when no PMC summary is committed for that kernel."""
     path = os.path.join(REPO, "profiles", "r01_hbm_traffic_pmc.json")
-    names = {"mca_gemm_nt": "gemm_nt_", "mca_gemm_tn_acc": "gemm_tn_", "mca_attn_fwd/layer": "attn_fwd_kernel",
+    names = {"mca_gemm_nt": "gemm_nt_", "mca_gemm_tn_acc": "gemm_tn_", "mca_gemm_tn_acc_group": "gemm_tn_256x256_group_kernel", "mca_attn_fwd/layer": "attn_fwd_kernel",
              "mca_attn_bwd/layer": "attn_bwd_kernel", "mca_gemm_nt_geglu_fwd": "gemm_nt_persist256_kernel<true>",
              "mca_gemm_nt_geglu_bwd": "gemm_nt_persist_kernel<3", "mca_gemm_nt_lnres": "gemm_nt_256_kernel<false, 1, 1, 2>"}
     if not os.path.exists(path) or kernel_key not in names:
@@ -128,7 +128,7 @@ def main():
         step()
         eng.overlap_wgrad, eng.micro_batches = saved
     timed = ("mca_attn_fwd", "mca_attn_bwd", "mca_gemm_nt", "mca_gemm_nt_lnres", "mca_gemm_nt_geglu_fwd", "mca_gemm_nt_geglu_bwd",
-             "mca_gemm_tn_acc")
+             "mca_gemm_tn_acc", "mca_gemm_tn_acc_group")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
