@@ -17,3 +17,13 @@ for mode in (0, 6, 9, 10):
         torch.cuda.synchronize(); assert rc == 0, rc
     n = rows * ld * passes * elems[mode]
     print(f"{names[mode]:48s}: {ms.value * 1e3:8.1f} us  {n / ms.value / 1e6:7.1f} G elements/s  ({n * 4 / ms.value / 1e9:6.2f} TB/s as fp32)", flush=True)
+# L2-resident variant: a buffer of one sample (2538 x 512 fp32 = 5.2 MB over 8 XCD L2s), many passes
+rows2, passes2 = 2538, 160
+dq2 = torch.zeros(rows2, ld, device="cuda")
+for mode in (0, 6, 1):
+    for _ in range(2):
+        ms = C.c_float()
+        rc = lib.atomics_run(mode, dq2.data_ptr(), rows2, ld, passes2, C.byref(ms))
+        torch.cuda.synchronize(); assert rc == 0, rc
+    n = rows2 * ld * passes2
+    print(f"[5 MB buffer] {names[mode]:48s}: {ms.value * 1e3:8.1f} us  {n / ms.value / 1e6:7.1f} G elements/s  ({n * 4 / ms.value / 1e9:6.2f} TB/s as fp32)", flush=True)
