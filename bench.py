@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--p-drop", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--sample-every", type=int, default=5, help="record per-kernel HIP events on every n-th timed step")
+    ap.add_argument("--sample-every", type=int, default=10, help="record per-kernel HIP events on every n-th timed step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
