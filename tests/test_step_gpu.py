@@ -208,6 +208,30 @@ def test_long_sequence_step_runs(P):
         assert torch.isfinite(p).all(), n
 
 
+def test_long_sequence_forward_vs_oracle(P):
+    """BASELINE config 5 layout (N = 6088, 24 key tiles per modality, ragged lengths + dropped modalities) at b = 1: pooled
+    embeddings and loss against the fp32 oracle (forward only: the oracle's dense 6088 x 6088 scores take ~10 s of CPU)."""
+    O = importlib.import_module("oracle.mca_oracle")
+    cfg = P.config.cmu_model_config(batch_size=2, long_seq=True)
+    sd = P.params.init_state_dict(cfg, seed=5)
+    batch = P.data.synthetic_batch(cfg, 2, seed=11, p_drop=0.2, lengths="uniform")
+    model = P.MCA(**copy.deepcopy(cfg))
+    model.load_state_dict(sd, strict=False)
+    model = model.cuda()
+    with torch.no_grad():
+        out = model(to_device(batch, "cuda"))
+        ref = O.mca_forward(O.Structure(copy.deepcopy(cfg)), {k: v.clone() for k, v in sd.items()}, batch, "fp32")
+    slots = model.output_slots()
+    by_slot = {}
+    for k, sl in slots.items():
+        by_slot.setdefault(sl, k)
+    pooled = torch.stack([out[by_slot[sl]] for sl in sorted(by_slot)], 1).cpu()
+    e = rel_err(pooled, ref["pooled"][:, :pooled.shape[1]])
+    assert e < TOL_POOLED, f"pooled rel err {e}"
+    scale = _logit_scale(ref["pooled"])
+    assert abs(float(out["loss"]) - float(ref["loss"])) <= TOL_LOGIT * scale + 1e-4
+
+
 def test_dropin_loop_and_no_loss(P):
     """the reference's loop shape (train_accel_gpu.py:108-119) runs unchanged; no_loss returns embeddings only."""
     optim = importlib.import_module("mca-paper_amd.optim")
