@@ -371,7 +371,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(
     // these loads (a tile crossing M used to skip them and then waited for too few of its DMA loads: a rare stale-LDS
     // race in the last 64 rows of the out-proj / FF2 / data-gradient GEMMs, caught by the bit-exactness test)
     int m = m0 + row; if (m > M - 1) m = M - 1;
-    return *reinterpret_cast<const f32x4*>(residual + (int64_t)m * ldres + n0 + c0);
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(residual + (int64_t)m * ldres + n0 + c0));          // streamed once
   };
   float* lnstat = reinterpret_cast<float*>(lds2 + 3 * STAGE);          // EPI == 2: [256] mean, [256] rstd
   float ln_val = 0.f;
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(
         }
         v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
         if (bias) { v[0] += bias[n0 + c0]; v[1] += bias[n0 + c0 + 1]; v[2] += bias[n0 + c0 + 2]; v[3] += bias[n0 + c0 + 3]; }
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cv) + (int64_t)m * ldc + n0 + c0) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cv) + (int64_t)m * ldc + n0 + c0));
       }
     }
     return;
@@ -481,10 +481,14 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(
 // [NST stores]; k-step 0 of the next tile waits vmcnt(6 + NST), k-step 1 vmcnt(NST + 6) (the DMA of k-step 2 is issued
 // in between), later steps vmcnt(6).  Tiles that cross M (predicated stores: unknown count) drain with vmcnt(0).
 // ---------------------------------------------------------------------------------------------------------
-#define PS_GLOAD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(ptr) : "memory")
+// The epilogue traffic (C tiles, the h / dh tiles of the GEGLU forms: 0.5-0.9 GB per launch) is streamed with the
+// non-temporal hint so that it does not evict the activation panels and weight tiles the k-loops re-read from L2
+// (GEGLU backward fetched 778 MB against 540 MB of operands; step -0.28 ms in an alternating-process A/B).
+#define PS_NT " nt"
+#define PS_GLOAD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" PS_NT : "=&v"(dst) : "v"(ptr) : "memory")
 // s_nop: a VMEM store of more than 64 bits needs a wait state before a VALU may overwrite its data VGPRs; hipcc
 // inserts it for its own stores but cannot see into inline asm
-#define PS_GSTORE(ptr, val) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(ptr), "v"(val) : "memory")
+#define PS_GSTORE(ptr, val) asm volatile("global_store_dwordx4 %0, %1, off" PS_NT "\n\ts_nop 1" ::"v"(ptr), "v"(val) : "memory")
 #define PS_DSW128(addr, val) asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(val) : "memory")
 #define PS_DSW64(addr, val) asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(val) : "memory")
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
