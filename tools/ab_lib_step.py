@@ -1,5 +1,5 @@
 """Step time of two builds of the library, alternating processes (each process: warm-up + 3 x 5 timed steps).
-usage: ab_lib_step.py <libA.so> <libB.so> [rounds]"""
+usage: ab_lib_step.py <libA.so> <libB.so> [more .so ...] [rounds]"""
 import os, subprocess, sys
 here = os.path.dirname(os.path.abspath(__file__))
 code = r'''
@@ -22,7 +22,7 @@ for _ in range(3):
     torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 5 * 1e3)
 print("%%.2f" %% sorted(ts)[1])
 ''' % here
-libs = sys.argv[1:3]; rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+libs = [a for a in sys.argv[1:] if a.endswith(".so")]; rounds = ([int(a) for a in sys.argv[1:] if a.isdigit()] or [3])[0]
 res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
