@@ -39,7 +39,12 @@ __device__ __forceinline__ int v_off(int r, int c) { return r * 64 + ((c ^ (((r 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int dbg) {
   __shared__ __attribute__((aligned(16))) u16 lds[2 * 2 * AK * DH];   // K,V double-buffered: 32 KiB
   __shared__ __attribute__((aligned(16))) uint8_t kinfo[2][AK];
-  __shared__ uint8_t flags_s[MAX_KTILES];       // this sample's key-tile flags (read from LDS: no vmcnt wait in the loop)
+  __shared__ uint8_t flags_s[MAX_KTILES];       // this sample's key-tile flags
+  // This query tile's list entries whose key tile has at least one valid key in this sample, compacted once: reading the
+  // CSR entry and the flag of the NEXT live tile at the top of every iteration was a chain of a scalar global load and an
+  // LDS read in front of the K / V loads (most of the 1,500 cycles the traced "S" phase took).
+  __shared__ uint32_t live_s[MAX_KTILES];
+  __shared__ int n_live_s;
   u16* Ks = lds;
   u16* Vs = lds + 2 * AK * DH;
 
@@ -124,13 +129,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
     if (tid < 16) *reinterpret_cast<uint32_t*>(&kinfo[buf][tid * 4]) = rinfo;
   };
 
-  // the tile list of this query tile, minus tiles whose keys are all padded in this sample
-  const int it_end = a.q_ptr[qt + 1];
-  int it = a.q_ptr[qt];
-  auto next_live = [&](int i) { while (i < it_end && flags_s[a.q_kt[i] & 0x7fffffffu] == 0) i++; return i; };
-  it = next_live(it);
+  // the tile list of this query tile, minus tiles whose keys are all padded in this sample (wavefront 0 compacts it)
+  if (wave == 0) {
+    const int lb = a.q_ptr[qt], le = a.q_ptr[qt + 1];
+    int n = 0;
+    for (int i0 = lb; i0 < le; i0 += 64) {
+      const int i = i0 + lane;
+      const uint32_t e = i < le ? a.q_kt[i] : 0u;
+      const bool keep = i < le && flags_s[e & 0x7fffffffu] != 0;
+      const unsigned long long m = __ballot(keep);
+      if (keep) live_s[n + __popcll(m & ((1ull << lane) - 1ull))] = e;
+      n += __popcll(m);
+    }
+    if (lane == 0) n_live_s = n;
+  }
+  __syncthreads();
+  const int it_end = n_live_s;
+  int it = 0;
   int buf = 0;
-  if (it < it_end) { gload((int)(a.q_kt[it] & 0x7fffffffu)); swrite(0); }
+  if (it < it_end) { gload((int)(live_s[0] & 0x7fffffffu)); swrite(0); }
   __syncthreads();
 
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
@@ -139,11 +156,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
   const uint64_t rt0 = tracing ? __builtin_amdgcn_s_memrealtime() : 0, cy0 = tracing ? __builtin_readcyclecounter() : 0;
   while (it < it_end) {
     FW_STAMP();
-    const uint32_t ent = a.q_kt[it];
+    const uint32_t ent = live_s[it];
     const int kt = (int)(ent & 0x7fffffffu);
     const bool need_mask = (ent >> 31) == 0 || (flags_s[kt] != 2);
-    const int nit = next_live(it + 1);
-    if (nit < it_end) gload((int)(a.q_kt[nit] & 0x7fffffffu));
+    const int nit = it + 1;
+    if (nit < it_end) gload((int)(live_s[nit] & 0x7fffffffu));
 
     const u16* ks = Ks + buf * AK * DH;
     const u16* vs = Vs + buf * AK * DH;
@@ -198,7 +215,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
           rs += p;
           pb[kb][sp][j] = (short)f2bf(p);
         }
-    FW_STAMP();
     rs += __shfl_xor(rs, 32, WAVE);
     l_run = l_run * alpha + rs;
     m_run = m_new;
@@ -260,6 +276,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
       }
   }
 }
+
 
 extern "C" int mca_attn_fwd(const mca_attn_fwd_args* a, mca_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->o || !a->lse || !a->qmask || !a->keyinfo || !a->ktile_flags || !a->q_ptr ||
