@@ -114,6 +114,29 @@ def test_gemm_tn_acc_group(H, R, members):
 
 
 # ------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,cols", [(4099, 512), (8192, 256), (4097, 1024), (5, 512)])
+def test_layernorm_fwd_trunk_form(H, rows, cols):
+    """gamma-only, bf16 output + statistics: the two-rows-per-wavefront kernel (odd row counts included) against torch and
+    against the general kernel (knob 12)."""
+    g = torch.Generator(device="cuda").manual_seed(31)
+    x = torch.randn(rows, cols, device="cuda", generator=g) * 3 + 1.5
+    gamma = torch.randn(cols, device="cuda", generator=g)
+    outs = []
+    for general in (0, 1):
+        H.lib().mca_debug_set(12, general)
+        yb = torch.full((rows, cols), 7.0, device="cuda", dtype=torch.bfloat16)
+        mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+        H.call("mca_layernorm_fwd", x.data_ptr(), cols, gamma.data_ptr(), None, None, None, 0, None, 0, 0, yb.data_ptr(), cols, cols,
+               mean.data_ptr(), rstd.data_ptr(), rows, cols, 1e-5, H.stream_ptr())
+        torch.cuda.synchronize()
+        outs.append((yb, mean, rstd))
+    H.lib().mca_debug_set(12, 0)
+    ref = torch.nn.functional.layer_norm(x, (cols,), gamma, None, 1e-5)
+    assert rel(outs[0][0].float(), ref) < 4e-3
+    assert rel(outs[0][1], x.mean(1)) < 1e-5 and rel(outs[0][2], (x.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+    assert rel(outs[0][0].float(), outs[1][0].float()) < 1e-3 and rel(outs[0][1], outs[1][1]) < 1e-6 and rel(outs[0][2], outs[1][2]) < 1e-6
+
+
 @pytest.mark.parametrize("rows,cols,affine,masked", [(1000, 512, False, False), (333, 74, True, True), (64, 713, True, True),
                                                       (90, 128, True, True)])
 def test_layernorm_fwd_bwd(H, rows, cols, affine, masked):

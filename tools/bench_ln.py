@@ -5,6 +5,7 @@ H = importlib.import_module("mca-paper_amd.hip"); E = importlib.import_module("m
 T, D = 32 * 2538, 512
 x = torch.randn(T, D, device="cuda"); g = torch.randn(D, device="cuda"); yb = torch.empty(T, D, device="cuda", dtype=torch.bfloat16)
 m = torch.empty(T, device="cuda"); r = torch.empty(T, device="cuda")
+H.lib().mca_debug_set(12, int(os.environ.get("LN_GENERAL", "0")))
 def fwd(): E.FusionEngine.ln_fwd(x, g, T, D, m, r, y_bf16=yb)
 for _ in range(3): fwd()
 torch.cuda.synchronize()
