@@ -268,6 +268,74 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   }
 }
 
+// Trunk form of the backward (gamma only, no mask / period, fp32 dx + bf16 copy, cols % 256 == 0): two rows per wavefront
+// and iteration, as in ln_fwd_trunk_kernel (8 KB of loads in flight per wavefront instead of 4).
+template <int NI>
+__global__ __launch_bounds__(256) void ln_bwd_trunk_kernel(const float* __restrict__ dy, int64_t ldy, const float* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                            const float* __restrict__ rstd_in, float* __restrict__ dx, int64_t lddx,
+                                                            u16* __restrict__ dx_bf16, int64_t ld_bf16, float* __restrict__ dgamma,
+                                                            int64_t rows, int cols) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 gm[NI], dg[NI];
+#pragma unroll
+  for (int i = 0; i < NI; i++) { gm[i] = *reinterpret_cast<const float4*>(gamma + (lane + 64 * i) * 4); dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  const float inv_cols = 1.f / (float)cols;
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 2; r0 < rows; r0 += (int64_t)gridDim.x * 8) {
+    const bool two = r0 + 1 < rows;
+    const int64_t r1 = two ? r0 + 1 : r0;
+    float4 xa[NI], xb[NI], da[NI], db[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int c = (lane + 64 * i) * 4;
+      xa[i] = *reinterpret_cast<const float4*>(x + r0 * ldx + c); da[i] = *reinterpret_cast<const float4*>(dy + r0 * ldy + c);
+      xb[i] = *reinterpret_cast<const float4*>(x + r1 * ldx + c); db[i] = *reinterpret_cast<const float4*>(dy + r1 * ldy + c);
+    }
+    const float ma = mean_in[r0], ra = rstd_in[r0], mb = mean_in[r1], rb = rstd_in[r1];
+    float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+    // xhat overwrites x, g = dy * gamma overwrites dy
+#define LNB_ELEM(X, D, G, DG, M, R, S1, S2, LIVE)  { const float xh_ = ((X) - (M)) * (R); const float g_ = (D) * (G); if (LIVE) (DG) += (D) * xh_; \
+                                                    (S1) += g_; (S2) += g_ * xh_; (X) = xh_; (D) = g_; }
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      LNB_ELEM(xa[i].x, da[i].x, gm[i].x, dg[i].x, ma, ra, s1a, s2a, true)  LNB_ELEM(xa[i].y, da[i].y, gm[i].y, dg[i].y, ma, ra, s1a, s2a, true)
+      LNB_ELEM(xa[i].z, da[i].z, gm[i].z, dg[i].z, ma, ra, s1a, s2a, true)  LNB_ELEM(xa[i].w, da[i].w, gm[i].w, dg[i].w, ma, ra, s1a, s2a, true)
+      LNB_ELEM(xb[i].x, db[i].x, gm[i].x, dg[i].x, mb, rb, s1b, s2b, two)   LNB_ELEM(xb[i].y, db[i].y, gm[i].y, dg[i].y, mb, rb, s1b, s2b, two)
+      LNB_ELEM(xb[i].z, db[i].z, gm[i].z, dg[i].z, mb, rb, s1b, s2b, two)   LNB_ELEM(xb[i].w, db[i].w, gm[i].w, dg[i].w, mb, rb, s1b, s2b, two)
+    }
+#undef LNB_ELEM
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s1a += __shfl_xor(s1a, o, WAVE); s2a += __shfl_xor(s2a, o, WAVE); s1b += __shfl_xor(s1b, o, WAVE); s2b += __shfl_xor(s2b, o, WAVE);
+    }
+    s1a *= inv_cols; s2a *= inv_cols; s1b *= inv_cols; s2b *= inv_cols;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int c = (lane + 64 * i) * 4;
+      float4 o;
+      o.x = ra * (da[i].x - s1a - xa[i].x * s2a); o.y = ra * (da[i].y - s1a - xa[i].y * s2a);
+      o.z = ra * (da[i].z - s1a - xa[i].z * s2a); o.w = ra * (da[i].w - s1a - xa[i].w * s2a);
+      if (dx) *reinterpret_cast<float4*>(dx + r0 * lddx + c) = o;
+      if (dx_bf16) { uint2 pk; pk.x = pack2bf(o.x, o.y); pk.y = pack2bf(o.z, o.w); *reinterpret_cast<uint2*>(dx_bf16 + r0 * ld_bf16 + c) = pk; }
+      if (two) {
+        o.x = rb * (db[i].x - s1b - xb[i].x * s2b); o.y = rb * (db[i].y - s1b - xb[i].y * s2b);
+        o.z = rb * (db[i].z - s1b - xb[i].z * s2b); o.w = rb * (db[i].w - s1b - xb[i].w * s2b);
+        if (dx) *reinterpret_cast<float4*>(dx + r1 * lddx + c) = o;
+        if (dx_bf16) { uint2 pk; pk.x = pack2bf(o.x, o.y); pk.y = pack2bf(o.z, o.w); *reinterpret_cast<uint2*>(dx_bf16 + r1 * ld_bf16 + c) = pk; }
+      }
+    }
+  }
+  // block reduction of the dgamma partials through LDS, then one atomic per column
+  __shared__ float red[4][1024];
+#pragma unroll
+  for (int i = 0; i < NI; i++) *reinterpret_cast<float4*>(&red[wave][(lane + 64 * i) * 4]) = dg[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    if (t != 0.f) atomicAdd(dgamma + c, t);
+  }
+}
+
 extern "C" int mca_layernorm_bwd(const float* dy, int64_t ldy, int64_t y_bstride, int64_t period,
                                  const float* x, int64_t ldx, const float* gamma,
                                  const float* mean, const float* rstd, const uint8_t* rowmask,
@@ -278,6 +346,15 @@ extern "C" int mca_layernorm_bwd(const float* dy, int64_t ldy, int64_t y_bstride
   const bool vec = (cols % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (y_bstride % 4 == 0) &&
                    (!dx || lddx % 4 == 0) && (!dx_bf16 || ld_bf16 % 4 == 0) &&
                    ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && (!dx || (uintptr_t)dx % 16 == 0);
+  if (vec && !rowmask && period <= 0 && !dbeta && dgamma && (cols == 256 || cols == 512 || cols == 1024) &&
+      (uintptr_t)gamma % 16 == 0 && mca_knobs[12] != 1) {          // knob 12 = 1: general kernel (A/B)
+    int64_t nb = (rows + 7) / 8;
+    if (nb > 1024) nb = 1024;
+    if (cols == 256) hipLaunchKernelGGL(ln_bwd_trunk_kernel<1>, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), dy, ldy, x, ldx, gamma, mean, rstd, dx, lddx, dx_bf16, ld_bf16, dgamma, rows, cols);
+    else if (cols == 512) hipLaunchKernelGGL(ln_bwd_trunk_kernel<2>, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), dy, ldy, x, ldx, gamma, mean, rstd, dx, lddx, dx_bf16, ld_bf16, dgamma, rows, cols);
+    else hipLaunchKernelGGL(ln_bwd_trunk_kernel<4>, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), dy, ldy, x, ldx, gamma, mean, rstd, dx, lddx, dx_bf16, ld_bf16, dgamma, rows, cols);
+    return launch_status();
+  }
   int64_t blocks = (rows + 3) / 4;
   if (blocks > 1024) blocks = 1024;          // bounds the number of atomics on dgamma/dbeta
   if (vec)

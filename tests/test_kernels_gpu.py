@@ -138,7 +138,8 @@ def test_layernorm_fwd_trunk_form(H, rows, cols):
 
 
 @pytest.mark.parametrize("rows,cols,affine,masked", [(1000, 512, False, False), (333, 74, True, True), (64, 713, True, True),
-                                                      (90, 128, True, True)])
+                                                      (90, 128, True, True), (4099, 512, False, False), (777, 256, False, False),
+                                                      (33, 1024, False, False)])
 def test_layernorm_fwd_bwd(H, rows, cols, affine, masked):
     g = torch.Generator(device="cuda").manual_seed(3)
     period = 30 if masked else 0
