@@ -86,6 +86,7 @@ class FusionEngine:
         # weight-gradient GEMMs on a side stream, concurrent with the backward chain
         self.overlap_wgrad = os.environ.get("MCA_OVERLAP_WGRAD", "1") != "0"
         self.group_wgrad = os.environ.get("MCA_GROUP_WGRAD", "1") != "0"      # one weight-gradient launch per layer
+        self.zero_dq_once = True                    # all dQ accumulators zeroed by one side-stream memset per step
         # micro-batch interleave (opt-in, MCA_MICRO_BATCHES=2): batches of at least micro_batch_min samples run as two
         # halves on two streams.  Measured on CMU b=32: 26.3 vs 26.7 ms/step when the host runs ahead, no gain when it
         # does not (tools/ab_step.py 102 1 2, tools/diag_switch.py) - kept off by default.
@@ -260,7 +261,12 @@ class FusionEngine:
         ws["present_native"] = torch.zeros(b, dtype=torch.int32, device=dev)
         # backward
         ws["dxa"], ws["dxb"], ws["dx_b"] = f32(T, D), f32(T, D), bf(T, D)
-        ws["dg"], ws["do"], ws["dq32"] = bf(T, Ip), bf(T, D), f32(T, D)
+        ws["dg"], ws["do"] = bf(T, Ip), bf(T, D)
+        # fp32 dQ accumulators, one per layer: all of them are zeroed by ONE memset on the side stream at the start of the
+        # backward (beside the pooling backward) instead of a 166 MB memset in front of every layer's attention backward
+        ws["dq32_all"] = f32(max(self.L, 1), T, D)
+        ws["dq32"] = ws["dq32_all"][0]
+        ws["dq32_zero_event"] = torch.cuda.Event()
         ws["dpool_b"], ws["dop"], ws["dqp32"], ws["dqp_sum"], ws["dqp_b"] = bf(b * R, D), bf(b * R, D), f32(b * R, D), f32(R, D), bf(R, D)
         ws["dkvp"], ws["drt"] = bf(T, 2 * D), f32(R, D)
         ws["enc"] = {}
@@ -615,6 +621,8 @@ class FusionEngine:
         def on_side(fn):
             side(fn, slot[0], ws); slot[0] += 1
 
+        if self.L and self.zero_dq_once:          # all dQ accumulators zeroed beside the pooling backward (inline when nothing runs on the side stream)
+            on_side(lambda: (ws["dq32_all"].zero_(), ws["dq32_zero_event"].record(torch.cuda.current_stream())))
         # pooled = op @ Wo^T + return_tokens
         call("mca_reduce_rows", ptr(dpool), D, R * D, R, ptr(G(m.return_tokens)), D, b * R, D, stream_ptr())
         call("mca_f32_to_bf16", ptr(dpool), D, ptr(ws["dpool_b"]), D, b * R, D, 1.0, stream_ptr())
@@ -663,10 +671,14 @@ class FusionEngine:
             # x1 = o @ Wo^T + xn
             on_side(lambda dx1=dx1, a=a, ly=ly: tn(dx1, a["o"], G(ly.attn.to_out.weight), T, D, D))
             self.gemm_nt(dx1, w["oT"], ws["do"], T, D, D)
-            ws["dq32"].zero_()
+            dq32 = ws["dq32_all"][i]
+            if not self.zero_dq_once:
+                dq32.zero_()
+            elif bi == 0:
+                torch.cuda.current_stream().wait_event(ws["dq32_zero_event"])
             self._attn_bwd(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], ws["do"], a["lse"],
-                           ws["delta"], ws["dq32"], N * D, dqkv, D, 2 * D, 3 * D, self.qmask_attn, self.sched_attn_b, ws, b, N)
-            call("mca_f32_to_bf16", ptr(ws["dq32"]), D, ptr(dqkv), 3 * D, T, D, 1.0, stream_ptr())
+                           ws["delta"], dq32, N * D, dqkv, D, 2 * D, 3 * D, self.qmask_attn, self.sched_attn_b, ws, b, N)
+            call("mca_f32_to_bf16", ptr(dq32), D, ptr(dqkv), 3 * D, T, D, 1.0, stream_ptr())
             # to_q.weight and to_kv.weight are adjacent in the flat gradient buffer: one (3D, D) weight-gradient GEMM
             gq = G(ly.attn.to_q.weight)
             assert G(ly.attn.to_kv.weight).data_ptr() == gq.data_ptr() + D * D * 4

@@ -17,7 +17,7 @@ res = {va: [], vb: []}
 for rnd in range(4):
     for v in (va, vb):
         if knob == 102: model.engine.micro_batches = v
-        elif knob >= 100: setattr(model.engine, {100: "fuse_geglu_bwd", 101: "overlap_wgrad", 103: "fuse_ln_residual", 104: "group_wgrad"}[knob], bool(v))
+        elif knob >= 100: setattr(model.engine, {100: "fuse_geglu_bwd", 101: "overlap_wgrad", 103: "fuse_ln_residual", 104: "group_wgrad", 105: "zero_dq_once"}[knob], bool(v))
         else: H.lib().mca_debug_set(knob, v)
         step(); torch.cuda.synchronize()
         t0 = time.perf_counter()
