@@ -353,16 +353,12 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restric
   int q_end = q_begin + PREP_ROWS; if (q_end > nq) q_end = nq;
   for (int c0 = 0; c0 < cols; c0 += 512) {
     const int h0 = c0 / DH;
-    {
-      const int hh = tid / PREP_ROWS, r = tid % PREP_ROWS;          // 8 heads x 32 rows = 256 threads
-      if (h0 + hh < heads && q_begin + r < q_end) lse_s[hh][r] = lse[((int64_t)b * heads + h0 + hh) * nq + q_begin + r];
-    }
-    __syncthreads();
     const int c = c0 + lane * 8;
     const int hl = lane >> 3;          // head of this lane inside the 512-column slab
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool any = false;
-    // all PREP_ROWS / 4 rows of this wavefront are requested before any is used (a row at a time the loop is latency-bound)
+    // all PREP_ROWS / 4 rows of this wavefront are requested before any is used (a row at a time the loop is latency-bound),
+    // and before the lse values the block waits for at its first barrier
     bf16x8 ovs[PREP_ROWS / 4], dvs[PREP_ROWS / 4];
 #pragma unroll
     for (int k = 0; k < PREP_ROWS / 4; k++) {
@@ -371,6 +367,11 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restric
       ovs[k] = *reinterpret_cast<const bf16x8*>(o + (int64_t)b * bstride + (int64_t)q * ld + cc);
       dvs[k] = *reinterpret_cast<const bf16x8*>(d_o + (int64_t)b * bstride + (int64_t)q * ld + cc);
     }
+    {
+      const int hh = tid / PREP_ROWS, r = tid % PREP_ROWS;          // 8 heads x 32 rows = 256 threads
+      if (h0 + hh < heads && q_begin + r < q_end) lse_s[hh][r] = lse[((int64_t)b * heads + h0 + hh) * nq + q_begin + r];
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < PREP_ROWS / 4; k++) {
       const int q = q_begin + wave + 4 * k;
