@@ -15,108 +15,78 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
     u16* __restrict__ y_bf16, int64_t ld_bf16, int cols_pad,
     float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t rows, int cols, float eps) {
   constexpr int NI = 16 / VEC;             // up to 1024 columns
-  constexpr int RPW = 2;                   // rows per wavefront and iteration: both rows' loads are in flight together
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += (int64_t)gridDim.x * 4 * RPW) {
-    bool live[RPW], masked[RPW];
-    float v[RPW][NI][VEC];
-    float s[RPW];
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const bool masked = rowmask && rowmask[row];
+    const float* xr = x + row * ldx;
+    float v[NI][VEC];
+    float s = 0.f;
 #pragma unroll
-    for (int rr = 0; rr < RPW; rr++) {
-      const int64_t row = row0 + rr;
-      live[rr] = row < rows;
-      masked[rr] = !live[rr] || (rowmask && rowmask[row]);
-      const float* xr = x + (live[rr] ? row : row0) * ldx;
-      s[rr] = 0.f;
+    for (int i = 0; i < NI; i++) {
+      const int c = (lane + 64 * i) * VEC;
+      if (c < cols) {
+        if (VEC == 4) {
+          float4 t = masked ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(xr + c);
+          v[i][0] = t.x; v[i][1 % VEC] = t.y; v[i][2 % VEC] = t.z; v[i][3 % VEC] = t.w;
+        } else {
+          v[i][0] = masked ? 0.f : xr[c];
+        }
 #pragma unroll
-      for (int i = 0; i < NI; i++) {
-        const int c = (lane + 64 * i) * VEC;
+        for (int j = 0; j < VEC; j++) s += v[i][j];
+      } else {
 #pragma unroll
-        for (int j = 0; j < VEC; j++) v[rr][i][j] = 0.f;
-        if (c < cols && !masked[rr]) {
+        for (int j = 0; j < VEC; j++) v[i][j] = 0.f;
+      }
+    }
+    const float mean = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int c = (lane + 64 * i) * VEC;
+      if (c < cols) {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) { const float d = v[i][j] - mean; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = masked ? 0.f : mean;
+      if (rstd_out) rstd_out[row] = masked ? 0.f : rstd;
+    }
+    const int64_t prow = period > 0 ? row % period : row;
+    float* yr = y ? (period > 0 ? y + (row / period) * y_bstride + prow * ldy : y + row * ldy) : nullptr;
+    const float* ar = add ? add + prow * (int64_t)cols : nullptr;
+    u16* br = y_bf16 ? y_bf16 + row * ld_bf16 : nullptr;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int c = (lane + 64 * i) * VEC;
+      if (c < cols) {
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          float t = (v[i][j] - mean) * rstd * gamma[c + j];
+          if (beta) t += beta[c + j];
+          o[j] = masked ? 0.f : t;
+        }
+        if (br) {
           if (VEC == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(xr + c);
-            v[rr][i][0] = t.x; v[rr][i][1 % VEC] = t.y; v[rr][i][2 % VEC] = t.z; v[rr][i][3 % VEC] = t.w;
+            uint2 pk; pk.x = pack2bf(o[0], o[1 % VEC]); pk.y = pack2bf(o[2 % VEC], o[3 % VEC]);
+            *reinterpret_cast<uint2*>(br + c) = pk;
           } else {
-            v[rr][i][0] = xr[c];
+            br[c] = f2bf(o[0]);
           }
+        }
+        if (yr) {
+          if (ar) {
+#pragma unroll
+            for (int j = 0; j < VEC; j++) o[j] += ar[c + j];
+          }
+          if (VEC == 4) *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
+          else yr[c] = o[0];
         }
       }
     }
-    float mean[RPW], rstd[RPW];
-#pragma unroll
-    for (int rr = 0; rr < RPW; rr++) {
-#pragma unroll
-      for (int i = 0; i < NI; i++)
-#pragma unroll
-        for (int j = 0; j < VEC; j++) s[rr] += v[rr][i][j];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-      for (int rr = 0; rr < RPW; rr++) s[rr] += __shfl_xor(s[rr], o, WAVE);
-    float q[RPW];
-#pragma unroll
-    for (int rr = 0; rr < RPW; rr++) {
-      mean[rr] = s[rr] / (float)cols;
-      q[rr] = 0.f;
-#pragma unroll
-      for (int i = 0; i < NI; i++) {
-        const int c = (lane + 64 * i) * VEC;
-        if (c < cols) {
-#pragma unroll
-          for (int j = 0; j < VEC; j++) { const float d = v[rr][i][j] - mean[rr]; q[rr] += d * d; }
-        }
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-      for (int rr = 0; rr < RPW; rr++) q[rr] += __shfl_xor(q[rr], o, WAVE);
-#pragma unroll
-    for (int rr = 0; rr < RPW; rr++) {
-      if (!live[rr]) continue;
-      const int64_t row = row0 + rr;
-      rstd[rr] = rsqrtf(q[rr] / (float)cols + eps);
-      if (lane == 0) {
-        if (mean_out) mean_out[row] = masked[rr] ? 0.f : mean[rr];
-        if (rstd_out) rstd_out[row] = masked[rr] ? 0.f : rstd[rr];
-      }
-      const int64_t prow = period > 0 ? row % period : row;
-      float* yr = y ? (period > 0 ? y + (row / period) * y_bstride + prow * ldy : y + row * ldy) : nullptr;
-      const float* ar = add ? add + prow * (int64_t)cols : nullptr;
-      u16* br = y_bf16 ? y_bf16 + row * ld_bf16 : nullptr;
-#pragma unroll
-      for (int i = 0; i < NI; i++) {
-        const int c = (lane + 64 * i) * VEC;
-        if (c < cols) {
-          float o[VEC];
-#pragma unroll
-          for (int j = 0; j < VEC; j++) {
-            float t = (v[rr][i][j] - mean[rr]) * rstd[rr] * gamma[c + j];
-            if (beta) t += beta[c + j];
-            o[j] = masked[rr] ? 0.f : t;
-          }
-          if (br) {
-            if (VEC == 4) {
-              uint2 pk; pk.x = pack2bf(o[0], o[1 % VEC]); pk.y = pack2bf(o[2 % VEC], o[3 % VEC]);
-              *reinterpret_cast<uint2*>(br + c) = pk;
-            } else {
-              br[c] = f2bf(o[0]);
-            }
-          }
-          if (yr) {
-            if (ar) {
-#pragma unroll
-              for (int j = 0; j < VEC; j++) o[j] += ar[c + j];
-            }
-            if (VEC == 4) *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
-            else yr[c] = o[0];
-          }
-        }
-      }
-      if (br) for (int c = cols + lane; c < cols_pad; c += 64) br[c] = 0;
-    }
+    if (br) for (int c = cols + lane; c < cols_pad; c += 64) br[c] = 0;
   }
 }
 
@@ -193,7 +163,7 @@ extern "C" int mca_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
     else hipLaunchKernelGGL(ln_fwd_trunk_kernel<4>, dim3(nb), dim3(256), 0, as_stream(stream), x, ldx, gamma, y_bf16, ld_bf16, mean, rstd, rows, cols, eps);
     return launch_status();
   }
-  int64_t blocks = (rows + 7) / 8;          // 4 wavefronts x 2 rows per block and iteration
+  int64_t blocks = (rows + 3) / 4;
   if (blocks > 8192) blocks = 8192;
   if (vec)
     hipLaunchKernelGGL(ln_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, ldx, gamma, beta,
@@ -223,84 +193,56 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   for (int i = 0; i < NI; i++)
 #pragma unroll
     for (int j = 0; j < VEC; j++) { dg[i][j] = 0.f; db[i][j] = 0.f; }
-  constexpr int RPW = 2;          // rows per wavefront and iteration: both rows' loads are in flight together
-  for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += (int64_t)gridDim.x * 4 * RPW) {
-    bool live[RPW], masked[RPW];
-    float xh[RPW][NI][VEC], g[RPW][NI][VEC];
-    float mean[RPW], rstd[RPW], s1[RPW], s2[RPW];
-    // loads of both rows first (x and dy rows into xh / g), arithmetic afterwards
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const bool masked = rowmask && rowmask[row];
+    const float* xr = x + row * ldx;
+    const float* dyr = period > 0 ? dy + (row / period) * y_bstride + (row % period) * ldy : dy + row * ldy;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float xh[NI][VEC], g[NI][VEC];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int rr = 0; rr < RPW; rr++) {
-      const int64_t row = row0 + rr;
-      live[rr] = row < rows;
-      const int64_t r = live[rr] ? row : row0;
-      masked[rr] = !live[rr] || (rowmask && rowmask[r]);
-      const float* xr = x + r * ldx;
-      const float* dyr = period > 0 ? dy + (r / period) * y_bstride + (r % period) * ldy : dy + r * ldy;
-      mean[rr] = mean_in[r]; rstd[rr] = rstd_in[r];
+    for (int i = 0; i < NI; i++) {
+      const int c = (lane + 64 * i) * VEC;
 #pragma unroll
-      for (int i = 0; i < NI; i++) {
-        const int c = (lane + 64 * i) * VEC;
+      for (int j = 0; j < VEC; j++) { xh[i][j] = 0.f; g[i][j] = 0.f; }
+      if (c < cols && !masked) {
+        float xv[VEC], dv[VEC];
+        if (VEC == 4) {
+          float4 a = *reinterpret_cast<const float4*>(xr + c), d = *reinterpret_cast<const float4*>(dyr + c);
+          xv[0] = a.x; xv[1 % VEC] = a.y; xv[2 % VEC] = a.z; xv[3 % VEC] = a.w;
+          dv[0] = d.x; dv[1 % VEC] = d.y; dv[2 % VEC] = d.z; dv[3 % VEC] = d.w;
+        } else { xv[0] = xr[c]; dv[0] = dyr[c]; }
 #pragma unroll
-        for (int j = 0; j < VEC; j++) { xh[rr][i][j] = 0.f; g[rr][i][j] = 0.f; }
-        if (c < cols && !masked[rr]) {
+        for (int j = 0; j < VEC; j++) {
+          xh[i][j] = (xv[j] - mean) * rstd;
+          g[i][j] = dv[j] * gamma[c + j];
+          dg[i][j] += dv[j] * xh[i][j];
+          db[i][j] += dv[j];
+          s1 += g[i][j];
+          s2 += g[i][j] * xh[i][j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)cols;
+    s2 = wave_sum(s2) / (float)cols;
+    float* dxr = dx ? dx + row * lddx : nullptr;
+    u16* br = dx_bf16 ? dx_bf16 + row * ld_bf16 : nullptr;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int c = (lane + 64 * i) * VEC;
+      if (c < cols) {
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; j++) o[j] = masked ? 0.f : rstd * (g[i][j] - s1 - xh[i][j] * s2);
+        if (dxr) {
+          if (VEC == 4) *reinterpret_cast<float4*>(dxr + c) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
+          else dxr[c] = o[0];
+        }
+        if (br) {
           if (VEC == 4) {
-            const float4 a = *reinterpret_cast<const float4*>(xr + c), d = *reinterpret_cast<const float4*>(dyr + c);
-            xh[rr][i][0] = a.x; xh[rr][i][1 % VEC] = a.y; xh[rr][i][2 % VEC] = a.z; xh[rr][i][3 % VEC] = a.w;
-            g[rr][i][0] = d.x; g[rr][i][1 % VEC] = d.y; g[rr][i][2 % VEC] = d.z; g[rr][i][3 % VEC] = d.w;
-          } else { xh[rr][i][0] = xr[c]; g[rr][i][0] = dyr[c]; }
-        }
-      }
-    }
-#pragma unroll
-    for (int rr = 0; rr < RPW; rr++) {
-      s1[rr] = 0.f; s2[rr] = 0.f;
-#pragma unroll
-      for (int i = 0; i < NI; i++) {
-        const int c = (lane + 64 * i) * VEC;
-        if (c < cols && !masked[rr]) {
-#pragma unroll
-          for (int j = 0; j < VEC; j++) {
-            const float dvj = g[rr][i][j];
-            const float xhj = (xh[rr][i][j] - mean[rr]) * rstd[rr];
-            const float gj = dvj * gamma[c + j];
-            xh[rr][i][j] = xhj; g[rr][i][j] = gj;
-            dg[i][j] += dvj * xhj;
-            db[i][j] += dvj;
-            s1[rr] += gj;
-            s2[rr] += gj * xhj;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-      for (int rr = 0; rr < RPW; rr++) { s1[rr] += __shfl_xor(s1[rr], o, WAVE); s2[rr] += __shfl_xor(s2[rr], o, WAVE); }
-#pragma unroll
-    for (int rr = 0; rr < RPW; rr++) {
-      if (!live[rr]) continue;
-      const int64_t row = row0 + rr;
-      const float m1 = s1[rr] / (float)cols, m2 = s2[rr] / (float)cols;
-      float* dxr = dx ? dx + row * lddx : nullptr;
-      u16* br = dx_bf16 ? dx_bf16 + row * ld_bf16 : nullptr;
-#pragma unroll
-      for (int i = 0; i < NI; i++) {
-        const int c = (lane + 64 * i) * VEC;
-        if (c < cols) {
-          float o[VEC];
-#pragma unroll
-          for (int j = 0; j < VEC; j++) o[j] = masked[rr] ? 0.f : rstd[rr] * (g[rr][i][j] - m1 - xh[rr][i][j] * m2);
-          if (dxr) {
-            if (VEC == 4) *reinterpret_cast<float4*>(dxr + c) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
-            else dxr[c] = o[0];
-          }
-          if (br) {
-            if (VEC == 4) {
-              uint2 pk; pk.x = pack2bf(o[0], o[1 % VEC]); pk.y = pack2bf(o[2 % VEC], o[3 % VEC]);
-              *reinterpret_cast<uint2*>(br + c) = pk;
-            } else br[c] = f2bf(o[0]);
-          }
+            uint2 pk; pk.x = pack2bf(o[0], o[1 % VEC]); pk.y = pack2bf(o[2 % VEC], o[3 % VEC]);
+            *reinterpret_cast<uint2*>(br + c) = pk;
+          } else br[c] = f2bf(o[0]);
         }
       }
     }
@@ -413,7 +355,7 @@ extern "C" int mca_layernorm_bwd(const float* dy, int64_t ldy, int64_t y_bstride
     else hipLaunchKernelGGL(ln_bwd_trunk_kernel<4>, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), dy, ldy, x, ldx, gamma, mean, rstd, dx, lddx, dx_bf16, ld_bf16, dgamma, rows, cols);
     return launch_status();
   }
-  int64_t blocks = (rows + 7) / 8;          // 4 wavefronts x 2 rows per block and iteration
+  int64_t blocks = (rows + 3) / 4;
   if (blocks > 1024) blocks = 1024;          // bounds the number of atomics on dgamma/dbeta
   if (vec)
     hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dy, ldy, y_bstride,
