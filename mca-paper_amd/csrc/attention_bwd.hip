@@ -60,6 +60,12 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
   const int mykey = key0 + wave * 32 + l31;
   int keyc = mykey; if (keyc > a.nk - 1) keyc = a.nk - 1;
   const float c2 = a.scale * 1.4426950408889634f, inv_c2 = 1.f / c2;
+  // One workgroup per CU: nothing hides this prologue, so its dependent loads are kept few: the list bounds and the first
+  // entry (scalar chain k_order -> k_ptr -> k_qt) start first; the first Q / dO tile, the K / V fragments and the K image are
+  // then all in flight together, and the LDS writes and the barrier come after all of them.
+  const int it_begin = a.k_ptr[kbi], it_end = a.k_ptr[kbi + 1];
+  const int n_it = it_end - it_begin;          // <= n_qtiles <= MAX_QTILES (checked by the host)
+  const int first_qt = n_it > 0 ? (int)(a.k_qt[it_begin] & 0x7fffffffu) : 0;
 
   const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
   const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
@@ -74,12 +80,6 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
   const bool key_ok = kinfo != 31u;
   const uint32_t keybit = key_ok ? (1u << kinfo) : 0u;          // bit of this lane's key group; 0 = padded key
   const bool wave_keys_ok = __all(key_ok);                      // wave-uniform
-  // K image for the dQ product
-  for (int id = tid; id < BKEYS * 8; id += 512) {
-    const int r = id >> 3, c = id & 7;
-    int kk = key0 + r; if (kk > a.nk - 1) kk = a.nk - 1;
-    *reinterpret_cast<bf16x8*>(Kimg + kt_off(r, c)) = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)kk * a.kv_ld + c * 8);
-  }
 
   f32x16 dk[2], dv[2];
 #pragma unroll
@@ -123,11 +123,25 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
     }
   };
 
-  const int it_begin = a.k_ptr[kbi], it_end = a.k_ptr[kbi + 1];
-  const int n_it = it_end - it_begin;          // <= n_qtiles <= MAX_QTILES (checked by the host)
-  for (int i = tid; i < n_it; i += 512) qlist[i] = a.k_qt[it_begin + i];
+  if (n_it > 0) gload(first_qt);
+  // K image for the dQ product: the four chunks of a thread are loaded before any is written
+  {
+    bf16x8 kimg_r[BKEYS * 8 / 512];
+#pragma unroll
+    for (int u = 0; u < BKEYS * 8 / 512; u++) {
+      const int id = tid + 512 * u, r = id >> 3, c = id & 7;
+      int kk = key0 + r; if (kk > a.nk - 1) kk = a.nk - 1;
+      kimg_r[u] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)kk * a.kv_ld + c * 8);
+    }
+    for (int i = tid; i < n_it; i += 512) qlist[i] = a.k_qt[it_begin + i];
+#pragma unroll
+    for (int u = 0; u < BKEYS * 8 / 512; u++) {
+      const int id = tid + 512 * u;
+      *reinterpret_cast<bf16x8*>(Kimg + kt_off(id >> 3, id & 7)) = kimg_r[u];
+    }
+  }
   int buf = 0;
-  if (n_it > 0) { gload((int)(a.k_qt[it_begin] & 0x7fffffffu)); swrite(0); }
+  if (n_it > 0) swrite(0);
   __syncthreads();
   const unsigned lds_qlist = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)qlist;
   auto entry_issue = [&](int i, uint32_t& v) {          // uniform LDS read, result valid after the next lgkmcnt(0)

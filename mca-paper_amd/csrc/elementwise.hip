@@ -103,9 +103,11 @@ __global__ __launch_bounds__(256) void ln_fwd_trunk_kernel(const float* __restri
   const bool two = r0 + 1 < rows;
   const float* xa = x + r0 * ldx;
   const float* xb = x + (two ? r0 + 1 : r0) * ldx;
-  float4 va[NI], vb[NI];
+  float4 va[NI], vb[NI], gv[NI];
 #pragma unroll
   for (int i = 0; i < NI; i++) { va[i] = *reinterpret_cast<const float4*>(xa + (lane + 64 * i) * 4); vb[i] = *reinterpret_cast<const float4*>(xb + (lane + 64 * i) * 4); }
+#pragma unroll
+  for (int i = 0; i < NI; i++) gv[i] = *reinterpret_cast<const float4*>(gamma + (lane + 64 * i) * 4);          // with the rows, not after the reductions
   float sa = 0.f, sb = 0.f;
 #pragma unroll
   for (int i = 0; i < NI; i++) {          // same summation order as ln_fwd_kernel
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void ln_fwd_trunk_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < NI; i++) {
     const int c = (lane + 64 * i) * 4;
-    const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 g = gv[i];
     uint2 pk;
     pk.x = pack2bf((va[i].x - ma) * ra * g.x, (va[i].y - ma) * ra * g.y); pk.y = pack2bf((va[i].z - ma) * ra * g.z, (va[i].w - ma) * ra * g.w);
     *reinterpret_cast<uint2*>(y_bf16 + r0 * ld_bf16 + c) = pk;
