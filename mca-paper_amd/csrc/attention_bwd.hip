@@ -19,6 +19,7 @@
 #define BKEYS 256
 #define BQ 64        // query rows per step: two 32-row sub-tiles between barriers
 #define DH 64
+#define MAX_QTILES 2048
 
 // [32 rows][64 d] image used for BOTH row reads and transposed reads (Q and dO tiles)
 __device__ __forceinline__ int qd_off(int r, int c) {
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
   // This key block's query-tile list, copied once and read with inline-asm LDS reads: a global load of the next entry at
   // the top of every step carries s_waitcnt vmcnt(0), i.e. waits for the dQ atomics the previous step has just issued.
   uint32_t* qlist = reinterpret_cast<uint32_t*>(rowc + 2 * 192);   // [MAX_QTILES]
+  float* dvm_s = reinterpret_cast<float*>(qlist + MAX_QTILES);     // [64] dvmean of this (sample, head): read in the epilogue
 
   // XCD-aware order: the key blocks of one (sample, head) sweep the same Q / dO tiles: one XCD takes them all
   const int lin0 = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
       kimg_r[u] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)kk * a.kv_ld + c * 8);
     }
     for (int i = tid; i < n_it; i += 512) qlist[i] = a.k_qt[it_begin + i];
+    if (tid < DH) dvm_s[tid] = a.dvmean[(int64_t)b * a.heads * DH + h * DH + tid];          // (the epilogue would wait a memory round trip for it)
 #pragma unroll
     for (int u = 0; u < BKEYS * 8 / 512; u++) {
       const int id = tid + 512 * u;
@@ -304,7 +307,6 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
   if (mykey < a.nk) {
     u16* dkp = a.dk + (int64_t)b * a.dkv_bstride + (int64_t)mykey * a.dkv_ld + h * DH;
     u16* dvp = a.dv + (int64_t)b * a.dkv_bstride + (int64_t)mykey * a.dkv_ld + h * DH;
-    const float* dvm = a.dvmean + (int64_t)b * a.heads * DH + h * DH;
 #pragma unroll
     for (int n = 0; n < 2; n++)
 #pragma unroll
@@ -314,15 +316,15 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
         pk.x = pack2bf(dk[n][4 * g] * a.scale, dk[n][4 * g + 1] * a.scale);
         pk.y = pack2bf(dk[n][4 * g + 2] * a.scale, dk[n][4 * g + 3] * a.scale);
         *reinterpret_cast<uint2*>(dkp + d) = pk;
-        pk.x = pack2bf(dv[n][4 * g] + dvm[d], dv[n][4 * g + 1] + dvm[d + 1]);
-        pk.y = pack2bf(dv[n][4 * g + 2] + dvm[d + 2], dv[n][4 * g + 3] + dvm[d + 3]);
+        const f32x4 dvm = *reinterpret_cast<const f32x4*>(dvm_s + d);
+        pk.x = pack2bf(dv[n][4 * g] + dvm[0], dv[n][4 * g + 1] + dvm[1]);
+        pk.y = pack2bf(dv[n][4 * g + 2] + dvm[2], dv[n][4 * g + 3] + dvm[3]);
         *reinterpret_cast<uint2*>(dvp + d) = pk;
       }
   }
 }
 
-#define MAX_QTILES 2048
-#define BWD_LDS_BYTES ((2 * BQ * DH * 2 + 2 * BKEYS * BQ + BKEYS * DH) * 2 + 2 * 192 * 4 + MAX_QTILES * 4)
+#define BWD_LDS_BYTES ((2 * BQ * DH * 2 + 2 * BKEYS * BQ + BKEYS * DH) * 2 + 2 * 192 * 4 + MAX_QTILES * 4 + DH * 4)
 
 extern "C" int mca_attn_bwd(const mca_attn_bwd_args* a, mca_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->d_o || !a->lse || !a->delta || !a->dvmean || !a->dq || !a->dk || !a->dv ||
