@@ -34,7 +34,7 @@ __device__ __forceinline__ int ds_off(int key, int c) { return key * 32 + ((c ^ 
 // timeline probe (knob 6 bit 3): wave 0 of one workgroup writes s_memtime stamps, read back by tools/trace_attn_bwd.py
 MCA_TRACE_BUFFER(attn_bwd)
 #ifdef MCA_TRACE_BUILD      // the stamps pin the instruction order, so the production build carries none (build.py: trace=True)
-#define AB_STAMP() do { if (tracing && ti < 1024) mca_trace_attn_bwd[ti++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define AB_STAMP() do { if (tracing && ti < 1000) mca_trace_attn_bwd[ti++] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define AB_STAMP() do { } while (0)
 #endif
@@ -52,6 +52,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
   float* dvm_s = reinterpret_cast<float*>(qlist + MAX_QTILES);     // [64] dvmean of this (sample, head): read in the epilogue
 
   // XCD-aware order: the key blocks of one (sample, head) sweep the same Q / dO tiles: one XCD takes them all
+#ifdef MCA_TRACE_BUILD
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
   const int lin0 = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
   const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y * gridDim.z));          // knob 9 = 16: launch order (A/B)
   const int kbi = a.k_order[lin % (int)gridDim.x];
@@ -126,6 +129,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
   };
 
   if (n_it > 0) gload(first_qt);
+#ifdef MCA_TRACE_BUILD
+  const unsigned long long t_chain = __builtin_amdgcn_s_memtime();          // the scalar chain has delivered first_qt
+#endif
   // K image for the dQ product: the four chunks of a thread are loaded before any is written
   {
     bf16x8 kimg_r[BKEYS * 8 / 512];
@@ -144,7 +150,13 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
     }
   }
   int buf = 0;
+#ifdef MCA_TRACE_BUILD
+  const unsigned long long t_kimg = __builtin_amdgcn_s_memtime();          // K image written (its loads have landed)
+#endif
   if (n_it > 0) swrite(0);
+#ifdef MCA_TRACE_BUILD
+  const unsigned long long t_sw = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
   const unsigned lds_qlist = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)qlist;
   auto entry_issue = [&](int i, uint32_t& v) {          // uniform LDS read, result valid after the next lgkmcnt(0)
@@ -159,8 +171,14 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1, g4 = lane >> 4;
   const int qb = wave & 1, db = wave >> 1;       // this wavefront's 16x16 block of the dQ tile
 
-  const bool tracing = (dbg & 8) && blockIdx.x == 2 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+  const bool tracing = (dbg & 8) && blockIdx.x == 2 && blockIdx.y == 0 && blockIdx.z == (gridDim.z > 16 ? 16 : 0) && tid == 0;          // a workgroup of a middle round, not of the cold first one
   int ti = 0;
+#ifdef MCA_TRACE_BUILD
+  if (tracing) {
+    mca_trace_attn_bwd[1000] = t_start; mca_trace_attn_bwd[1001] = __builtin_amdgcn_s_memtime();
+    mca_trace_attn_bwd[1004] = t_chain; mca_trace_attn_bwd[1005] = t_kimg; mca_trace_attn_bwd[1006] = t_sw;
+  }
+#endif
   for (int it = 0; it < n_it; it++) {
     AB_STAMP();
     const uint32_t ent = e_cur;
@@ -303,6 +321,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
     e_nxt = __builtin_amdgcn_readfirstlane(e_nn_v);
   }
 
+#ifdef MCA_TRACE_BUILD
+  if (tracing) mca_trace_attn_bwd[1002] = __builtin_amdgcn_s_memtime();
+#endif
   // ---- epilogue: dK = scale * dK^T, dV = dV^T + dvmean (uniform rows spread over every key)
   if (mykey < a.nk) {
     u16* dkp = a.dk + (int64_t)b * a.dkv_bstride + (int64_t)mykey * a.dkv_ld + h * DH;
@@ -322,6 +343,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
         *reinterpret_cast<uint2*>(dvp + d) = pk;
       }
   }
+#ifdef MCA_TRACE_BUILD
+  if (tracing) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mca_trace_attn_bwd[1003] = __builtin_amdgcn_s_memtime(); }
+#endif
 }
 
 #define BWD_LDS_BYTES ((2 * BQ * DH * 2 + 2 * BKEYS * BQ + BKEYS * DH) * 2 + 2 * 192 * 4 + MAX_QTILES * 4 + DH * 4)

@@ -32,3 +32,6 @@ for i in range(0, 1024 - 11, 11):          # 11 stamps per 64-query step
 print(f"{len(rows)} query steps traced")
 for r in rows[:8]: print("  " + "  ".join(f"{n}={v}" for n, v in zip(names, r[:10])) + f"  | step {r[10]}")
 print("median:", {n: st.median(r[k] for r in rows) for k, n in enumerate(names)}, "step", st.median(r[10] for r in rows))
+if t[1003] > t[1000] > 0:
+    print(f"workgroup: prologue {t[1001] - t[1000]} cycles, loop {t[1002] - t[1001]}, epilogue (stores retired) {t[1003] - t[1002]}")
+    print(f"  prologue: scalar chain + first-tile load issue {t[1004] - t[1000]}, K image written {t[1005] - t[1004]}, first tile written {t[1006] - t[1005]}, barrier + entries {t[1001] - t[1006]}")
