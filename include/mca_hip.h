@@ -204,6 +204,9 @@ typedef struct {
   const int32_t* k_ptr; const uint32_t* k_qt; const int32_t* k_order;   /* k_qt: query-tile index | (full << 31) */
   int batch, heads, nq, nk, nk_pad, n_qtiles, n_ktiles;
   float scale;
+  /* optional (may be NULL): per launch slot i < n_ktiles the four int32 {k_order[i], k_ptr[k_order[i]], number of entries,
+   * query tile of the first entry}: one 16-byte load at workgroup start instead of the k_order -> k_ptr -> k_qt chain    */
+  const int32_t* k_wg;
 } mca_attn_bwd_args;
 /* key block 256 (one workgroup), query step 64.                                                  */
 int mca_attn_bwd(const mca_attn_bwd_args* args, mca_stream_t stream);

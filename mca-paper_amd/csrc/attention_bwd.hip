@@ -57,7 +57,17 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
 #endif
   const int lin0 = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
   const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y * gridDim.z));          // knob 9 = 16: launch order (A/B)
-  const int kbi = a.k_order[lin % (int)gridDim.x];
+  // launch slot -> key block, list bounds and first query tile: one 16-byte scalar load when the host passes the table
+  int kbi, it_begin, n_it, first_qt;
+  if (a.k_wg) {
+    const int4 w = reinterpret_cast<const int4*>(a.k_wg)[lin % (int)gridDim.x];
+    kbi = w.x; it_begin = w.y; n_it = w.z; first_qt = w.w;
+  } else {
+    kbi = a.k_order[lin % (int)gridDim.x];
+    it_begin = a.k_ptr[kbi];
+    n_it = a.k_ptr[kbi + 1] - it_begin;          // <= n_qtiles <= MAX_QTILES (checked by the host)
+    first_qt = n_it > 0 ? (int)(a.k_qt[it_begin] & 0x7fffffffu) : 0;
+  }
   const int h = (lin / (int)gridDim.x) % (int)gridDim.y, b = lin / (int)(gridDim.x * gridDim.y);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -65,22 +75,16 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
   const int mykey = key0 + wave * 32 + l31;
   int keyc = mykey; if (keyc > a.nk - 1) keyc = a.nk - 1;
   const float c2 = a.scale * 1.4426950408889634f, inv_c2 = 1.f / c2;
-  // One workgroup per CU: nothing hides this prologue, so its dependent loads are kept few: the list bounds and the first
-  // entry (scalar chain k_order -> k_ptr -> k_qt) start first; the first Q / dO tile, the K / V fragments and the K image are
-  // then all in flight together, and the LDS writes and the barrier come after all of them.
-  const int it_begin = a.k_ptr[kbi], it_end = a.k_ptr[kbi + 1];
-  const int n_it = it_end - it_begin;          // <= n_qtiles <= MAX_QTILES (checked by the host)
-  const int first_qt = n_it > 0 ? (int)(a.k_qt[it_begin] & 0x7fffffffu) : 0;
+  // One workgroup per CU: nothing hides this prologue, so its dependent loads are kept few (slot table above); the first
+  // Q / dO tile, the V fragments and the K image are all in flight together, and the LDS writes and the barrier come after
+  // all of them.  The K fragments are read back from the K image (the direct form is 16-byte pieces of 32 rows per instruction).
 
   const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
   const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
   // K / V fragments (B operands): lane = key, k = d
   bf16x8 kf[4], vf[4];
 #pragma unroll
-  for (int s = 0; s < 4; s++) {
-    kf[s] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)keyc * a.kv_ld + 16 * s + 8 * lh);
-    vf[s] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)keyc * a.kv_ld + 16 * s + 8 * lh);
-  }
+  for (int s = 0; s < 4; s++) vf[s] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)keyc * a.kv_ld + 16 * s + 8 * lh);
   const uint32_t kinfo = a.keyinfo[(int64_t)b * a.nk_pad + mykey];     // nk_pad covers every key block
   const bool key_ok = kinfo != 31u;
   const uint32_t keybit = key_ok ? (1u << kinfo) : 0u;          // bit of this lane's key group; 0 = padded key
@@ -158,6 +162,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
   const unsigned long long t_sw = __builtin_amdgcn_s_memtime();
 #endif
   __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 4; s++) kf[s] = *reinterpret_cast<const bf16x8*>(Kimg + kt_off(wave * 32 + l31, 2 * s + lh));
   const unsigned lds_qlist = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)qlist;
   auto entry_issue = [&](int i, uint32_t& v) {          // uniform LDS read, result valid after the next lgkmcnt(0)
     asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(lds_qlist + 4u * (unsigned)i));

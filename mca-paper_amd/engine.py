@@ -51,6 +51,12 @@ class _Sched:
         pack = lambda idx, full: (idx.astype(np.uint32) | (full.astype(np.uint32) << 31)).view(np.int32)
         self.q_ptr, self.q_kt, self.q_order = _dev(s.q_ptr, device), _dev(pack(s.q_kt, s.q_full), device), _dev(s.q_order, device)
         self.k_ptr, self.k_qt, self.k_order = _dev(s.k_ptr, device), _dev(pack(s.k_qt, s.k_full), device), _dev(s.k_order, device)
+        # per launch slot of the backward: {key block, first entry, number of entries, query tile of the first entry}
+        wg = np.zeros((len(s.k_order), 4), np.int32)
+        for i, kb in enumerate(s.k_order):
+            lo, hi = int(s.k_ptr[kb]), int(s.k_ptr[kb + 1])
+            wg[i] = (kb, lo, hi - lo, int(s.k_qt[lo]) if hi > lo else 0)
+        self.k_wg = _dev(wg, device)
 
 
 class FusionEngine:
@@ -379,6 +385,7 @@ class FusionEngine:
         a.dkv_bstride, a.dkv_ld = N * dkv_ld, dkv_ld
         a.qmask, a.keyinfo, a.ktile_flags = qmask.data_ptr(), ws["keyinfo"].data_ptr(), ws["kflags"].data_ptr()
         a.k_ptr, a.k_qt, a.k_order = sched.k_ptr.data_ptr(), sched.k_qt.data_ptr(), sched.k_order.data_ptr()
+        a.k_wg = sched.k_wg.data_ptr()
         a.batch, a.heads, a.nq, a.nk, a.nk_pad = b, self.H, nq, N, self.nk_pad
         a.n_qtiles, a.n_ktiles, a.scale = sched.s.n_q, sched.s.n_k, self.scale
         hip.set_tag("pool" if nq != N else "layer")

@@ -74,6 +74,7 @@ class AttnBwdArgs(C.Structure):
         ("k_ptr", C.c_void_p), ("k_qt", C.c_void_p), ("k_order", C.c_void_p),
         ("batch", C.c_int), ("heads", C.c_int), ("nq", C.c_int), ("nk", C.c_int), ("nk_pad", C.c_int),
         ("n_qtiles", C.c_int), ("n_ktiles", C.c_int), ("scale", C.c_float),
+        ("k_wg", C.c_void_p),
     ]
 
 
