@@ -358,8 +358,9 @@ def test_full_size_gradients_new_vs_conservative_kernels(P, kind, b):
     finally:
         for key in (7, 5, 9):
             hipm.lib().mca_debug_set(key, 0)
-    # dropped modalities give rows with no valid key: their output is mean(V), summed with fp32 atomics (order-dependent)
-    assert abs(l_new - l_new2) <= 5e-5 * abs(l_new)
+    # dropped modalities give rows with no valid key: their output is mean(V), summed with fp32 atomics (order-dependent);
+    # observed spread of the loss up to 5.2e-5 relative (the logits are O(10^4)); the races this test caught moved it by 1e-2
+    assert abs(l_new - l_new2) <= 2e-4 * abs(l_new)
     assert abs(l_new - l_old) <= 2e-3 * abs(l_old)           # bf16 rounding placement differs (fused vs unfused epilogues)
     # The two paths round in different places (fused FF1+GEGLU epilogue, fp32 vs bf16 dg): pooled embeddings differ by a few
     # 1e-4 and the temperature-14 contrastive softmax turns that into a uniform ~1-3 % on every gradient (measured:
