@@ -186,7 +186,10 @@ def main():
             n, ms, fl = dom[1]
             ach = fl / (ms * 1e-3) / 1e12
             line["roofline"] = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom[0]),
+                                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                                # HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE of the committed PMC passes) or null
+                                "traffic": (pmc_traffic(dom[0]) or {}).get("bytes_per_launch"),
+                                "traffic_source": (pmc_traffic(dom[0]) or {}).get("source"),
                                 "avg_launch_us": round(ms / n * 1e3, 1), "alg_flops_per_launch": fl / n,
                                 "sampled_steps": sampled}
             line["kernels"] = kern
