@@ -30,8 +30,6 @@ typedef void* mca_stream_t;
 
 /* version / build info: returns a static string */
 const char* mca_version(void);
-/* tuning knobs for A/B measurements (key 1: GEMM register prefetch depth 1|2); returns 0 */
-int mca_debug_set(int key, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM  (all Linear layers: encoders.py:190, model.py:49-51,69-71; their autograd backward)
@@ -162,6 +160,12 @@ typedef struct { const void* mask; uint8_t* rowmask; int32_t elem_bytes, n, offs
 typedef struct { mca_mask_desc m[MCA_MAX_MODALITIES]; int32_t n_mod, batch, n_tokens, n_fusion; } mca_pack_masks_args;
 int mca_pack_masks(const mca_pack_masks_args* args, uint8_t* padding, int32_t* present, mca_stream_t stream);
 
+/* Finite check of encoder inputs / pooled outputs without a host sync (encoders.py:197-198,206-213: the reference raises
+ * after `.sum()` syncs).  *flag |= bit if any of the n[i] floats at p[i], i < count, is Inf or NaN.  The caller zeroes the
+ * flag word, reads it once per step and passes it to mca_adamw_step as skip_flag.                                       */
+typedef struct { const float* p[MCA_MAX_MODALITIES]; int64_t n[MCA_MAX_MODALITIES]; int32_t count, pad_; } mca_finite_args;
+int mca_nonfinite_flag(const mca_finite_args* args, int32_t* flag, int bit, mca_stream_t stream);
+
 /* keyinfo[b, nk_pad] = padded ? 31 : kgroup[j]; entries >= nk are 31.
  * ktile_flags[b, n_ktiles] = 0 no valid key in the 64-key tile, 1 mixed, 2 all valid.
  * padding: u8 (b, nk), 1 = padded key (model.py:465-466).                                       */
@@ -235,11 +239,13 @@ int mca_contrastive_fwd_bwd(const float* pooled_all, const uint32_t* present_all
  * --------------------------------------------------------------------------------------------- */
 /* sqnorm[0] += sum g^2  (caller zeroes sqnorm)                                                   */
 int mca_grad_sqnorm(const float* g, int64_t n, float* sqnorm, mca_stream_t stream);
-/* grads scaled by min(1, max_norm/(sqrt(sqnorm)+1e-6)) when max_norm > 0, then decoupled AdamW.  */
+/* grads scaled by min(1, max_norm/(sqrt(sqnorm)+1e-6)) when max_norm > 0, then decoupled AdamW.
+ * skip_flag (may be NULL): device word written by mca_nonfinite_flag; non-zero = the step is skipped,
+ * parameters and moments untouched (the reference raises before optimizer.step(), encoders.py:197-213). */
 int mca_adamw_step(float* p, const float* g, float* m, float* v, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay,
                    float bias_corr1, float bias_corr2, float max_norm, const float* sqnorm,
-                   mca_stream_t stream);
+                   const int32_t* skip_flag, mca_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -24,10 +24,13 @@ def main():
     assert torch.cuda.device_count() >= 1
     device = torch.device("cuda", 0)
     config = P.config.training_config(sys.argv[1])
+    torch.manual_seed(0)                                                        # infer_accel_gpu.py:28 (seeds the predrop draws)
     model_config = P.config.get_model_config(config)
     model = P.MCA(**model_config).to(device)
     if config.restart:
-        P.checkpoint.load_model(model, config.restart, strict=False)
+        missing, unexpected = P.checkpoint.load_model(model, config.restart, strict=False)
+        if missing or unexpected:          # embeddings from partly random weights are worse than no embeddings
+            raise KeyError(f"checkpoint {config.restart} does not match the model: missing {missing[:8]} unexpected {unexpected[:8]}")
     elif not synthetic:
         raise AssertionError("config.restart must name a checkpoint")           # infer_accel_gpu.py:90
     model.eval()
@@ -40,11 +43,10 @@ def main():
                 yield b
         splits = {"train": split(100), "eval": split(10_000)}
     else:
-        from datasets import load_from_disk
         from torch.utils.data import DataLoader
-        ds = load_from_disk(config.dataset).with_format("torch")
-        if config.split and config.split != 1.0:
-            ds = ds.train_test_split(config.split, seed=config.ds_seed)
+        # infer_accel_gpu.py:36-41 of the reference: the same setup_data call as training (ds_frac, predrop, split)
+        ds = P.data.setup_data(config.dataset, split=config.split, ds_frac=config.ds_frac, ds_seed=config.ds_seed,
+                               predrop=bool(config.get("predrop", False)), predrop_config=config.get("modality_config", {}))
         coll = P.MultimodalCollator(config.get("modality_config", {}), labels=label_col)
         splits = {"train": DataLoader(ds["train"], collate_fn=coll, batch_size=config.batch_size, drop_last=True, shuffle=False),
                   "eval": DataLoader(ds["test"], collate_fn=coll, batch_size=config.batch_size, drop_last=True, shuffle=False)}

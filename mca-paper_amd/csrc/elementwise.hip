@@ -698,3 +698,39 @@ extern "C" int mca_pack_masks(const mca_pack_masks_args* args, uint8_t* padding,
   hipLaunchKernelGGL(pack_masks_kernel, dim3(args->batch), dim3(256), 0, as_stream(stream), *args, padding, present);
   return launch_status();
 }
+
+
+// =====================================================================================================
+// Device-side finite check (encoders.py:197-213: the reference raises on non-finite encoder inputs / outputs after
+// `.sum()` host syncs; here the tensors are scanned on the device and a bit is OR-ed into one flag word the host reads
+// once per step, and that mca_adamw_step honours so a bad step never reaches the weights).
+// grid (blocks, n tensors): block row y scans tensor y with 16-byte loads where the pointer allows.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(mca_finite_args a, int32_t* __restrict__ flag, int bit) {
+  const float* __restrict__ p = a.p[blockIdx.y];
+  const int64_t n = a.n[blockIdx.y];
+  bool bad = false;
+  const bool vec = ((uintptr_t)p & 15) == 0;
+  const int64_t n4 = vec ? n / 4 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const uint4 v = reinterpret_cast<const uint4*>(p)[i];
+    bad |= ((v.x & 0x7f800000u) == 0x7f800000u) | ((v.y & 0x7f800000u) == 0x7f800000u) | ((v.z & 0x7f800000u) == 0x7f800000u) |
+           ((v.w & 0x7f800000u) == 0x7f800000u);
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    bad |= (__float_as_uint(p[i]) & 0x7f800000u) == 0x7f800000u;
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, bit);
+}
+extern "C" int mca_nonfinite_flag(const mca_finite_args* args, int32_t* flag, int bit, mca_stream_t stream) {
+  if (!args || !flag || args->count <= 0 || args->count > MCA_MAX_MODALITIES || bit == 0) return MCA_E_BADARG;
+  int64_t nmax = 0;
+  for (int i = 0; i < args->count; i++) {
+    if (!args->p[i] || args->n[i] < 0) return MCA_E_BADARG;
+    if ((uintptr_t)args->p[i] % 4) return MCA_E_ALIGN;
+    if (args->n[i] > nmax) nmax = args->n[i];
+  }
+  if (nmax == 0) return MCA_OK;
+  int64_t blocks = (nmax / 4 + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)blocks, (unsigned)args->count), dim3(256), 0, as_stream(stream), *args, flag, bit);
+  return launch_status();
+}

@@ -3,6 +3,7 @@
 // betas (0.9, 0.999), eps 1e-8, weight_decay 0.01 applied to every tensor).  The reference walks 61
 // tensors with for-each kernels and syncs the host for the norm; here the norm stays on the device.
 #include "common.h"
+#include "../../include/mca_hip_debug.h"
 
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, int64_t n4, int64_t n, float* __restrict__ out) {
   __shared__ float red[4];
@@ -29,7 +30,9 @@ extern "C" int mca_grad_sqnorm(const float* g, int64_t n, float* sqnorm, mca_str
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                      float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                                                     float wd, float bc1, float bc2, float max_norm, const float* __restrict__ sqnorm) {
+                                                     float wd, float bc1, float bc2, float max_norm, const float* __restrict__ sqnorm,
+                                                     const int32_t* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag != 0) return;          // a non-finite step (mca_nonfinite_flag) never reaches the weights
   float clip = 1.f;
   if (max_norm > 0.f && sqnorm) {
     const float c = max_norm / (sqrtf(*sqnorm) + 1e-6f);       // torch.nn.utils.clip_grad_norm_
@@ -49,15 +52,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 extern "C" int mca_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                               float eps, float weight_decay, float bias_corr1, float bias_corr2, float max_norm,
-                              const float* sqnorm, mca_stream_t stream) {
+                              const float* sqnorm, const int32_t* skip_flag, mca_stream_t stream) {
   if (!p || !g || !m || !v || n <= 0) return MCA_E_BADARG;
   int64_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, bias_corr1, bias_corr2, max_norm, sqnorm);
+                     weight_decay, bias_corr1, bias_corr2, max_norm, sqnorm, skip_flag);
   return launch_status();
 }
 
 int mca_knobs[16] = {0};
 extern "C" int mca_debug_set(int key, int value) { if (key >= 0 && key < 16) mca_knobs[key] = value; return 0; }
+extern "C" int mca_debug_reset(void) { for (int i = 0; i < 16; i++) mca_knobs[i] = 0; return 0; }
 
 extern "C" const char* mca_version(void) { return "mca_hip 0.1 (gfx950)"; }

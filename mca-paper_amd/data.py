@@ -81,3 +81,25 @@ def batch_predrop(modality_config: dict, random_seed: int = 42):
         return {k: (droppers[k](v) if k in droppers else v) for k, v in sample.items()}
 
     return apply
+
+
+def setup_data(dataset_path, split=0.1, ds_frac=1.0, ds_seed=42, model=3, predrop=False, predrop_config=None):
+    """The reference's dataset pipeline (utils/dataset.py:72-84), same signature and order: load_from_disk -> optional
+    prefix selection (ds_frac) -> optional per-sample modality pre-dropout (``dataset.map``, BEFORE the split, so train and
+    test are both pre-dropped) -> train_test_split.  ``predrop=True`` without a usable ``predrop_config`` raises instead of
+    silently training on fully-present data."""
+    from datasets import load_from_disk
+    dataset = load_from_disk(dataset_path).with_format("torch")
+    if ds_frac < 1.0:
+        dataset = dataset.select(list(range(0, int(len(dataset) * ds_frac))))
+    if predrop:
+        if not predrop_config:
+            raise ValueError("predrop is set but the config has no modality_config to take the dropout rates from")
+        missing = [k for k, c in predrop_config.items() if "dropout" not in c]
+        if missing:
+            raise KeyError(f"predrop: modality_config entries without a 'dropout' key: {missing}")           # config['dropout'] in the reference
+        print(f"Running preprocessing dropout of modalities using random seed {torch.random.initial_seed()}")
+        dataset = dataset.map(batch_predrop(predrop_config, ds_seed), batched=False)
+    if split and split != 1.0:
+        dataset = dataset.train_test_split(split, seed=ds_seed)
+    return dataset

@@ -51,14 +51,18 @@ class BucketReducer:
         self.flat = flat_grads
         self.group = group
         self.world = dist.get_world_size(group)
+        self.avg_op = dist.get_backend(group) == "nccl"
         self.pending: List = []
 
     def bucket_ready(self, lo: int, hi: int):
         if hi <= lo or self.world == 1:
             return
         chunk = self.flat[lo:hi]
-        chunk.div_(self.world)                                         # pre-scale: sum of means = mean
-        self.pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.avg_op:                                                # RCCL: the mean is taken inside the collective
+            self.pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+        else:                                                          # gloo has no AVG: pre-scale, sum of means = mean
+            chunk.div_(self.world)
+            self.pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         for w in self.pending:
@@ -77,8 +81,13 @@ class DataParallelMCA:
         eng = model.engine
         if broadcast_weights and dist.get_world_size(group) > 1:
             dist.broadcast(eng.flat, src=0, group=group)               # same initial weights on every rank
-        self.reducer = BucketReducer(eng.gflat, group)
-        eng.gather_hook = lambda pooled, present: gather_pooled(pooled, present, group)
+            eng.invalidate_weights()
+        model._dp_wrapper = self          # MCA.engine re-installs the hooks if .to() / .float() rebuilds the engine
+        self.install(eng)
+
+    def install(self, eng):
+        self.reducer = BucketReducer(eng.gflat, self.group)
+        eng.gather_hook = lambda pooled, present: gather_pooled(pooled, present, self.group)
         eng.grad_bucket_hook = self.reducer.bucket_ready
 
     def __call__(self, batch, no_loss: bool = False):

@@ -85,7 +85,14 @@ class FusionEngine:
         self._weights_version = -1
         self.grad_bucket_hook: Optional[Callable[[int, int], None]] = None   # (lo, hi) offsets ready
         self.gather_hook: Optional[Callable] = None                          # DP: pooled/present all-gather
+        # Finite checks of the reference (encoders.py:197-213) without its host syncs: the kernels OR bits into one device
+        # word; the host reads it once per step through a pinned mirror.  check_finite: True = raise inside the forward that
+        # saw the bad values (one sync per forward, the reference's behaviour); "deferred" = no sync: poll_finite() /
+        # assert_finite() raise afterwards, and FusedAdamW skips the update of a flagged step on the device; False = off.
         self.check_finite = True
+        self.finite_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._flag_event: Optional[torch.cuda.Event] = None
         self.fuse_geglu_bwd = True
         self._mod_shifts = torch.arange(len(model.modality_types), dtype=torch.int32, device=self.device)
         self.fuse_ln_residual = True                # residual LayerNorm recomputed in the GEMM epilogue (large batches)
@@ -193,8 +200,18 @@ class FusionEngine:
         rp, cp = (c, r) if transpose else (r, c)
         self._cast_list.append(hip.CastDesc(ptr(src), ptr(d), src.stride(0), r, c, dst.stride(0), rp, cp, int(transpose), 0))
 
+    def invalidate_weights(self):
+        """Call after writing parameters through an alias autograd's version counters cannot see (``p.data.op_()``, a raw
+        pointer): the bf16 GEMM-weight copies are rebuilt by the next forward."""
+        self._weights_version = -1
+
+    def _param_version(self) -> int:
+        # every Parameter is a view of `flat` with its OWN version counter (p.data = flat[...]): load_state_dict, p.copy_,
+        # torch.optim steps and dist.broadcast(p) bump the parameter's counter, FusedAdamW / broadcast(flat) bump flat's
+        return self.flat._version + sum(p._version for p in self.param_order)
+
     def refresh_weights(self, force=False):
-        v = self.flat._version
+        v = self._param_version()
         if not force and v == self._weights_version:
             return
         if getattr(self, "_cast_table", None) is not None:
@@ -248,7 +265,7 @@ class FusionEngine:
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         bf = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
         u8 = lambda *s: torch.empty(*s, dtype=torch.uint8, device=dev)
-        ws = dict(b=b, T=T)
+        ws = dict(b=b, T=T, gen=0)
         ws["x"] = [f32(T, D) for _ in range(self.L + 1)]
         ws["layers"] = [dict(x1=f32(T, D), m1=f32(T), r1=f32(T), m2=f32(T), r2=f32(T), xn_b=bf(T, D), qkv=bf(T, 3 * D),
                              o=bf(T, D), lse=f32(b, H, N), x1n_b=bf(T, D), h=bf(T, 2 * Ip), g=bf(T, Ip),
@@ -306,7 +323,7 @@ class FusionEngine:
                 part["done"] = [torch.cuda.Event() for _ in range(len(self.bucket_bounds))]
                 parts.append(part)
             self._ws[key] = dict(b=b, parts=parts, pooled=pooled, stream=torch.cuda.Stream(device=self.device),
-                                 start=torch.cuda.Event())
+                                 start=torch.cuda.Event(), gen=0)
         return self._ws[key]
 
     # ------------------------------------------------------------------------------------------------
@@ -723,6 +740,11 @@ class FusionEngine:
             else:
                 toks = ws["foreign"][name]
                 if toks.requires_grad:
+                    # the foreign encoder's parameters live in the flat buffers too: point their .grad at the flat views so
+                    # that autograd ACCUMULATES in place (FusedAdamW.zero_grad leaves None, and a fresh .grad tensor would be
+                    # replaced by the zeroed flat view after this backward)
+                    for p in enc.parameters():
+                        p.grad = G(p)
                     torch.autograd.backward(toks, dx.view(b, N, D)[:, off:off + n].to(toks.dtype))
         on_side(lambda: bucket_ready(len(self.bucket_bounds) - 1))
 
@@ -782,22 +804,30 @@ class FusionEngine:
         b = next(iter(first.values())).shape[0]
         need_grad = torch.is_grad_enabled() and not no_loss
         if self.check_finite:
-            bad = [(~torch.isfinite(v["tokens"])).any() for v in batch.values() if isinstance(v, dict) and "tokens" in v]
-            if bad and bool(torch.stack(bad).any()):
-                raise Exception("Tokens are not finite")               # encoders.py:197-198
+            self.poll_finite()                                         # a flagged EARLIER step raises here (no sync)
+            self._flag_inputs(batch)
         self.refresh_weights()
         native = all(isinstance(m.encoders[n], (EmbeddedSequenceEncoder, TabularEncoder)) for n in m.modality_types)
         if self.micro_batches == 2 and native and b % 2 == 0 and b >= self.micro_batch_min:
             ws, sample_mask = self._forward_split(batch, b, need_grad)
+            ws["gen"] += 1
             pooled = ws["pooled"].view(b, self.R, self.D)
         else:
             ws = self.workspace(b)
+            ws["gen"] += 1          # the saved activations of any earlier forward of this batch size are gone from here on
             sample_mask = self._encode(batch, ws, need_grad)
             pooled = self.forward_trunk(ws).view(b, self.R, self.D)
         slots = m.output_slots()
+        if self.check_finite:
+            self._flag_tensors([pooled], 2)
+            self._flag_host.copy_(self.finite_flag, non_blocking=True)
+            self._flag_event = torch.cuda.Event()
+            self._flag_event.record()
         if no_loss:
             out = {k: pooled[:, s] for k, s in slots.items()}
             out["modality_sample_mask"] = sample_mask
+            if self.check_finite and self.check_finite != "deferred":
+                self.assert_finite()
             return out
         # in-place clamp of the temperature parameter (utils/contrastive_loss_with_temperature.py:187)
         ls = m.loss.loss_fn
@@ -817,9 +847,53 @@ class FusionEngine:
             out["no-fcl_loss"] = torch.nan_to_num(terms[nf]).mean()
         out["loss"] = loss.reshape(())
         out["modality_sample_mask"] = sample_mask
-        if self.check_finite and not bool(torch.isfinite(pooled_out).all()):
-            raise Exception("Encoder transform / fusion resulted in non-finite values")   # encoders.py:206-213
+        if self.check_finite and self.check_finite != "deferred":
+            self.assert_finite()
         return out
+
+    # ---- finite flag ---------------------------------------------------------------------------------
+    def _flag_tensors(self, tensors, bit: int):
+        fa = hip.FiniteArgs()
+        keep = []
+        for t in tensors:
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.float().contiguous()
+            keep.append(t)
+            fa.p[len(keep) - 1], fa.n[len(keep) - 1] = t.data_ptr(), t.numel()
+        fa.count = len(keep)
+        if keep:
+            call("mca_nonfinite_flag", C.byref(fa), ptr(self.finite_flag), bit, stream_ptr())
+
+    def _flag_inputs(self, batch):
+        """bit 0: a non-finite value anywhere in an encoder input (encoders.py:197-198 checks the whole `tokens` tensor,
+        padded positions included); one launch for every modality."""
+        ts = [v[k] for v in batch.values() if isinstance(v, dict) for k in ("tokens", "values") if k in v and torch.is_tensor(v[k])]
+        self._flag_tensors(ts[:hip.MAX_MODALITIES], 1)
+
+    def _raise_flag(self, bits: int):
+        self.finite_flag.zero_()
+        self._flag_host.zero_()
+        self._flag_event = None
+        if bits & 1:
+            raise Exception("Tokens are not finite")                                      # encoders.py:197-198
+        raise Exception("Encoder transform / fusion resulted in non-finite values")       # encoders.py:206-213
+
+    def poll_finite(self):
+        """Non-blocking: raises if a step whose flag copy has already landed on the host saw non-finite values."""
+        ev = self._flag_event
+        if ev is not None and ev.query():
+            bits = int(self._flag_host[0])
+            if bits:
+                self._raise_flag(bits)
+
+    def assert_finite(self):
+        """Blocking form: waits for the last step's flag copy and raises if it is set."""
+        ev = self._flag_event
+        if ev is not None:
+            ev.synchronize()
+            bits = int(self._flag_host[0])
+            if bits:
+                self._raise_flag(bits)
 
 
 def _loss_forward(engine, pooled, present):
@@ -841,13 +915,17 @@ class _MCAStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, ws, pooled, present, *params):
         pooled_out, terms, loss, res = _loss_forward(engine, pooled, present)
-        ctx.engine, ctx.ws, ctx.res = engine, ws, res
+        ctx.engine, ctx.ws, ctx.res, ctx.gen = engine, ws, res, ws["gen"]
         ctx.mark_non_differentiable(terms)
         return pooled_out, terms, loss
 
     @staticmethod
     def backward(ctx, g_pooled, g_terms, g_loss):
         engine, ws, res = ctx.engine, ctx.ws, ctx.res
+        if ws["gen"] != ctx.gen:
+            raise RuntimeError(
+                "MCA.backward: another forward of the same batch size ran after the forward this loss came from; the step keeps "
+                "ONE set of saved activations per batch size, so run backward() before the next forward (train or eval)")
         d_pooled = res["d_pooled"] * g_loss.reshape(())
         if g_pooled is not None:
             d_pooled = d_pooled + g_pooled

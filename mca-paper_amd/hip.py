@@ -44,6 +44,10 @@ class MaskDesc(C.Structure):
                 ("pad_", C.c_int32)]
 
 
+class FiniteArgs(C.Structure):
+    _fields_ = [("p", C.c_void_p * MAX_MODALITIES), ("n", C.c_int64 * MAX_MODALITIES), ("count", C.c_int32), ("pad_", C.c_int32)]
+
+
 class PackMasksArgs(C.Structure):
     _fields_ = [("m", MaskDesc * MAX_MODALITIES), ("n_mod", C.c_int32), ("batch", C.c_int32), ("n_tokens", C.c_int32),
                 ("n_fusion", C.c_int32)]
@@ -83,7 +87,6 @@ _P, _I64, _I, _F = C.c_void_p, C.c_int64, C.c_int, C.c_float
 # name -> (restype, argtypes).  Must list EVERY symbol include/mca_hip.h declares (tests check this).
 SIGNATURES = {
     "mca_version": (C.c_char_p, []),
-    "mca_debug_set": (_I, [_I, _I]),
     "mca_gemm_nt": (_I, [_P, _I64, _P, _I64, _P, _I64, _I, _P, _P, _I64, _I64, _I64, _I64, _I64, _P]),
     "mca_gemm_nt_geglu_bwd": (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P]),
     "mca_gemm_nt_lnres": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _P]),
@@ -111,7 +114,13 @@ SIGNATURES = {
     "mca_contrastive_workspace_bytes": (_I64, [_I, _I]),
     "mca_contrastive_fwd_bwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "mca_grad_sqnorm": (_I, [_P, _I64, _P, _P]),
-    "mca_adamw_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
+    "mca_adamw_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P]),
+    "mca_nonfinite_flag": (_I, [C.POINTER(FiniteArgs), _P, _I, _P]),
+}
+# measurement hooks (include/mca_hip_debug.h): exported by the library, not part of the drop-in ABI
+DEBUG_SIGNATURES = {
+    "mca_debug_set": (_I, [_I, _I]),
+    "mca_debug_reset": (_I, []),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -126,7 +135,7 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: the HIP extension is not built (run `python __graft_entry__.py build`). "
                 "There is no CPU or eager fallback for the MCA step.")
         l = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
             fn = getattr(l, name)          # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
@@ -170,6 +179,22 @@ class cached_stream:
     def __exit__(self, *exc):
         global _STREAM_CACHE
         _STREAM_CACHE = self.prev
+
+
+class knobs:
+    """context manager for tests / tools: set measurement knobs (include/mca_hip_debug.h) and ALWAYS reset all of them on
+    exit, so a failing test cannot leave the conservative kernels switched on for the rest of the process."""
+
+    def __init__(self, **kv):
+        self.kv = {int(k[1:]) if isinstance(k, str) else int(k): int(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            lib().mca_debug_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        lib().mca_debug_reset()
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

@@ -114,6 +114,11 @@ class MCA(nn.Module):
             ed = getattr(enc, "embedding_dim", dim)
             if ed != dim:
                 raise ValueError(f"encoder {name}: embedding_dim {ed} != model dim {dim}")
+            # TabularEncoder: the table is indexed by arange(max_tokens) (encoders.py:80-94); the kernels renormalise and read
+            # max_tokens rows and freeze row max_tokens - 1 (padding_idx = -1), so the table must have exactly that many rows
+            ne = getattr(enc, "num_embeddings", None)
+            if getattr(enc, "kind", "") == "tabular" and ne is not None and ne != encoder_configs[name]["max_tokens"]:
+                raise ValueError(f"encoder {name}: num_embeddings {ne} != max_tokens {encoder_configs[name]['max_tokens']}")
         self.fusion_tokens = nn.Parameter(torch.randn(st.num_fusion_tokens, dim))
         self.register_buffer("fusion_mask", torch.zeros(st.num_fusion_tokens, dtype=torch.bool))
         self.layers = nn.ModuleList([MCALayer(dim, dim_head, heads, ff_mult) for _ in range(depth)])
@@ -127,6 +132,14 @@ class MCA(nn.Module):
 
         self.loss_terms = loss_terms(self.modality_types, st, bimodal_contrastive, non_fusion_fcl)
         self._engine = None
+        self._dp_wrapper = None
+        # load_state_dict writes the parameters in place: the bf16 GEMM-weight copies of the engine must follow
+        self.register_load_state_dict_post_hook(MCA._after_load_state_dict)
+
+    @staticmethod
+    def _after_load_state_dict(module, incompatible_keys):
+        if module._engine is not None:
+            module._engine.invalidate_weights()
 
     # ---- engine ------------------------------------------------------------------------------------
     @property
@@ -134,6 +147,9 @@ class MCA(nn.Module):
         if self._engine is None:
             from .engine import FusionEngine
             self._engine = FusionEngine(self)
+            dp = getattr(self, "_dp_wrapper", None)
+            if dp is not None:          # the data-parallel hooks live on the engine: a rebuilt engine gets them again
+                dp.install(self._engine)
         return self._engine
 
     def _apply(self, fn, *args, **kwargs):

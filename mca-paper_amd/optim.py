@@ -47,6 +47,7 @@ class FusedAdamW(torch.optim.Optimizer):
         sq = eng._ws.get("sqnorm")
         call("mca_adamw_step", ptr(eng.flat), ptr(eng.gflat), ptr(self.exp_avg), ptr(self.exp_avg_sq), eng.n_params,
              float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], bc1, bc2, max_norm, ptr(sq) if max_norm > 0 else None,
+             ptr(eng.finite_flag) if eng.check_finite else None,          # a step flagged non-finite leaves the weights alone
              stream_ptr())
         eng._pending_clip = 0.0
         eng.flat.add_(0)                 # bump the version counter: bf16 weight copies are refreshed next forward

@@ -15,6 +15,9 @@ Fixtures
   collators.pt   : the reference's MultimodalCollator (sequence / embedded_sequence / matrix) on ragged samples with
                    missing modalities: input samples and collated batch.
   tcga_b2.pt     : TCGA_config1-shaped config (4 tabular modalities, N=2548, 60 loss terms) at b=2, same recipe as cmu_*.
+  ref_state/, ref_state_io.pt : a state directory in the layout of the reference's accelerator.save_state (model.safetensors,
+                   optimizer.bin, scheduler.bin) after two reference training steps on a native-sized small model, the
+                   embeddings / masks the reference's inference loop produces from it, and the reference's third step.
   cmu_<case>.pt  : CMU-shaped config (N=2538, D=512, L=5) at b=2 with weights from the build's own
                    deterministic initialiser; pooled embeddings, loss terms, per-parameter grad norms.
 """
@@ -270,6 +273,86 @@ def make_tcga(refmodel):
     print(f"tcga: loss {float(rec['loss']):.5f}, {len(rec['losses'])} terms, pooled {tuple(rec['pooled'].shape)}")
 
 
+def make_ckpt(refmodel):
+    """A state directory as the reference's ``accelerator.save_state`` lays it out (train_accel_gpu.py:122-123):
+    model.safetensors (``safetensors.torch.save_file(model.state_dict())``, which is what Accelerate's save_model does),
+    optimizer.bin (``torch.save(AdamW.state_dict())``) and scheduler.bin (``get_scheduler('cosine')`` state), written after
+    two training steps of the reference on a native-sized small model (dim 128 = 2 heads x 64, mixed sequence / tabular
+    encoders), plus what the reference's inference loop (infer_accel_gpu.py:97-136) produces from that state:
+    embeddings and modality masks of an eval batch.  The third optimizer step is recorded too, so a resumed native run
+    can be checked against the reference continuing from the same state."""
+    import importlib
+    from safetensors.torch import save_file
+    from transformers import get_scheduler
+    sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+    pkg = importlib.import_module("mca-paper_amd")
+    from util_small import small_config
+    cfg = small_config("tab", depth=1)
+    out_dir = os.path.join(GOLD, "ref_state")
+    os.makedirs(out_dir, exist_ok=True)
+    real_save = torch.save
+    torch.save = lambda *a, **k: None
+    try:
+        torch.manual_seed(5)
+        model = refmodel.MCA(**cfg)
+        perturb_(model, 6)
+        model.train()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        sched = get_scheduler(name="cosine", optimizer=opt, num_warmup_steps=2, num_training_steps=10)
+        batches = [pkg.data.synthetic_batch(cfg, 4, seed=50 + i, p_drop=0.3) for i in range(3)]
+        for i in range(2):
+            out = model(batches[i])
+            opt.zero_grad()
+            out["loss"].backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 2.0)
+            opt.step(); sched.step()
+        save_file({k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}, os.path.join(out_dir, "model.safetensors"))
+        real_save(opt.state_dict(), os.path.join(out_dir, "optimizer.bin"))
+        real_save(sched.state_dict(), os.path.join(out_dir, "scheduler.bin"))
+        lr_next = opt.param_groups[0]["lr"]
+        # inference from that state (eval mode, no grad), as infer_accel_gpu.py:97-136 collects it
+        model.eval()
+        eval_batch = pkg.data.synthetic_batch(cfg, 4, seed=99, p_drop=0.3)
+        with torch.no_grad():
+            o = model(eval_batch)
+        emb = {("|".join(map(str, sorted(k))) if isinstance(k, frozenset) else k): v.detach().clone()
+               for k, v in o.items() if isinstance(v, torch.Tensor) and v.dim() == 2}
+        masks = {k: v.clone() for k, v in o["modality_sample_mask"].items()}
+        # the reference continues: third step from the saved state
+        model.train()
+        out = model(batches[2])
+        opt.zero_grad()
+        out["loss"].backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 2.0)
+        opt.step(); sched.step()
+        after3 = {n: p.detach().clone() for n, p in model.named_parameters()}
+    finally:
+        torch.save = real_save
+    torch.save({"config": cfg, "train_batches": batches, "eval_batch": eval_batch, "embeddings": emb, "masks": masks,
+                "lr_step3": lr_next, "loss_step3": out["loss"].detach().clone(), "state_step3": after3},
+               os.path.join(GOLD, "ref_state_io.pt"))
+    print("wrote ref_state/ and ref_state_io.pt:", {k: os.path.getsize(os.path.join(out_dir, k)) for k in os.listdir(out_dir)})
+
+
+def make_unrunnable(refmodel):
+    """Configurations of the reference that raise in the reference itself (recorded, not worked around)."""
+    import json
+    real_save = torch.save
+    torch.save = lambda *a, **k: None
+    rec = {}
+    try:
+        cfg = tiny_model_config("mca"); cfg["mean_pool"] = True
+        try:
+            refmodel.MCA(**cfg)(tiny_batch(3, {}))
+            rec["MCA(mean_pool=True).forward"] = {"type": None, "message": "ran"}
+        except Exception as e:          # model.py:264 `if self.token_types` on an N-element tensor
+            rec["MCA(mean_pool=True).forward"] = {"type": type(e).__name__, "message": str(e), "where": "model.py:264 MeanTokenProjectionPool.forward"}
+    finally:
+        torch.save = real_save
+    json.dump(rec, open(os.path.join(GOLD, "ref_unrunnable.json"), "w"), indent=1)
+    print("ref_unrunnable:", rec)
+
+
 def make_collators(refenc):
     """The reference's collators (encoders.py:286-403) on ragged samples with missing modalities, NaNs, over-long rows."""
     g = torch.Generator().manual_seed(7)
@@ -312,6 +395,7 @@ if __name__ == "__main__":
     ap.add_argument("--cmu", action="store_true")
     ap.add_argument("--init", action="store_true")
     ap.add_argument("--tiny", action="store_true")
+    ap.add_argument("--ckpt", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     refmodel, refenc = import_reference()
@@ -319,7 +403,10 @@ if __name__ == "__main__":
         make_collators(refenc)
     if a.tcga:
         make_tcga(refmodel)
-    if a.tiny or not (a.cmu or a.init or a.collators or a.tcga):
+    if a.ckpt:
+        make_ckpt(refmodel)
+        make_unrunnable(refmodel)
+    if a.tiny or not (a.cmu or a.init or a.collators or a.tcga or a.ckpt):
         make_tiny(refmodel)
     if a.init:
         make_init_parity(refmodel)

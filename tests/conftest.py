@@ -23,3 +23,13 @@ def pkg():
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _reset_measurement_knobs():
+    """The A/B knobs of the library (include/mca_hip_debug.h) are process-global: whatever a test set, and however it
+    ended, they are all back to 0 before the next test."""
+    yield
+    hip = sys.modules.get("mca-paper_amd.hip")
+    if hip is not None and getattr(hip, "_lib", None) is not None:
+        hip._lib.mca_debug_reset()

@@ -526,6 +526,6 @@ def test_clip_adamw(H):
         H.call("mca_grad_sqnorm", gd.data_ptr(), n, sq.data_ptr(), H.stream_ptr())
         assert abs(float(sq.sqrt()) - float(gn)) < 1e-4 * float(gn)
         H.call("mca_adamw_step", p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.01,
-               1 - 0.9 ** step, 1 - 0.999 ** step, 2.0, sq.data_ptr(), H.stream_ptr())
+               1 - 0.9 ** step, 1 - 0.999 ** step, 2.0, sq.data_ptr(), None, H.stream_ptr())
         err = (p.cpu() - p_ref.detach()).abs().max()
         assert err < 5e-6, f"step {step}: {err}"

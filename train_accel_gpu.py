@@ -25,12 +25,28 @@ optim = importlib.import_module("mca-paper_amd.optim")
 dpmod = importlib.import_module("mca-paper_amd.dp")
 
 
+def lr_factor(name, step, warmup, total):
+    """Multiplier of the base LR at optimizer step `step`: transformers.get_scheduler(name, ...) as called at
+    train_accel_gpu.py:81-86 (names used by the reference's YAMLs: cosine, constant_with_warmup; plus linear and constant).
+    Unknown names raise, as get_scheduler does."""
+    if name == "constant":
+        return 1.0
+    if name == "constant_with_warmup":
+        return step / max(1.0, warmup) if step < warmup else 1.0
+    if name == "linear":
+        if step < warmup:
+            return step / max(1, warmup)
+        return max(0.0, (total - step) / max(1, total - warmup))
+    if name == "cosine":
+        if step < warmup:
+            return step / max(1, warmup)
+        prog = (step - warmup) / max(1, total - warmup)
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+    raise ValueError(f"{name} is not a valid SchedulerType")
+
+
 def cosine_with_warmup(step, warmup, total):
-    """transformers.get_scheduler('cosine') (train_accel_gpu.py:81-86)."""
-    if step < warmup:
-        return step / max(1, warmup)
-    prog = (step - warmup) / max(1, total - warmup)
-    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+    return lr_factor("cosine", step, warmup, total)
 
 
 def move_to(obj, device):
@@ -68,14 +84,12 @@ def main():
         steps_per_epoch = synthetic_steps
         eval_batches = None
     else:
-        from datasets import load_from_disk
         from torch.utils.data import DataLoader
         from torch.utils.data.distributed import DistributedSampler
-        ds = load_from_disk(config.dataset).with_format("torch")
-        if config.ds_frac < 1.0:
-            ds = ds.select(list(range(0, int(len(ds) * config.ds_frac))))
-        if config.split and config.split != 1.0:
-            ds = ds.train_test_split(config.split, seed=config.ds_seed)
+        # train_accel_gpu.py:31-36: predrop / predrop_config come from the YAML; dropped modalities reach the model as
+        # fully-padded rows through the collators
+        ds = P.data.setup_data(config.dataset, split=config.split, ds_frac=config.ds_frac, ds_seed=config.ds_seed,
+                               predrop=bool(config.get("predrop", False)), predrop_config=modality_config)
         collate = P.MultimodalCollator(modality_config)
         sampler = DistributedSampler(ds["train"], world, rank, shuffle=True, drop_last=True) if world > 1 else None
         train_dl = DataLoader(ds["train"], collate_fn=collate, batch_size=config.batch_size, shuffle=sampler is None, sampler=sampler,
@@ -94,18 +108,27 @@ def main():
     opt = optim.FusedAdamW(model, lr=config.lr)
     dp = dpmod.DataParallelMCA(model) if world > 1 else None
     total_steps = config.epochs * steps_per_epoch
+    # Accelerate's prepared scheduler advances num_processes times per optimizer step (AcceleratedScheduler.step with
+    # split_batches=False), while num_training_steps counts the per-rank batches: under DP=W the reference's warm-up and
+    # cosine run W times faster than the YAML reads.  Reproduced by default; MCA_SCHED_PER_STEP=1 steps once per update.
+    sched_stride = 1 if os.environ.get("MCA_SCHED_PER_STEP") == "1" else world
+    model.engine.check_finite = "deferred"          # device flag, read without a sync; AdamW skips a flagged step
     if config.restart:
-        P.checkpoint.load_state(config.restart, model, opt)                  # train_accel_gpu.py:97-99
+        meta = P.checkpoint.load_state(config.restart, model, opt)           # train_accel_gpu.py:97-99
+        if rank == 0 and meta.get("warnings"):
+            print("\n".join(meta["warnings"]), flush=True)
     log = open(os.path.join(config.output_dir, "log.jsonl"), "a") if rank == 0 else None
     step = config.start_epoch * steps_per_epoch
+    if config.restart and "scheduler_last_epoch" in meta:          # the restored scheduler position, as load_state gives the reference
+        step = meta["scheduler_last_epoch"] // sched_stride
     model.train()
     for epoch in range(config.start_epoch, config.epochs):
         t_epoch = time.time()
         for idb, batch in enumerate(batches(epoch)):
             batch = move_to(batch, device)
             for g in opt.param_groups:
-                g["lr"] = config.lr * (cosine_with_warmup(step, config.num_warmup_steps, total_steps)
-                                       if config.lr_scheduler_type == "cosine" else 1.0)
+                g["lr"] = config.lr * lr_factor(config.lr_scheduler_type, step * sched_stride, config.num_warmup_steps,
+                                                total_steps * sched_stride)
             outputs = model(batch)
             opt.zero_grad()
             loss = outputs["loss"]
@@ -115,6 +138,7 @@ def main():
             gnorm = optim.clip_grad_norm_(model, config.clip) if config.clip else None
             opt.step()
             step += 1
+            model.engine.poll_finite()          # raises for a completed step that saw non-finite values (no host sync)
             if rank == 0 and (idb % 10 == 0 or idb == steps_per_epoch - 1):
                 rec = {"epoch": epoch, "step": step, "total_loss": float(loss), "lr": opt.param_groups[0]["lr"],
                        "grad_norm": float(gnorm) if gnorm is not None else None,
@@ -122,9 +146,10 @@ def main():
                 print(json.dumps(rec), flush=True)
                 log.write(json.dumps(rec) + "\n"); log.flush()
             if config.n_step_checkpoint and idb % config.n_step_checkpoint == 0 and rank == 0:
-                P.checkpoint.save_state(config.output_dir, model, opt, step)
+                P.checkpoint.save_state(config.output_dir, model, opt, step, sched_stride=sched_stride)
+        model.engine.assert_finite()
         if rank == 0:
-            P.checkpoint.save_state(os.path.join(config.output_dir, str(epoch)), model, opt, step)
+            P.checkpoint.save_state(os.path.join(config.output_dir, str(epoch)), model, opt, step, sched_stride=sched_stride)
             print(f"epoch {epoch} done in {time.time() - t_epoch:.1f}s", flush=True)
         if config.run_eval_loop and eval_batches is not None:
             # eval loop of the reference (train_accel_gpu.py:137-181): losses + Wang-Isola alignment / uniformity
