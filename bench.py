@@ -1,15 +1,19 @@
 """bench.py — training samples/sec of the native MCA step (fwd + bwd + clip + AdamW) on synthetic CMU-shaped
 batches (BASELINE.json metric), one process per GPU.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 3                    # BASELINE configs[1]: CMU 4-modality MCA, b = 32
+    python bench.py --workload long --steps 5 --warmup 2              # BASELINE configs[4]: 4 x 1500 tokens, b = 128
+    python bench.py --batch 8                                         # the per-GPU batch of the two DP = 8 configs
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W [--batch 8] [--variant mma --p-drop 0.4]
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     : the dominant kernel of the step, timed live with HIP events on its launch stream; achieved =
                  algorithmic flops per launch / average launch duration (DESIGN.md section "Measurement").
   cpu_baseline : the oracle (CPU restatement of the reference, oracle/mca_oracle.py) timed on this host on a
                  bounded sample of the same workload (N=1, rank 0 only).
+The step timed is the one train_accel_gpu.py runs: finite checks ON (device flag, polled without a host sync; the
+fused AdamW skips a flagged step), inputs resident in HBM (same batch every step).
 """
 import argparse
 import importlib
@@ -25,43 +29,87 @@ sys.path.insert(0, REPO)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic GFLOP per sample per step, mask-aware, 2 flop/MAC, bwd = 2 x fwd
-STEP_GFLOP = {"cmu_mca": 334.8, "cmu_mma": 337.4}
+STEP_GFLOP = {"cmu_mca": 334.8, "cmu_mma": 337.4, "long_mca": 885.7}
+PMC_JSON = os.path.join("profiles", "r02_hbm_traffic_pmc.json")
 
 
 def pmc_traffic(kernel_key: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 per
-    MI355X_MICROARCH.md section HBM, + WRITE_SIZE; separate --pmc passes of this same command, see profiles/README.md).
-    None when no PMC summary is committed for that kernel."""
-    path = os.path.join(REPO, "profiles", "r01_hbm_traffic_pmc.json")
-    names = {"mca_gemm_nt": "gemm_nt_", "mca_gemm_tn_acc": "gemm_tn_", "mca_gemm_tn_acc_group": "gemm_tn_256x256_group_kernel", "mca_attn_fwd/layer": "attn_fwd_kernel",
-             "mca_attn_bwd/layer": "attn_bwd_kernel", "mca_gemm_nt_geglu_fwd": "gemm_nt_persist256_kernel<true>",
+    MI355X_MICROARCH.md section HBM, + WRITE_SIZE; separate --pmc passes of this same command, see profiles/README.md;
+    layer launches only: tools/pmc_traffic_json.py keeps the largest grid of a kernel).  None when no PMC summary is
+    committed for that kernel."""
+    path = os.path.join(REPO, PMC_JSON)
+    names = {"mca_gemm_nt": "gemm_nt_", "mca_gemm_tn_acc": "gemm_tn_", "mca_gemm_tn_acc_group": "gemm_tn_256x256_group_kernel",
+             "mca_attn_fwd/layer": "attn_fwd", "mca_attn_bwd/layer": "attn_bwd", "mca_gemm_nt_geglu_fwd": "gemm_nt_persist256_kernel<true>",
              "mca_gemm_nt_geglu_bwd": "gemm_nt_persist_kernel<3", "mca_gemm_nt_lnres": "gemm_nt_256_kernel<false, 1, 1, 2>"}
     if not os.path.exists(path) or kernel_key not in names:
         return None
     tot_b, tot_n = 0.0, 0
     for k, v in json.load(open(path)).items():
-        if names[kernel_key] in k and not (kernel_key == "mca_gemm_nt" and ("persist_kernel<3" in k or "persist256_kernel<true>" in k or "1, 1, 2>" in k)):
+        if names[kernel_key] in k and "prep" not in k and not (kernel_key == "mca_gemm_nt" and ("persist_kernel<3" in k or "persist256_kernel<true>" in k or "1, 1, 2>" in k)):
             tot_b += (v["fetch_MB_x2_gfx950"] + v["write_MB_per_launch"]) * 1e6 * v["launches"]
             tot_n += v["launches"]
-    return {"bytes_per_launch": round(tot_b / tot_n), "source": "profiles/r01_hbm_traffic_pmc.json"} if tot_n else None
+    return {"bytes_per_launch": round(tot_b / tot_n), "source": PMC_JSON} if tot_n else None
 
 
-def cpu_baseline(P, cfg, threads: int, b: int = 4):
+def host_cpu():
+    """(model name, physical cores this process may use)."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = min(len(cores), allowed) if cores else allowed
+    return model, max(1, n)
+
+
+def cpu_baseline(P, workload: str, variant: str, protocol: str):
+    """the oracle's full step (fwd + bwd + clip + AdamW), fp32, b = 8, the same synthetic CMU-shaped
+    batch generator, all physical cores this process may use (count and CPU model stated).  protocol 'short' (default, keeps
+    the bench within minutes): 1 warm-up + 3 timed steps; 'full': >= 3 warm-up + >= 5 timed steps and an 8-thread run beside
+    it (the figure comparable with BASELINE.md section 2's container numbers).  LONG: b = 1, 1 + 1 steps (N = 6088 dense)."""
     from oracle import mca_oracle as O
-    torch.set_num_threads(threads)
+    model, phys = host_cpu()
+    long_seq = workload == "long"
+    b = 1 if long_seq else 8
+    cfg = P.config.cmu_model_config(batch_size=b, zorro=variant == "mma", long_seq=long_seq)
     S = O.Structure(cfg)
-    sd = P.params.init_state_dict(cfg, seed=43)
+    sd0 = P.params.init_state_dict(cfg, seed=43)
     batch = P.data.synthetic_batch(cfg, b, seed=1234, lengths="uniform")
-    opt = None
-    times = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        _, _, _, opt = O.train_step(S, sd, batch, "fp32", lr=1e-4, clip=2.0, opt_state=opt)
-        times.append(time.perf_counter() - t0)
-    timed = sum(times[1:])
-    return {"value": round(2 * b / timed, 4), "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"CMU 4-modality MCA fp32 full step (fwd+bwd+clip+AdamW) at batch {b}, 2 timed steps after 1 warm-up step "
-                      f"({timed:.1f} s of CPU work)"}
+
+    def run(threads, warm, timed):
+        torch.set_num_threads(threads)
+        sd = {k: v.clone() for k, v in sd0.items()}
+        opt = None
+        ts = []
+        for _ in range(warm + timed):
+            t0 = time.perf_counter()
+            _, _, _, opt = O.train_step(S, sd, batch, "fp32", lr=1e-4, clip=2.0, opt_state=opt)
+            ts.append(time.perf_counter() - t0)
+        return b * timed / sum(ts[warm:]), sum(ts)
+
+    warm, timed = (1, 1) if long_seq else ((3, 5) if protocol == "full" else (1, 3))
+    v, spent = run(phys, warm, timed)
+    out = {"value": round(v, 4), "unit": "samples/s", "cores": phys, "physical_cores": phys, "cpu_model": model, "kind": "port",
+           "sample": f"{'LONG 4x1500' if long_seq else 'CMU 4-modality'} {'MMA' if variant == 'mma' else 'MCA'} fp32 full step (fwd+bwd+clip+AdamW) "
+                     f"at batch {b}, uniform lengths, {timed} timed steps after {warm} warm-up ({spent:.0f} s of CPU work on {phys} threads)"}
+    if protocol == "full" and not long_seq:
+        v8, spent8 = run(min(8, phys), 3, 5)
+        out["value_8_threads"] = round(v8, 4)
+        out["sample"] += f"; 8-thread run {spent8:.0f} s"
+    return out
 
 
 def main():
@@ -69,11 +117,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE config: 32 on 1 GPU)")
+    ap.add_argument("--workload", default="cmu", choices=["cmu", "long"],
+                    help="cmu: BASELINE configs[1-3] (N = 2538); long: configs[4] (4 x 1500 tokens, N = 6088, batch 128 per GPU)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 32 for cmu, 128 for long; the DP = 8 configs use 8)")
     ap.add_argument("--variant", default="mca", choices=["mca", "mma"])
     ap.add_argument("--lengths", default="full", choices=["full", "uniform"])
     ap.add_argument("--p-drop", type=float, default=0.0)
+    ap.add_argument("--attn", default="bf16", choices=["bf16", "fp8"], help="attention operand type (fp8: block-scaled MFMA, BASELINE configs[4])")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (small per-GPU batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-protocol", default="short", choices=["short", "full"])
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--sample-every", type=int, default=10, help="record per-kernel HIP events on every n-th timed step")
     args = ap.parse_args()
@@ -100,17 +153,20 @@ def main():
     hip = importlib.import_module("mca-paper_amd.hip")
     optim = importlib.import_module("mca-paper_amd.optim")
     dpmod = importlib.import_module("mca-paper_amd.dp")
-    b = args.batch
-    cfg = P.config.cmu_model_config(batch_size=b, zorro=args.variant == "mma")
+    long_seq = args.workload == "long"
+    b = args.batch or (128 if long_seq else 32)
+    cfg = P.config.cmu_model_config(batch_size=b, zorro=args.variant == "mma", long_seq=long_seq)
     torch.manual_seed(43)
     model = P.MCA(**cfg).to(dev)
     eng = model.engine
-    eng.check_finite = False                   # no host syncs inside the timed region (checked once after it)
+    eng.check_finite = "deferred"              # as train_accel_gpu.py: finite checks ON, device flag, no host sync in the step
+    if args.attn == "fp8":
+        eng.set_attention_dtype("fp8")
     opt = optim.FusedAdamW(model, lr=1e-4)
     dp = dpmod.DataParallelMCA(model) if world > 1 else None
     batch = P.data.synthetic_batch(cfg, b, seed=1234 + rank, p_drop=args.p_drop, lengths=args.lengths, device=dev)
 
-    def step():
+    def eager_step():
         out = model(batch)
         opt.zero_grad()
         out["loss"].backward()
@@ -118,10 +174,16 @@ def main():
             dp.finish_backward()
         optim.clip_grad_norm_(model, 2.0)
         opt.step()
+        eng.poll_finite()
         return out["loss"]
 
+    step = eager_step
+    if args.graph:
+        graphed = importlib.import_module("mca-paper_amd.graph").GraphedStep(model, opt, batch, clip=2.0, dp=dp)
+        step = graphed.step
+
     for w in range(args.warmup):
-        exclusive = w == 0 and not args.no_kernel_timing and args.warmup > 1      # also warm the schedule the sampled steps use
+        exclusive = w == 0 and not args.no_kernel_timing and args.warmup > 1 and not args.graph      # also warm the schedule the sampled steps use
         saved = (eng.overlap_wgrad, eng.micro_batches)
         if exclusive:
             eng.overlap_wgrad, eng.micro_batches = False, 1
@@ -129,15 +191,16 @@ def main():
         eng.overlap_wgrad, eng.micro_batches = saved
     timed = ("mca_attn_fwd", "mca_attn_bwd", "mca_gemm_nt", "mca_gemm_nt_lnres", "mca_gemm_nt_geglu_fwd", "mca_gemm_nt_geglu_bwd",
              "mca_gemm_tn_acc", "mca_gemm_tn_acc_group")
+    kernel_timing = not args.no_kernel_timing and not args.graph
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    if not args.no_kernel_timing:
+    if kernel_timing:
         hip.profile_start(timed)
     t0 = time.perf_counter()
     sampled = 0
     for i in range(args.steps):
-        rec = (not args.no_kernel_timing) and (i % args.sample_every) == 0
+        rec = kernel_timing and (i % args.sample_every) == 0
         hip.profile_enable(rec)
         sampled += int(rec)
         if rec:
@@ -156,27 +219,35 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    prof = hip.profile_stop() if not args.no_kernel_timing else {}
+    prof = hip.profile_stop() if kernel_timing else {}
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+    eng.assert_finite()                        # the device flag of the last step (blocking read, outside the timed region)
     assert bool(torch.isfinite(loss)), "non-finite loss in the timed region"
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = world * b * args.steps / dt
-        wl = f"cmu_{args.variant}"
+        wl = f"{args.workload}_{args.variant}"
+        gf = STEP_GFLOP.get(wl)
+        N = eng.N
         line = {
             "metric": "training samples/sec (fwd+bwd+opt), CMU 4-modality MCA", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"synthetic CMU 4-modality ({'MCA fcl' if args.variant == 'mca' else 'MMA/zorro'}), N=2538 D=512 L=5 H=8 F=88, "
-                                   f"lengths={args.lengths}, p_drop={args.p_drop}", "per_gpu_batch": b, "global_batch": b * world,
-                       "parallelism": f"dp{world}"},
-            "step_tflops": round(value * STEP_GFLOP[wl] / 1e3, 1),
-            "step_frac_of_mfma_peak": round(value * STEP_GFLOP[wl] / 1e3 / (MFMA_BF16_PEAK_TFLOPS * world), 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.attn == "bf16" else "bf16 (attention QK^T / PV operands fp8 e4m3)",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic {'LONG 4 x 1500 tokens' if long_seq else 'CMU 4-modality'} ({'MCA fcl' if args.variant == 'mca' else 'MMA/zorro'}), "
+                                   f"N={N} D=512 L=5 H=8 F=88, lengths={args.lengths}, p_drop={args.p_drop}",
+                       "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
+                       "inputs": "device-resident, same batch every step", "finite_checks": "on (device flag, polled)",
+                       "attention_operands": args.attn, "launch": "hipGraph replay" if args.graph else "eager",
+                       "collectives": (f"{dist.get_backend()} over {dist.get_world_size()} ranks" if world > 1 else "none")},
         }
+        if gf:
+            line["step_tflops"] = round(value * gf / 1e3, 1)
+            line["step_frac_of_mfma_peak"] = round(value * gf / 1e3 / (MFMA_BF16_PEAK_TFLOPS * world), 4)
         if prof:
             kern = {}
             for key, (n, ms, fl) in prof.items():
@@ -185,17 +256,17 @@ def main():
             dom = max(prof.items(), key=lambda kv: kv[1][1])
             n, ms, fl = dom[1]
             ach = fl / (ms * 1e-3) / 1e12
+            tr = pmc_traffic(dom[0]) if not long_seq and b == 32 else None          # the committed PMC passes are of the default workload
             line["roofline"] = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                                 # HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE of the committed PMC passes) or null
-                                "traffic": (pmc_traffic(dom[0]) or {}).get("bytes_per_launch"),
-                                "traffic_source": (pmc_traffic(dom[0]) or {}).get("source"),
+                                "traffic": (tr or {}).get("bytes_per_launch"),
+                                "traffic_source": (tr or {}).get("source"),
                                 "avg_launch_us": round(ms / n * 1e3, 1), "alg_flops_per_launch": fl / n,
                                 "sampled_steps": sampled}
             line["kernels"] = kern
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(16, os.cpu_count() or 1)
-            line["cpu_baseline"] = cpu_baseline(P, P.config.cmu_model_config(batch_size=4, zorro=args.variant == "mma"), threads)
+            line["cpu_baseline"] = cpu_baseline(P, args.workload, args.variant, args.cpu_protocol)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

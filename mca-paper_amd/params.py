@@ -10,7 +10,7 @@ def init_state_dict(model_config: dict, seed: int = 43) -> Dict[str, torch.Tenso
     """state_dict (reference key names) of a freshly constructed ``MCA(**model_config)`` under
     ``torch.manual_seed(seed)`` on the CPU generator.  Because the module tree is created in the reference's
     order with the same torch constructors, this equals the reference's own initial weights for that seed
-    (checked by tests/test_model_surface.py against tests/golden/cmu_init_checksums.pt)."""
+    (checked by tests/test_host_cpu.py::test_state_dict_keys_and_same_seed_init_as_reference against tests/golden/cmu_init_checksums.pt)."""
     from .model import MCA
     gen_state = torch.random.get_rng_state()
     try:
