@@ -28,9 +28,10 @@ TOL_POOLED = 1e-3        # rel L2 of the pooled embeddings vs the reference / fp
 TOL_POOLED_EMU = 1e-3    # vs the oracle with bf16 rounding inserted where the kernels round
 TOL_LOGIT = 1e-4         # |d loss term| <= TOL_LOGIT * (temperature * max |a.b|): the logits are O(10^3..10^4), the
                          # loss is a difference of logits, so its error scales with the logit magnitude
-TOL_GRAD = 0.20          # rel L2 per gradient tensor vs fp32 (the contrastive softmax at temperature 14 over
-                         # un-normalised embeddings amplifies the 1e-3 embedding error into % level gradient error;
-                         # the bf16-emulating oracle shows the same 1.5-6 %)
+TOL_GRADNORM_CMU = 0.03  # per-tensor gradient-NORM error vs the reference's own numbers at CMU size (observed max 0.7 % MCA,
+                         # 1.1 % MMA with 40 % modality drop: tools/probe_golden_margins.py); per-tensor rel-L2 bounds are
+                         # relative to the bf16-emulating oracle (the contrastive softmax at temperature 14 over un-normalised
+                         # embeddings amplifies the 1e-3 embedding error into %-level gradient error for ANY bf16 path)
 TOL_GRAD_MEDIAN = 0.03
 TOL_GN = 1e-2            # rel of the global gradient norm
 
@@ -127,7 +128,7 @@ def test_cmu_b2_vs_reference_golden(P, case):
             continue
         r = abs(gn - gn_ref) / gn_ref
         rels.append(r)
-        if r > TOL_GRAD:
+        if r > TOL_GRADNORM_CMU:
             bad.append((n, gn, gn_ref))
         ref_sl = rec["grad_slices"][n]
         if ref_sl.abs().max() > 0 and rel_err(nat["grads"][n].flatten()[:64], ref_sl) > 0.25:
@@ -185,7 +186,7 @@ def test_tcga_b2_vs_reference_golden(P):
             continue
         rels.append(abs(float(nat["grads"][n].norm()) - gn_ref) / gn_ref)
     rels.sort()
-    assert rels[len(rels) // 2] < 0.10 and rels[-1] < 0.5, (rels[len(rels) // 2], rels[-1])
+    assert rels[len(rels) // 2] < 0.02 and rels[-1] < 0.15, (rels[len(rels) // 2], rels[-1])          # observed 0.8 % / 7.2 %
 
 
 def test_long_sequence_step_runs(P):

@@ -1,0 +1,117 @@
+// Operand-layout and issue-rate probe of the block-scaled fp8 MFMA (measurement tool, not part of the library):
+//   v_mfma_scale_f32_32x32x64_f8f6f4 with e4m3 operands and unit scales (E8M0 127).
+// Layout: which (lane, byte) of the A operand meets which (lane, byte) of the B operand in the K sum, and which output
+// row / column a lane's operand bytes feed.  Exact small integers only (e4m3 holds 1..16 exactly).
+//   build: hipcc -O3 --offload-arch=gfx950 -shared -fPIC -o /tmp/probe_fp8.so tools/probe_fp8.hip
+#include <hip/hip_runtime.h>
+#include <cstdint>
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+
+__device__ __forceinline__ uint8_t e4m3_of_int(int v) {          // exact for 0..16
+  if (v == 0) return 0;
+  int e = 31 - __clz(v);                 // v = 2^e * (1 + m/8)
+  int m = ((v << 3) >> e) & 7;
+  return (uint8_t)(((e + 7) << 3) | m);
+}
+__device__ __forceinline__ void set_byte(v8i& r, int j, uint8_t b) {
+  uint32_t w = (uint32_t)r[j >> 2];
+  w = (w & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)b << (8 * (j & 3)));
+  r[j >> 2] = (int)w;
+}
+__device__ __forceinline__ f32x16 mfma8(v8i a, v8i b) {
+  f32x16 c;
+  for (int i = 0; i < 16; i++) c[i] = 0.f;
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+// out[test][lane][16]; tests:
+//   0..63   : A one-hot at lane (row 0 -> lane 0 or 32: half = t >> 5), byte t & 31, value 1; B byte j of every lane = 1 + (j & 15)
+//   64..127 : same A; B byte j of lane l = 1 + (j >> 4) + 2 * (l >> 5)
+//   128     : A byte j of lane l = 1 if j == 0 else 0 for lane l only per test ... (row map): A[lane][0] = 1 + (lane & 15) hmm
+//   128     : A all ones, B all ones (sum = 64)
+//   129     : A lane l byte 0 = 1 (else 0), B all ones -> D[row][col] = 1 for rows fed by byte 0 of some lane
+//   130+q   : A = 1 at byte 0 of lanes with (lane >> q) & 1 (q = 0..5), B all ones -> row index bits of a lane
+//   136+q   : B = 1 at byte 0 of lanes with (lane >> q) & 1, A all ones   -> column index bits of a lane
+__global__ void layout_kernel(float* out) {
+  const int lane = threadIdx.x;
+  for (int t = 0; t < 142; t++) {
+    v8i A, B;
+    for (int i = 0; i < 8; i++) { A[i] = 0; B[i] = 0; }
+    if (t < 128) {
+      const int tt = t & 63, half = tt >> 5, byte = tt & 31;
+      if (lane == 32 * half) set_byte(A, byte, e4m3_of_int(1));
+      for (int j = 0; j < 32; j++) set_byte(B, j, e4m3_of_int(t < 64 ? 1 + (j & 15) : 1 + (j >> 4) + 2 * (lane >> 5)));
+    } else if (t == 128) {
+      for (int j = 0; j < 32; j++) { set_byte(A, j, e4m3_of_int(1)); set_byte(B, j, e4m3_of_int(1)); }
+    } else if (t == 129) {
+      set_byte(A, 0, e4m3_of_int(1));
+      for (int j = 0; j < 32; j++) set_byte(B, j, e4m3_of_int(1));
+    } else if (t < 136) {
+      const int q = t - 130;
+      if ((lane >> q) & 1) set_byte(A, 0, e4m3_of_int(1));
+      for (int j = 0; j < 32; j++) set_byte(B, j, e4m3_of_int(1));
+    } else {
+      const int q = t - 136;
+      if ((lane >> q) & 1) set_byte(B, 0, e4m3_of_int(1));
+      for (int j = 0; j < 32; j++) set_byte(A, j, e4m3_of_int(1));
+    }
+    const f32x16 d = mfma8(A, B);
+    for (int i = 0; i < 16; i++) out[(t * 64 + lane) * 16 + i] = d[i];
+  }
+}
+extern "C" int probe_fp8_layout(float* out) {
+  hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(64), 0, 0, out);
+  return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+}
+
+// fp8 conversion check: out[i] = bits of cvt_pk_fp8_f32(in[2i], in[2i+1])
+__global__ void cvt_kernel(const float* in, int* out, int n) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < n) out[i] = __builtin_amdgcn_cvt_pk_fp8_f32(in[2 * i], in[2 * i + 1], 0, false);
+}
+extern "C" int probe_fp8_cvt(const float* in, int* out, int n) {
+  hipLaunchKernelGGL(cvt_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, in, out, n);
+  return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+}
+
+// issue rate: MODE 0 = fp8 scaled 32x32x64 x4 independent accumulators, 1 = bf16 32x32x16 x4, 2 = fp8 non-scaled 32x32x16
+template <int MODE>
+__global__ __launch_bounds__(1024) void rate_kernel(int iters, float* out, uint64_t* stamps) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 16; j++) acc[i][j] = 0.f;
+  v8i a, b;
+  for (int j = 0; j < 8; j++) { a[j] = 0x38383838 + (int)threadIdx.x; b[j] = 0x38303438; }
+  bf16x8 ha, hb;
+  for (int j = 0; j < 8; j++) { ha[j] = (short)(0x3f80 + threadIdx.x); hb[j] = (short)0x3f80; }
+  const int sc = 0x7f7f7f7f;
+  const uint64_t t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (MODE == 0) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(acc[i]) : "v"(a), "v"(b), "v"(sc));
+      else if (MODE == 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(ha), "v"(hb));
+      else asm volatile("v_mfma_f32_32x32x16_fp8_fp8 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(*(long*)&a), "v"(*(long*)&b));
+    }
+  }
+  const uint64_t t1 = __builtin_readcyclecounter();
+  float r = 0.f;
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 16; j++) r += acc[i][j];
+  if (r == 123.456f) out[0] = r;
+  if (blockIdx.x == 0 && threadIdx.x == 0) stamps[0] = t1 - t0;
+}
+extern "C" int probe_fp8_rate(int mode, int blocks, int threads, int iters, float* out, uint64_t* stamps, float* ms) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 2; rep++) {
+    hipEventRecord(e0, 0);
+    if (mode == 0) hipLaunchKernelGGL(rate_kernel<0>, dim3(blocks), dim3(threads), 0, 0, iters, out, stamps);
+    else if (mode == 1) hipLaunchKernelGGL(rate_kernel<1>, dim3(blocks), dim3(threads), 0, 0, iters, out, stamps);
+    else hipLaunchKernelGGL(rate_kernel<2>, dim3(blocks), dim3(threads), 0, 0, iters, out, stamps);
+    hipEventRecord(e1, 0);
+    if (hipEventSynchronize(e1) != hipSuccess) return -1;
+  }
+  hipEventElapsedTime(ms, e0, e1);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return 0;
+}
