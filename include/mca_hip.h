@@ -120,7 +120,8 @@ int mca_cast_pad_bf16(const float* src, int64_t lds, int64_t rows, int64_t cols,
                       uint16_t* dst, int64_t ldd, int64_t rows_pad, int64_t cols_pad, int transpose,
                       mca_stream_t stream);
 /* the same for n tensors in ONE launch; descs_dev is a device array (built once by the caller)   */
-typedef struct { const void* src; void* dst; int64_t lds, rows, cols, ldd, rows_pad, cols_pad; int32_t transpose, pad_; } mca_cast_desc;
+/* scale: every element is multiplied by it before rounding (0 is read as 1; used to fold scale * log2(e) into W_q)  */
+typedef struct { const void* src; void* dst; int64_t lds, rows, cols, ldd, rows_pad, cols_pad; int32_t transpose; float scale; } mca_cast_desc;
 int mca_cast_pad_bf16_multi(const mca_cast_desc* descs_dev, int n, mca_stream_t stream);
 /* dst[r*ldd + c] = bf16(src[r*lds + c] * scale) */
 int mca_f32_to_bf16(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t rows, int64_t cols,
@@ -188,7 +189,12 @@ typedef struct {
   const float* vmean;               /* (b, heads*64)                                               */
   int batch, heads, nq, nk, nk_pad, n_qtiles, n_ktiles;
   float scale;                      /* dim_head ** -0.5                                            */
+  int flags;                        /* MCA_ATTN_* bits                                             */
 } mca_attn_fwd_args;
+/* q already carries scale * log2(e) (folded into the bf16 copy of to_q.weight by mca_cast_pad_bf16_multi's per-tensor
+ * scale): the kernels then take q.k as the log2-domain logit and never multiply a score.  lse, o, dq, dk, dv keep their
+ * meaning (dq is the gradient w.r.t. the UNSCALED q, so the data- and weight-gradient GEMMs are unchanged).              */
+#define MCA_ATTN_Q_PRESCALED 1
 /* dim_head is fixed at 64; query tile 128 rows, key tile 64.                                     */
 int mca_attn_fwd(const mca_attn_fwd_args* args, mca_stream_t stream);
 
@@ -211,9 +217,34 @@ typedef struct {
   /* optional (may be NULL): per launch slot i < n_ktiles the four int32 {k_order[i], k_ptr[k_order[i]], number of entries,
    * query tile of the first entry}: one 16-byte load at workgroup start instead of the k_order -> k_ptr -> k_qt chain    */
   const int32_t* k_wg;
+  int flags;                        /* MCA_ATTN_* bits (MCA_ATTN_Q_PRESCALED)                      */
 } mca_attn_bwd_args;
 /* key block 256 (one workgroup), query step 64.                                                  */
 int mca_attn_bwd(const mca_attn_bwd_args* args, mca_stream_t stream);
+
+/* The same backward in two passes WITHOUT atomics (production path; float atomics run at ~1.3 TB/s chip-wide on MI355X and
+ * put a 690 us floor under the one-pass kernel): every output element has one owner, results are bitwise reproducible.
+ *   mca_attn_bwd_dq : one workgroup per 128-row query tile, key tiles of 64 (the forward's schedule); dq written once,
+ *                     bf16 (dq_f32 == 0) or fp32, no pre-zeroing.  Needs q_ptr / q_kt / q_order, n_qtiles128, n_ktiles64.
+ *   mca_attn_bwd_dkv: one workgroup per 256-key block, query steps of 64 (the one-pass kernel's schedule); dk, dv bf16.
+ *                     Needs k_wg (see mca_attn_bwd_args) / k_qt, n_qtiles64, n_kblocks256, dvmean.
+ * Both need mca_attn_bwd_prep's delta (and dvmean).  The two launches are independent of each other.                     */
+typedef struct {
+  const uint16_t* q; int64_t q_bstride; int64_t q_ld;
+  const uint16_t* k; const uint16_t* v; int64_t kv_bstride; int64_t kv_ld;
+  const uint16_t* d_o; int64_t o_bstride; int64_t o_ld;
+  const float* lse; const float* delta; const float* dvmean;
+  void* dq; int64_t dq_bstride; int64_t dq_ld; int dq_f32;
+  uint16_t* dk; uint16_t* dv; int64_t dkv_bstride; int64_t dkv_ld;
+  const uint32_t* qmask; const uint8_t* keyinfo; const uint8_t* ktile_flags;
+  const int32_t* q_ptr; const uint32_t* q_kt; const int32_t* q_order; int n_qtiles128, n_ktiles64;
+  const int32_t* k_wg; const uint32_t* k_qt; int n_qtiles64, n_kblocks256;
+  int batch, heads, nq, nk, nk_pad;
+  float scale;
+  int flags;
+} mca_attn_bwd2_args;
+int mca_attn_bwd_dq(const mca_attn_bwd2_args* args, mca_stream_t stream);
+int mca_attn_bwd_dkv(const mca_attn_bwd2_args* args, mca_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * All-pairs contrastive loss with temperature

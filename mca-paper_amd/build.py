@@ -9,11 +9,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmca_hip.so")
-SOURCES = ["elementwise.hip", "gemm.hip", "attention_fwd.hip", "attention_bwd.hip", "loss.hip", "optim.hip"]
+SOURCES = ["elementwise.hip", "gemm.hip", "attention_fwd.hip", "attention_bwd.hip", "attention_bwd2.hip", "loss.hip", "optim.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++20", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 # per-file extras: keep the attention accumulators in VGPRs (the softmax VALU works on them in place; the default
 # AGPR form costs 256 v_accvgpr moves per key tile)
-EXTRA = {"attention_fwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA = {"attention_fwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attention_bwd2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def needs_build() -> bool:
@@ -25,6 +25,27 @@ def needs_build() -> bool:
 
 
 TRACE_OUT = os.path.join(HERE, "libmca_hip_trace.so")
+
+
+def build_variant(out_path: str, defines=()) -> str:
+    """An A/B build of the same ABI with extra -D defines (tools/ab_lib_*.py load it through MCA_HIP_LIB)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    bdir = os.path.join(HERE, "build_" + os.path.splitext(os.path.basename(out_path))[0])
+    os.makedirs(bdir, exist_ok=True)
+    procs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(bdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [hipcc, *FLAGS, *[f"-D{d}" for d in defines], *EXTRA.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out_path], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    return out_path
 
 
 def build(force: bool = False, verbose: bool = True, trace: bool = False) -> str:

@@ -74,7 +74,10 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
   const int key0 = kbi * BKEYS;
   const int mykey = key0 + wave * 32 + l31;
   int keyc = mykey; if (keyc > a.nk - 1) keyc = a.nk - 1;
-  const float c2 = a.scale * 1.4426950408889634f, inv_c2 = 1.f / c2;
+  // q pre-scaled by scale * log2(e) (MCA_ATTN_Q_PRESCALED): q.k is the log2-domain logit; dK^T then carries that factor too
+  const bool prescaled = (a.flags & MCA_ATTN_Q_PRESCALED) != 0;
+  const float c2 = prescaled ? 1.f : a.scale * 1.4426950408889634f, inv_c2 = 1.f / c2;
+  const float dk_scale = prescaled ? 0.6931471805599453f : a.scale;
   // One workgroup per CU: nothing hides this prologue, so its dependent loads are kept few (slot table above); the first
   // Q / dO tile, the V fragments and the K image are all in flight together, and the LDS writes and the barrier come after
   // all of them.  The K fragments are read back from the K image (the direct form is 16-byte pieces of 32 rows per instruction).
@@ -340,8 +343,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(mca_attn_bwd_args a, int 
       for (int g = 0; g < 4; g++) {
         const int d = n * 32 + 8 * g + 4 * lh;
         uint2 pk;
-        pk.x = pack2bf(dk[n][4 * g] * a.scale, dk[n][4 * g + 1] * a.scale);
-        pk.y = pack2bf(dk[n][4 * g + 2] * a.scale, dk[n][4 * g + 3] * a.scale);
+        pk.x = pack2bf(dk[n][4 * g] * dk_scale, dk[n][4 * g + 1] * dk_scale);
+        pk.y = pack2bf(dk[n][4 * g + 2] * dk_scale, dk[n][4 * g + 3] * dk_scale);
         *reinterpret_cast<uint2*>(dkp + d) = pk;
         const f32x4 dvm = *reinterpret_cast<const f32x4*>(dvm_s + d);
         pk.x = pack2bf(dv[n][4 * g] + dvm[0], dv[n][4 * g + 1] + dvm[1]);

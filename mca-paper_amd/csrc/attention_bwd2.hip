@@ -1,0 +1,474 @@
+// Block-masked fused attention, backward in TWO passes without atomics (autograd of model.py:73-105).
+//
+// Why two passes: the one-pass kernel (attention_bwd.hip) owns a 256-key block and has to SUM dQ across key blocks.  On
+// MI355X float atomics execute at the memory side at ~1.3 TB/s chip-wide (MI355X_MICROARCH.md, "Global float atomics"): the
+// 0.9 GB of fp32 dQ adds per layer are a 690 us floor under a 1,000 us kernel, on top of a 166 MB memset and a 250 MB
+// fp32 -> bf16 pass per layer.  Here every output element has exactly one owner:
+//   mca_attn_bwd_dq   one workgroup = a 128-row QUERY tile of one (sample, head), sweeping the key tiles the structure allows
+//                     (the forward's schedule): recomputes P^T and dP^T with the query on the lane, forms dS^T in registers
+//                     and accumulates dQ^T += K^T . dS^T (dS^T accumulators ARE the B operand).  dQ leaves once, as bf16
+//                     (or fp32), no LDS round trip of dS, no atomics, no memset, no conversion pass.
+//   mca_attn_bwd_dkv  one workgroup = a 256-key block (8 wavefronts x 32 keys), sweeping 64-query steps: the one-pass kernel
+//                     without its dS^T image, K image, dQ product and atomics.
+// The price is S and dP computed twice (7 MFMA products instead of 5); both passes are bitwise reproducible.
+#include "common.h"
+
+#define DH 64
+#define AQ 128      // dq pass: query rows per workgroup
+#define AK 64       // dq pass: keys per tile
+#define MAX_KTILES 512
+#define BKEYS 256   // dkv pass: keys per workgroup
+#define BQ 64       // dkv pass: query rows per step
+#define MAX_QTILES 2048
+
+// [rows][64 d] bf16 image (128-byte rows) serving BOTH ds_read_b128 row reads and ds_read_b64_tr_b16 transposed reads
+__device__ __forceinline__ int rt_off(int r, int c) {
+  const int s = ((r >> 1) & 7) ^ (((r >> 1) & 1) << 2);
+  return r * 64 + ((c ^ s) << 3);
+}
+// row reads only: chunk c (16 B) of row r at c ^ ((r>>1)&7)
+__device__ __forceinline__ int row_off(int r, int c) { return r * 64 + ((c ^ ((r >> 1) & 7)) << 3); }
+
+// =====================================================================================================
+// dQ pass
+// =====================================================================================================
+template <bool PRESCALED, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(mca_attn_bwd2_args a, int dbg) {
+  __shared__ __attribute__((aligned(16))) u16 lds[2 * 2 * AK * DH];   // K,V double-buffered: 32 KiB
+  __shared__ __attribute__((aligned(16))) uint8_t kinfo[2][AK];
+  __shared__ uint8_t flags_s[MAX_KTILES];
+  __shared__ uint32_t live_s[MAX_KTILES];
+  __shared__ int n_live_s;
+  u16* Ks = lds;
+  u16* Vs = lds + 2 * AK * DH;
+
+  const int lin0 = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+  const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y * gridDim.z));
+  const int qt = a.q_order[lin % (int)gridDim.x];
+  const int h = (lin / (int)gridDim.x) % (int)gridDim.y, b = lin / (int)(gridDim.x * gridDim.y);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int q0 = qt * AQ + wave * 32;
+  int qrow = q0 + l31;
+  const bool qvalid = qrow < a.nq;
+  if (qrow > a.nq - 1) qrow = a.nq - 1;
+
+  // B operands held for the whole kernel: lane = query, 8 consecutive d per k-step
+  bf16x8 qf[4], dof[4];
+  {
+    const u16* qp = a.q + (int64_t)b * a.q_bstride + (int64_t)qrow * a.q_ld + h * DH + 8 * lh;
+    const u16* op = a.d_o + (int64_t)b * a.o_bstride + (int64_t)qrow * a.o_ld + h * DH + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 4; s++) { qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s); dof[s] = *reinterpret_cast<const bf16x8*>(op + 16 * s); }
+  }
+  const uint32_t qm = a.qmask[qrow];
+  const float c2 = a.scale * 1.4426950408889634f;
+  // row constants as accumulator start values: S - lse (log2 domain; lse = +inf marks a uniform row: P = 0) and dP - delta
+  f32x16 neglse, negdel;
+  {
+    const int64_t ri = ((int64_t)b * a.heads + h) * a.nq + qrow;
+    const float nl = -a.lse[ri], nd = -a.delta[ri];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { neglse[r] = nl; negdel[r] = nd; }
+  }
+  f32x16 sinit = neglse;          // un-prescaled q: the scores are scaled AFTER the product, so they start from zero
+  if (!PRESCALED) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) sinit[r] = 0.f;
+  }
+  f32x16 dq[2];
+#pragma unroll
+  for (int n = 0; n < 2; n++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) dq[n][r] = 0.f;
+
+  const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
+  const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
+  const uint8_t* kinfo_g = a.keyinfo + (int64_t)b * a.nk_pad;
+  {
+    const uint8_t* flags_g = a.ktile_flags + (int64_t)b * a.n_ktiles64;
+    for (int i = tid; i < a.n_ktiles64; i += 256) flags_s[i] = flags_g[i];
+  }
+  __syncthreads();
+
+  int srow[2], sc[2];
+  unsigned loff[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int id = tid + 256 * i; srow[i] = id >> 3; sc[i] = id & 7;
+    loff[i] = (unsigned)(srow[i] * (int)a.kv_ld + sc[i] * 8);
+  }
+  const int last_kt = a.n_ktiles64 - 1;
+  bf16x8 rk[2], rv[2];
+  uint32_t rinfo = 0;
+  auto gload = [&](int kt) {
+    const u16* kb = kbase + (int64_t)kt * AK * a.kv_ld;
+    const u16* vb = vbase + (int64_t)kt * AK * a.kv_ld;
+    if (kt != last_kt) {
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        rk[i] = *reinterpret_cast<const bf16x8*>(kb + loff[i]);
+        rv[i] = *reinterpret_cast<const bf16x8*>(vb + loff[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        int key = kt * AK + srow[i]; if (key > a.nk - 1) key = a.nk - 1;
+        rk[i] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * a.kv_ld + sc[i] * 8);
+        rv[i] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * a.kv_ld + sc[i] * 8);
+      }
+    }
+    if (tid < 16) rinfo = *reinterpret_cast<const uint32_t*>(kinfo_g + kt * AK + tid * 4);
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      *reinterpret_cast<bf16x8*>(Ks + buf * AK * DH + rt_off(srow[i], sc[i])) = rk[i];          // rows for S, columns for dQ
+      *reinterpret_cast<bf16x8*>(Vs + buf * AK * DH + row_off(srow[i], sc[i])) = rv[i];
+    }
+    if (tid < 16) *reinterpret_cast<uint32_t*>(&kinfo[buf][tid * 4]) = rinfo;
+  };
+
+  if (wave == 0) {
+    const int lb = a.q_ptr[qt], le = a.q_ptr[qt + 1];
+    int n = 0;
+    for (int i0 = lb; i0 < le; i0 += 64) {
+      const int i = i0 + lane;
+      const uint32_t e = i < le ? a.q_kt[i] : 0u;
+      const bool keep = i < le && flags_s[e & 0x7fffffffu] != 0;
+      const unsigned long long m = __ballot(keep);
+      if (keep) live_s[n + __popcll(m & ((1ull << lane) - 1ull))] = e;
+      n += __popcll(m);
+    }
+    if (lane == 0) n_live_s = n;
+  }
+  __syncthreads();
+  const int it_end = n_live_s;
+  int it = 0;
+  int buf = 0;
+  if (it < it_end) { gload((int)(live_s[0] & 0x7fffffffu)); swrite(0); }
+  __syncthreads();
+
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  while (it < it_end) {
+    const uint32_t ent = live_s[it];
+    const int kt = (int)(ent & 0x7fffffffu);
+    const bool need_mask = (ent >> 31) == 0 || (flags_s[kt] != 2);
+    const int nit = it + 1;
+    if (nit < it_end) gload((int)(live_s[nit] & 0x7fffffffu));
+
+    const u16* ks = Ks + buf * AK * DH;
+    const u16* vs = Vs + buf * AK * DH;
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+      for (int st = 0; st < 4; st++) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + rt_off(kb * 32 + l31, 2 * st + lh));
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs + row_off(kb * 32 + l31, 2 * st + lh));
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], st == 0 ? sinit : s[kb], 0, 0, 0);
+        dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[st], st == 0 ? negdel : dp[kb], 0, 0, 0);
+      }
+    }
+    if (!PRESCALED) {
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[kb][r] = fmaf(s[kb][r], c2, neglse[r]);
+    }
+    if (need_mask) {
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const uint32_t info4 = *reinterpret_cast<const uint32_t*>(&kinfo[buf][kb * 32 + 8 * g + 4 * lh]);
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const uint32_t grp = (info4 >> (8 * e)) & 0xffu;
+            const bool ok = (qm >> grp) & 1u;
+            s[kb][4 * g + e] = ok ? s[kb][4 * g + e] : -INFINITY;
+          }
+        }
+    }
+    // dS^T = P^T o (dP^T - delta), packed as the B operand of the dQ^T product
+    bf16x8 dsb[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int sp = 0; sp < 2; sp++)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const float d0 = __builtin_amdgcn_exp2f(s[kb][8 * sp + j]) * dp[kb][8 * sp + j];
+          const float d1 = __builtin_amdgcn_exp2f(s[kb][8 * sp + j + 1]) * dp[kb][8 * sp + j + 1];
+          const uint32_t pk = pack2bf(d0, d1);
+          dsb[kb][sp][j] = (short)(pk & 0xffffu); dsb[kb][sp][j + 1] = (short)(pk >> 16);
+        }
+    // dQ^T[d][q] += K^T[d][key] dS^T[key][q]: A = K^T by transposed reads of the K image (element j of k-step sp carries
+    // key 16sp + 8(j>>2) + 4lh + (j&3) of the 32-key block, the accumulator-as-operand order)
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int sp = 0; sp < 2; sp++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+          bf16x8 ktf;
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            const int key = kb * 32 + 16 * sp + 8 * t + 4 * lh + tq;
+            const int d = n * 32 + 16 * tg + 4 * tp;
+            const bf16x4 k4 = lds_read_tr16(ks + rt_off(key, d >> 3) + (d & 7));
+#pragma unroll
+            for (int e = 0; e < 4; e++) ktf[4 * t + e] = k4[e];
+          }
+          dq[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsb[kb][sp], dq[n], 0, 0, 0);
+        }
+
+    if (nit < it_end) swrite(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+    it = nit;
+  }
+
+  // ---- epilogue: dq = scale * dS K (gradient w.r.t. the unscaled q), one owner per element
+  if (qvalid) {
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int d = n * 32 + 8 * g + 4 * lh;
+        const float v0 = dq[n][4 * g] * a.scale, v1 = dq[n][4 * g + 1] * a.scale, v2 = dq[n][4 * g + 2] * a.scale, v3 = dq[n][4 * g + 3] * a.scale;
+        if (OUT_F32) {
+          float* p = reinterpret_cast<float*>(a.dq) + (int64_t)b * a.dq_bstride + (int64_t)qrow * a.dq_ld + h * DH + d;
+          *reinterpret_cast<f32x4*>(p) = f32x4{v0, v1, v2, v3};
+        } else {
+          u16* p = reinterpret_cast<u16*>(a.dq) + (int64_t)b * a.dq_bstride + (int64_t)qrow * a.dq_ld + h * DH + d;
+          uint2 pk; pk.x = pack2bf(v0, v1); pk.y = pack2bf(v2, v3);
+          *reinterpret_cast<uint2*>(p) = pk;
+        }
+      }
+  }
+}
+
+static int check_bwd2(const mca_attn_bwd2_args* a) {
+  if (!a || !a->q || !a->k || !a->v || !a->d_o || !a->lse || !a->delta || !a->qmask || !a->keyinfo || !a->ktile_flags) return MCA_E_BADARG;
+  if (a->batch <= 0 || a->heads <= 0 || a->nq <= 0 || a->nk <= 0) return MCA_E_BADARG;
+  if (a->q_ld % 8 || a->kv_ld % 8 || a->o_ld % 8 || a->q_bstride % 8 || a->kv_bstride % 8 || a->o_bstride % 8) return MCA_E_ALIGN;
+  if ((uintptr_t)a->q % 16 || (uintptr_t)a->k % 16 || (uintptr_t)a->v % 16 || (uintptr_t)a->d_o % 16) return MCA_E_ALIGN;
+  if (a->heads > 65535 || a->batch > 65535) return MCA_E_UNSUPPORTED;
+  return MCA_OK;
+}
+
+extern "C" int mca_attn_bwd_dq(const mca_attn_bwd2_args* a, mca_stream_t stream) {
+  const int rc = check_bwd2(a);
+  if (rc != MCA_OK) return rc;
+  if (!a->dq || !a->q_ptr || !a->q_kt || !a->q_order) return MCA_E_BADARG;
+  if (a->n_qtiles128 != (a->nq + AQ - 1) / AQ || a->n_ktiles64 != (a->nk + AK - 1) / AK) return MCA_E_BADARG;
+  if (a->nk_pad < a->n_ktiles64 * AK || a->nk_pad % 4 || (uintptr_t)a->keyinfo % 4) return MCA_E_BADARG;
+  if (a->dq_ld % 4 || a->dq_bstride % 4 || (uintptr_t)a->dq % (a->dq_f32 ? 16 : 8)) return MCA_E_ALIGN;
+  if (a->n_ktiles64 > MAX_KTILES) return MCA_E_UNSUPPORTED;
+  const dim3 grid(a->n_qtiles128, a->heads, a->batch);
+  const bool pre = (a->flags & MCA_ATTN_Q_PRESCALED) != 0;
+  const int dbg = mca_knobs[9];
+  if (pre && !a->dq_f32) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), grid, dim3(256), 0, as_stream(stream), *a, dbg);
+  else if (pre) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), grid, dim3(256), 0, as_stream(stream), *a, dbg);
+  else if (!a->dq_f32) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), grid, dim3(256), 0, as_stream(stream), *a, dbg);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), grid, dim3(256), 0, as_stream(stream), *a, dbg);
+  return launch_status();
+}
+
+// =====================================================================================================
+// dK / dV pass: one workgroup = 256 keys (8 wavefronts x 32 keys, K / V fragments and dK^T / dV^T in registers), sweeping the
+// 64-query steps the structure allows for the block; the key sits on the MFMA lane, so P and dS are directly the B operands
+// of the dV^T / dK^T products (guide, Appendix B "Attention backward").  Q / dO tiles in one LDS image for row AND column reads.
+// =====================================================================================================
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) u16 lds[];
+  u16* Qs = lds;                               // 2 x 64 x 64
+  u16* Os = Qs + 2 * BQ * DH;                  // 2 x 64 x 64   (dO)
+  float* rowc = reinterpret_cast<float*>(Os + 2 * BQ * DH);       // [2][3][64]: -lse, -delta, qmask(bits)
+  uint32_t* qlist = reinterpret_cast<uint32_t*>(rowc + 2 * 192);  // [MAX_QTILES]
+  float* dvm_s = reinterpret_cast<float*>(qlist + MAX_QTILES);    // [64]
+
+  const int lin0 = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+  const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y * gridDim.z));
+  const int4 w = reinterpret_cast<const int4*>(a.k_wg)[lin % (int)gridDim.x];
+  const int kbi = w.x, it_begin = w.y, n_it = w.z, first_qt = w.w;
+  const int h = (lin / (int)gridDim.x) % (int)gridDim.y, b = lin / (int)(gridDim.x * gridDim.y);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int key0 = kbi * BKEYS;
+  const int mykey = key0 + wave * 32 + l31;
+  int keyc = mykey; if (keyc > a.nk - 1) keyc = a.nk - 1;
+  const bool prescaled = (a.flags & MCA_ATTN_Q_PRESCALED) != 0;
+  const float c2 = prescaled ? 1.f : a.scale * 1.4426950408889634f, inv_c2 = 1.f / c2;
+  const float dk_scale = prescaled ? 0.6931471805599453f : a.scale;
+
+  const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
+  const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    kf[s] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)keyc * a.kv_ld + 16 * s + 8 * lh);
+    vf[s] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)keyc * a.kv_ld + 16 * s + 8 * lh);
+  }
+  const uint32_t kinfo = a.keyinfo[(int64_t)b * a.nk_pad + mykey];     // nk_pad covers every key block
+  const bool key_ok = kinfo != 31u;
+  const uint32_t keybit = key_ok ? (1u << kinfo) : 0u;
+  const bool wave_keys_ok = __all(key_ok);
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int n = 0; n < 2; n++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dk[n][r] = 0.f; dv[n][r] = 0.f; }
+
+  const u16* qbase = a.q + (int64_t)b * a.q_bstride + h * DH;
+  const u16* obase = a.d_o + (int64_t)b * a.o_bstride + h * DH;
+  const float* lse_g = a.lse + ((int64_t)b * a.heads + h) * a.nq;
+  const float* delta_g = a.delta + ((int64_t)b * a.heads + h) * a.nq;
+
+  const int srow = tid >> 3, sc = tid & 7;
+  bf16x8 stage_q, stage_o;
+  float stage_c = 0.f;
+  bool stage_oob = false;
+  const int cwhich = tid >> 6 < 2 ? tid >> 6 : 2, crow = tid & 63;
+  const float* cbase = cwhich == 0 ? lse_g : (cwhich == 1 ? delta_g : reinterpret_cast<const float*>(a.qmask));
+  auto gload = [&](int qt) {
+    int q = qt * BQ + srow; if (q > a.nq - 1) q = a.nq - 1;
+    stage_q = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)q * a.q_ld + sc * 8);
+    stage_o = *reinterpret_cast<const bf16x8*>(obase + (int64_t)q * a.o_ld + sc * 8);
+    int qq = qt * BQ + crow;
+    stage_oob = qq >= a.nq;
+    if (qq > a.nq - 1) qq = a.nq - 1;
+    stage_c = cbase[qq];
+  };
+  auto swrite = [&](int buf) {
+    *reinterpret_cast<bf16x8*>(Qs + buf * BQ * DH + rt_off(srow, sc)) = stage_q;
+    *reinterpret_cast<bf16x8*>(Os + buf * BQ * DH + rt_off(srow, sc)) = stage_o;
+    if (tid < 192) {          // rows past nq contribute nothing: lse = +inf (P = 0), delta = 0, qmask = 0
+      float v = stage_oob ? (cwhich == 0 ? INFINITY : 0.f) : stage_c;
+      if (cwhich == 0) v = -v * inv_c2; else if (cwhich == 1) v = -v;
+      rowc[buf * 192 + tid] = v;
+    }
+  };
+
+  if (n_it > 0) gload(first_qt);
+  for (int i = tid; i < n_it; i += 512) qlist[i] = a.k_qt[it_begin + i];
+  if (tid < DH) dvm_s[tid] = a.dvmean[(int64_t)b * a.heads * DH + h * DH + tid];
+  int buf = 0;
+  if (n_it > 0) swrite(0);
+  __syncthreads();
+
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  for (int it = 0; it < n_it; it++) {
+    const uint32_t ent = __builtin_amdgcn_readfirstlane(qlist[it]);          // wave-uniform: scalar branch on `full`
+    const bool full = (ent >> 31) != 0;
+    if (it + 1 < n_it) gload((int)(__builtin_amdgcn_readfirstlane(qlist[it + 1]) & 0x7fffffffu));
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+      const u16* qs = Qs + buf * BQ * DH + sub * 32 * DH;
+      const u16* os = Os + buf * BQ * DH + sub * 32 * DH;
+      const float* rc = rowc + buf * 192 + sub * 32;
+      f32x16 s, dp;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(rc + 8 * g + 4 * lh);
+        const f32x4 del4 = *reinterpret_cast<const f32x4*>(rc + 64 + 8 * g + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { s[4 * g + e] = lse4[e]; dp[4 * g + e] = del4[e]; }
+      }
+#pragma unroll
+      for (int st = 0; st < 4; st++) {
+        const bf16x8 qfrag = *reinterpret_cast<const bf16x8*>(qs + rt_off(l31, 2 * st + lh));
+        const bf16x8 ofrag = *reinterpret_cast<const bf16x8*>(os + rt_off(l31, 2 * st + lh));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfrag, kf[st], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofrag, vf[st], dp, 0, 0, 0);
+      }
+      bf16x8 pb[2], sb[2];
+      if (full && wave_keys_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(s[r] * c2), p1 = __builtin_amdgcn_exp2f(s[r + 1] * c2);
+          const uint32_t pp = pack2bf(p0, p1), ss = pack2bf(p0 * dp[r], p1 * dp[r + 1]);
+          pb[r >> 3][r & 7] = (short)(pp & 0xffffu); pb[r >> 3][(r & 7) + 1] = (short)(pp >> 16);
+          sb[r >> 3][r & 7] = (short)(ss & 0xffffu); sb[r >> 3][(r & 7) + 1] = (short)(ss >> 16);
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const f32x4 qm4 = *reinterpret_cast<const f32x4*>(rc + 128 + 8 * g + 4 * lh);
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const int r = 4 * g + e;
+            const uint32_t q0 = full ? 0xffffffffu : __float_as_uint(qm4[e]), q1 = full ? 0xffffffffu : __float_as_uint(qm4[e + 1]);
+            float p0 = __builtin_amdgcn_exp2f(s[r] * c2), p1 = __builtin_amdgcn_exp2f(s[r + 1] * c2);
+            p0 = (q0 & keybit) ? p0 : 0.f; p1 = (q1 & keybit) ? p1 : 0.f;
+            const uint32_t pp = pack2bf(p0, p1), ss = pack2bf(p0 * dp[r], p1 * dp[r + 1]);
+            pb[r >> 3][r & 7] = (short)(pp & 0xffffu); pb[r >> 3][(r & 7) + 1] = (short)(pp >> 16);
+            sb[r >> 3][r & 7] = (short)(ss & 0xffffu); sb[r >> 3][(r & 7) + 1] = (short)(ss >> 16);
+          }
+        }
+      }
+      // dV^T += dO^T P ; dK^T += Q^T dS   (element j of k-step sp carries q = 16sp + 8(j>>2) + 4lh + (j&3))
+#pragma unroll
+      for (int sp = 0; sp < 2; sp++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+          bf16x8 ot, qtf;
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            const int qr = 16 * sp + 8 * t + 4 * lh + tq;
+            const int d = n * 32 + 16 * tg + 4 * tp;
+            const bf16x4 o4 = lds_read_tr16(os + rt_off(qr, d >> 3) + (d & 7));
+            const bf16x4 q4 = lds_read_tr16(qs + rt_off(qr, d >> 3) + (d & 7));
+#pragma unroll
+            for (int e = 0; e < 4; e++) { ot[4 * t + e] = o4[e]; qtf[4 * t + e] = q4[e]; }
+          }
+          dv[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot, pb[sp], dv[n], 0, 0, 0);
+          dk[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, sb[sp], dk[n], 0, 0, 0);
+        }
+    }
+    if (it + 1 < n_it) swrite(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue: dK = dk_scale * dK^T, dV = dV^T + dvmean (uniform rows spread over every key)
+  if (mykey < a.nk) {
+    u16* dkp = a.dk + (int64_t)b * a.dkv_bstride + (int64_t)mykey * a.dkv_ld + h * DH;
+    u16* dvp = a.dv + (int64_t)b * a.dkv_bstride + (int64_t)mykey * a.dkv_ld + h * DH;
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int d = n * 32 + 8 * g + 4 * lh;
+        uint2 pk;
+        pk.x = pack2bf(dk[n][4 * g] * dk_scale, dk[n][4 * g + 1] * dk_scale);
+        pk.y = pack2bf(dk[n][4 * g + 2] * dk_scale, dk[n][4 * g + 3] * dk_scale);
+        *reinterpret_cast<uint2*>(dkp + d) = pk;
+        const f32x4 dvm = *reinterpret_cast<const f32x4*>(dvm_s + d);
+        pk.x = pack2bf(dv[n][4 * g] + dvm[0], dv[n][4 * g + 1] + dvm[1]);
+        pk.y = pack2bf(dv[n][4 * g + 2] + dvm[2], dv[n][4 * g + 3] + dvm[3]);
+        *reinterpret_cast<uint2*>(dvp + d) = pk;
+      }
+  }
+}
+#define DKV_LDS_BYTES (2 * BQ * DH * 2 * 2 + 2 * 192 * 4 + MAX_QTILES * 4 + DH * 4)
+
+extern "C" int mca_attn_bwd_dkv(const mca_attn_bwd2_args* a, mca_stream_t stream) {
+  const int rc = check_bwd2(a);
+  if (rc != MCA_OK) return rc;
+  if (!a->dk || !a->dv || !a->dvmean || !a->k_wg || !a->k_qt) return MCA_E_BADARG;
+  if (a->n_qtiles64 != (a->nq + BQ - 1) / BQ || a->n_kblocks256 != (a->nk + BKEYS - 1) / BKEYS) return MCA_E_BADARG;
+  if (a->nk_pad < a->n_kblocks256 * BKEYS) return MCA_E_BADARG;
+  if (a->dkv_ld % 4 || a->dkv_bstride % 4 || (uintptr_t)a->dk % 8 || (uintptr_t)a->dv % 8 || (uintptr_t)a->k_wg % 16) return MCA_E_ALIGN;
+  if (a->n_qtiles64 > MAX_QTILES) return MCA_E_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES) != hipSuccess)
+      return MCA_E_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(a->n_kblocks256, a->heads, a->batch), dim3(512), DKV_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
+  return launch_status();
+}

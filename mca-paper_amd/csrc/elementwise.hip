@@ -469,14 +469,15 @@ __global__ __launch_bounds__(256) void cast_pad_multi_kernel(const mca_cast_desc
   const int64_t tiles_c = (d.cols_pad + 63) / 64, tiles_r = (d.rows_pad + 63) / 64;
   // source extent in DESTINATION coordinates: plain (rows x cols), transposed (cols x rows)
   const int64_t vr = d.transpose ? d.cols : d.rows, vc = d.transpose ? d.rows : d.cols;
+  const float sc = d.scale == 0.f ? 1.f : d.scale;
   for (int64_t t = blockIdx.x; t < tiles_r * tiles_c; t += gridDim.x) {
     const int64_t r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;          // destination tile origin
 #pragma unroll 4
     for (int i = 0; i < 16; i++) {
       const int a = i * 4 + (tid >> 6), bq = tid & 63;          // source-major walk: `bq` runs along a source row
       float v = 0.f;
-      if (!d.transpose) { if (r0 + a < vr && c0 + bq < vc) v = src[(r0 + a) * d.lds + c0 + bq]; tile[a][bq] = v; }
-      else { if (c0 + a < vc && r0 + bq < vr) v = src[(c0 + a) * d.lds + r0 + bq]; tile[bq][a] = v; }          // tile[dst row][dst col]
+      if (!d.transpose) { if (r0 + a < vr && c0 + bq < vc) v = src[(r0 + a) * d.lds + c0 + bq] * sc; tile[a][bq] = v; }
+      else { if (c0 + a < vc && r0 + bq < vr) v = src[(c0 + a) * d.lds + r0 + bq] * sc; tile[bq][a] = v; }          // tile[dst row][dst col]
     }
     __syncthreads();
 #pragma unroll 4

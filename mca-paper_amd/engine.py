@@ -27,7 +27,7 @@ import torch
 
 from . import hip
 from .encoders import EmbeddedSequenceEncoder, NativeEncoder, TabularEncoder
-from .hip import AttnBwdArgs, AttnFwdArgs, LossTerm, call, ptr, stream_ptr
+from .hip import AttnBwd2Args, AttnBwdArgs, AttnFwdArgs, LossTerm, call, ptr, stream_ptr
 
 LN_EPS = 1e-5
 FWD_BQ, FWD_BK = 128, 64
@@ -77,6 +77,10 @@ class FusionEngine:
         self.I = model.layers[0].ff.inner_dim if self.L else int(self.D * 4 * 2 / 3)
         self.Ip = _pad_to(self.I, 64)
         self.scale = model.dim_head ** -0.5
+        self.q_scale = self.scale * 1.4426950408889634          # folded into the forward bf16 copy of every to_q.weight
+        self.attn_flags = hip.ATTN_Q_PRESCALED
+        if os.environ.get("MCA_Q_PRESCALE", "1") == "0":        # A/B: plain W_q copy, the kernels scale the scores themselves
+            self.q_scale, self.attn_flags = 0.0, 0
         self.nk_pad = _pad_to(self.N, 256)
         self._flatten_parameters()
         self._build_static()
@@ -99,7 +103,10 @@ class FusionEngine:
         # weight-gradient GEMMs on a side stream, concurrent with the backward chain
         self.overlap_wgrad = os.environ.get("MCA_OVERLAP_WGRAD", "1") != "0"
         self.group_wgrad = os.environ.get("MCA_GROUP_WGRAD", "1") != "0"      # one weight-gradient launch per layer
-        self.zero_dq_once = True                    # all dQ accumulators zeroed by one side-stream memset per step
+        self.zero_dq_once = True                    # (one-pass backward) all dQ accumulators zeroed by one side-stream memset per step
+        # attention backward in two passes without atomics (mca_attn_bwd_dq + mca_attn_bwd_dkv): dQ written once as bf16 straight
+        # into the dqkv operand of the data- / weight-gradient GEMMs; MCA_ATTN_BWD_ONE_PASS=1 keeps the atomic one-pass kernel
+        self.attn_bwd_two_pass = os.environ.get("MCA_ATTN_BWD_ONE_PASS", "0") != "1"
         # micro-batch interleave (opt-in, MCA_MICRO_BATCHES=2): batches of at least micro_batch_min samples run as two
         # halves on two streams.  Measured on CMU b=32: 26.3 vs 26.7 ms/step when the host runs ahead, no gain when it
         # does not (tools/ab_step.py 102 1 2, tools/diag_switch.py) - kept off by default.
@@ -192,13 +199,13 @@ class FusionEngine:
             elif isinstance(enc, TabularEncoder):
                 self.we[name] = dict(w2=bf(D, D), w2T=bf(D, D))
 
-    def _cast(self, src: torch.Tensor, dst: torch.Tensor, transpose=False, dst_row0=0, dst_col0=0):
+    def _cast(self, src: torch.Tensor, dst: torch.Tensor, transpose=False, dst_row0=0, dst_col0=0, scale=0.0):
         """dst[dst_row0:, dst_col0:] (bf16) <- src (fp32 2-D), zero padding untouched (buffers start zeroed).  Only
         RECORDS the copy: all of them run as one multi-tensor launch (the parameter / copy addresses never change)."""
         r, c = src.shape
         d = dst[dst_row0:, dst_col0:]
         rp, cp = (c, r) if transpose else (r, c)
-        self._cast_list.append(hip.CastDesc(ptr(src), ptr(d), src.stride(0), r, c, dst.stride(0), rp, cp, int(transpose), 0))
+        self._cast_list.append(hip.CastDesc(ptr(src), ptr(d), src.stride(0), r, c, dst.stride(0), rp, cp, int(transpose), float(scale)))
 
     def invalidate_weights(self):
         """Call after writing parameters through an alias autograd's version counters cannot see (``p.data.op_()``, a raw
@@ -222,7 +229,9 @@ class FusionEngine:
         m, D, I, Ip = self.model, self.D, self.I, self.Ip
         for i, ly in enumerate(m.layers):
             w = self.wl[i]
-            self._cast(ly.attn.to_q.weight.data, w["qkv"])
+            # forward copy of W_q carries scale * log2(e): q.k comes out of the QKV GEMM as the log2-domain logit (the
+            # transposed copies used by the backward data-gradient GEMMs stay unscaled: mca_hip.h, MCA_ATTN_Q_PRESCALED)
+            self._cast(ly.attn.to_q.weight.data, w["qkv"], scale=self.q_scale)
             self._cast(ly.attn.to_kv.weight.data, w["qkv"], dst_row0=D)
             self._cast(ly.attn.to_q.weight.data, w["qkvT"], transpose=True)
             self._cast(ly.attn.to_kv.weight.data, w["qkvT"], transpose=True, dst_col0=D)
@@ -237,7 +246,7 @@ class FusionEngine:
             self._cast(w2, w["w2"])
             self._cast(w2, w["w2T"], transpose=True)
         ap = m.attn_pool
-        self._cast(ap.to_q.weight.data, self.wp["q"]); self._cast(ap.to_q.weight.data, self.wp["qT"], transpose=True)
+        self._cast(ap.to_q.weight.data, self.wp["q"], scale=self.q_scale); self._cast(ap.to_q.weight.data, self.wp["qT"], transpose=True)
         self._cast(ap.to_kv.weight.data, self.wp["kv"]); self._cast(ap.to_kv.weight.data, self.wp["kvT"], transpose=True)
         self._cast(ap.to_out.weight.data, self.wp["o"]); self._cast(ap.to_out.weight.data, self.wp["oT"], transpose=True)
         for name in m.modality_types:
@@ -287,8 +296,9 @@ class FusionEngine:
         ws["dg"], ws["do"] = bf(T, Ip), bf(T, D)
         # fp32 dQ accumulators, one per layer: all of them are zeroed by ONE memset on the side stream at the start of the
         # backward (beside the pooling backward) instead of a 166 MB memset in front of every layer's attention backward
-        ws["dq32_all"] = f32(max(self.L, 1), T, D)
-        ws["dq32"] = ws["dq32_all"][0]
+        if not self.attn_bwd_two_pass:
+            ws["dq32_all"] = f32(max(self.L, 1), T, D)
+            ws["dq32"] = ws["dq32_all"][0]
         ws["dq32_zero_event"] = torch.cuda.Event()
         ws["dpool_b"], ws["dop"], ws["dqp32"], ws["dqp_sum"], ws["dqp_b"] = bf(b * R, D), bf(b * R, D), f32(b * R, D), f32(R, D), bf(R, D)
         ws["dkvp"], ws["drt"] = bf(T, 2 * D), f32(R, D)
@@ -379,10 +389,38 @@ class FusionEngine:
         a.q_ptr, a.q_kt, a.q_order = sched.q_ptr.data_ptr(), sched.q_kt.data_ptr(), sched.q_order.data_ptr()
         a.vmean = ws["vmean"].data_ptr()
         a.batch, a.heads, a.nq, a.nk, a.nk_pad = b, self.H, nq, N, self.nk_pad
-        a.n_qtiles, a.n_ktiles, a.scale = sched.s.n_q, sched.s.n_k, self.scale
+        a.n_qtiles, a.n_ktiles, a.scale, a.flags = sched.s.n_q, sched.s.n_k, self.scale, self.attn_flags
         call("mca_attn_vmean", a.v, a.kv_bstride, a.kv_ld, ws["vmean"].data_ptr(), b, N, self.H, stream_ptr())
         hip.set_tag("pool" if nq != N else "layer")
         call("mca_attn_fwd", C.byref(a), stream_ptr(), flops=4.0 * 64 * sched.s.allowed_pairs * self.H * b)
+        hip.set_tag("")
+
+    def _attn_bwd2(self, q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, d_o, lse, delta, dq_ptr, dq_bstride, dq_ld, dq_f32, dkv,
+                   dk_off, dv_off, dkv_ld, qmask, sched_f, sched_b, ws, b, nq):
+        """two-pass backward (attention_bwd2.hip): dq (bf16 or fp32) is WRITTEN, not accumulated."""
+        N, esz = self.N, 2
+        call("mca_attn_bwd_prep", o.data_ptr(), d_o.data_ptr(), nq * o.stride(0), o.stride(0), lse.data_ptr(),
+             delta.data_ptr(), ws["dvmean"].data_ptr(), b, self.H, nq, N, stream_ptr())
+        a = AttnBwd2Args()
+        a.q, a.q_bstride, a.q_ld = q, q_bstride, q_ld
+        a.k, a.v = kv.data_ptr() + k_off * esz, kv.data_ptr() + v_off * esz
+        a.kv_bstride, a.kv_ld = N * kv_ld, kv_ld
+        a.d_o, a.o_bstride, a.o_ld = d_o.data_ptr(), nq * d_o.stride(0), d_o.stride(0)
+        a.lse, a.delta, a.dvmean = lse.data_ptr(), delta.data_ptr(), ws["dvmean"].data_ptr()
+        a.dq, a.dq_bstride, a.dq_ld, a.dq_f32 = dq_ptr, dq_bstride, dq_ld, int(dq_f32)
+        a.dk, a.dv = dkv.data_ptr() + dk_off * esz, dkv.data_ptr() + dv_off * esz
+        a.dkv_bstride, a.dkv_ld = N * dkv_ld, dkv_ld
+        a.qmask, a.keyinfo, a.ktile_flags = qmask.data_ptr(), ws["keyinfo"].data_ptr(), ws["kflags"].data_ptr()
+        a.q_ptr, a.q_kt, a.q_order = sched_f.q_ptr.data_ptr(), sched_f.q_kt.data_ptr(), sched_f.q_order.data_ptr()
+        a.n_qtiles128, a.n_ktiles64 = sched_f.s.n_q, sched_f.s.n_k
+        a.k_wg, a.k_qt, a.n_qtiles64, a.n_kblocks256 = sched_b.k_wg.data_ptr(), sched_b.k_qt.data_ptr(), sched_b.s.n_q, sched_b.s.n_k
+        a.batch, a.heads, a.nq, a.nk, a.nk_pad, a.scale, a.flags = b, self.H, nq, N, self.nk_pad, self.scale, self.attn_flags
+        pairs = sched_b.s.allowed_pairs
+        hip.set_tag("pool" if nq != N else "layer")
+        # algorithmic flops of the whole backward (2 x forward) split 3 : 5 over the passes by their share of the five
+        # products a one-pass backward needs (dq pass: S, dP, dQ minus the recomputed S, dP counted once)
+        call("mca_attn_bwd_dkv", C.byref(a), stream_ptr(), flops=8.0 * 64 * pairs * self.H * b * 0.6)
+        call("mca_attn_bwd_dq", C.byref(a), stream_ptr(), flops=8.0 * 64 * pairs * self.H * b * 0.4)
         hip.set_tag("")
 
     def _attn_bwd(self, q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, d_o, lse, delta, dq, dq_bstride, dkv, dk_off,
@@ -404,7 +442,7 @@ class FusionEngine:
         a.k_ptr, a.k_qt, a.k_order = sched.k_ptr.data_ptr(), sched.k_qt.data_ptr(), sched.k_order.data_ptr()
         a.k_wg = sched.k_wg.data_ptr()
         a.batch, a.heads, a.nq, a.nk, a.nk_pad = b, self.H, nq, N, self.nk_pad
-        a.n_qtiles, a.n_ktiles, a.scale = sched.s.n_q, sched.s.n_k, self.scale
+        a.n_qtiles, a.n_ktiles, a.scale, a.flags = sched.s.n_q, sched.s.n_k, self.scale, self.attn_flags
         hip.set_tag("pool" if nq != N else "layer")
         call("mca_attn_bwd", C.byref(a), stream_ptr(), flops=8.0 * 64 * sched.s.allowed_pairs * self.H * b)
         hip.set_tag("")
@@ -645,7 +683,7 @@ class FusionEngine:
         def on_side(fn):
             side(fn, slot[0], ws); slot[0] += 1
 
-        if self.L and self.zero_dq_once:          # all dQ accumulators zeroed beside the pooling backward (inline when nothing runs on the side stream)
+        if self.L and self.zero_dq_once and not self.attn_bwd_two_pass:          # all dQ accumulators zeroed beside the pooling backward (inline when nothing runs on the side stream)
             on_side(lambda: (ws["dq32_all"].zero_(), ws["dq32_zero_event"].record(torch.cuda.current_stream())))
         # pooled = op @ Wo^T + return_tokens
         call("mca_reduce_rows", ptr(dpool), D, R * D, R, ptr(G(m.return_tokens)), D, b * R, D, stream_ptr())
@@ -653,9 +691,14 @@ class FusionEngine:
         self.gemm_nt(ws["dpool_b"], self.wp["oT"], ws["dop"], b * R, D, D)
         on_side(lambda: tn(ws["dpool_b"], ws["op"], G(ap.to_out.weight), b * R, D, D))
         # pooling attention
-        ws["dqp32"].zero_()
-        self._attn_bwd(ws["qp"].data_ptr(), 0, D, ws["kvp"], 0, D, 2 * D, ws["op"], ws["dop"], ws["lse_p"], ws["delta_p"],
-                       ws["dqp32"], R * D, ws["dkvp"], 0, D, 2 * D, self.qmask_pool, self.sched_pool_b, ws, b, R)
+        if self.attn_bwd_two_pass:
+            self._attn_bwd2(ws["qp"].data_ptr(), 0, D, ws["kvp"], 0, D, 2 * D, ws["op"], ws["dop"], ws["lse_p"], ws["delta_p"],
+                            ws["dqp32"].data_ptr(), R * D, D, True, ws["dkvp"], 0, D, 2 * D, self.qmask_pool, self.sched_pool_f,
+                            self.sched_pool_b, ws, b, R)
+        else:
+            ws["dqp32"].zero_()
+            self._attn_bwd(ws["qp"].data_ptr(), 0, D, ws["kvp"], 0, D, 2 * D, ws["op"], ws["dop"], ws["lse_p"], ws["delta_p"],
+                           ws["dqp32"], R * D, ws["dkvp"], 0, D, 2 * D, self.qmask_pool, self.sched_pool_b, ws, b, R)
         ws["dqp_sum"].zero_()
         call("mca_reduce_rows", ptr(ws["dqp32"]), D, R * D, R, ptr(ws["dqp_sum"]), D, b * R, D, stream_ptr())
         call("mca_f32_to_bf16", ptr(ws["dqp_sum"]), D, ptr(ws["dqp_b"]), D, R, D, 1.0, stream_ptr())
@@ -695,14 +738,20 @@ class FusionEngine:
             # x1 = o @ Wo^T + xn
             on_side(lambda dx1=dx1, a=a, ly=ly: tn(dx1, a["o"], G(ly.attn.to_out.weight), T, D, D))
             self.gemm_nt(dx1, w["oT"], ws["do"], T, D, D)
-            dq32 = ws["dq32_all"][i]
-            if not self.zero_dq_once:
-                dq32.zero_()
-            elif bi == 0:
-                torch.cuda.current_stream().wait_event(ws["dq32_zero_event"])
-            self._attn_bwd(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], ws["do"], a["lse"],
-                           ws["delta"], dq32, N * D, dqkv, D, 2 * D, 3 * D, self.qmask_attn, self.sched_attn_b, ws, b, N)
-            call("mca_f32_to_bf16", ptr(dq32), D, ptr(dqkv), 3 * D, T, D, 1.0, stream_ptr())
+            if self.attn_bwd_two_pass:
+                # dq | dk | dv land in dqkv as bf16, each element written once
+                self._attn_bwd2(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], ws["do"], a["lse"],
+                                ws["delta"], dqkv.data_ptr(), N * 3 * D, 3 * D, False, dqkv, D, 2 * D, 3 * D, self.qmask_attn,
+                                self.sched_attn_f, self.sched_attn_b, ws, b, N)
+            else:
+                dq32 = ws["dq32_all"][i]
+                if not self.zero_dq_once:
+                    dq32.zero_()
+                elif bi == 0:
+                    torch.cuda.current_stream().wait_event(ws["dq32_zero_event"])
+                self._attn_bwd(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], ws["do"], a["lse"],
+                               ws["delta"], dq32, N * D, dqkv, D, 2 * D, 3 * D, self.qmask_attn, self.sched_attn_b, ws, b, N)
+                call("mca_f32_to_bf16", ptr(dq32), D, ptr(dqkv), 3 * D, T, D, 1.0, stream_ptr())
             # to_q.weight and to_kv.weight are adjacent in the flat gradient buffer: one (3D, D) weight-gradient GEMM
             gq = G(ly.attn.to_q.weight)
             assert G(ly.attn.to_kv.weight).data_ptr() == gq.data_ptr() + D * D * 4

@@ -28,7 +28,7 @@ class LossTerm(C.Structure):
 
 class CastDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("lds", C.c_int64), ("rows", C.c_int64), ("cols", C.c_int64),
-                ("ldd", C.c_int64), ("rows_pad", C.c_int64), ("cols_pad", C.c_int64), ("transpose", C.c_int32), ("pad_", C.c_int32)]
+                ("ldd", C.c_int64), ("rows_pad", C.c_int64), ("cols_pad", C.c_int64), ("transpose", C.c_int32), ("scale", C.c_float)]
 
 
 MAX_MODALITIES = 16
@@ -62,8 +62,11 @@ class AttnFwdArgs(C.Structure):
         ("q_ptr", C.c_void_p), ("q_kt", C.c_void_p), ("q_order", C.c_void_p),
         ("vmean", C.c_void_p),
         ("batch", C.c_int), ("heads", C.c_int), ("nq", C.c_int), ("nk", C.c_int), ("nk_pad", C.c_int),
-        ("n_qtiles", C.c_int), ("n_ktiles", C.c_int), ("scale", C.c_float),
+        ("n_qtiles", C.c_int), ("n_ktiles", C.c_int), ("scale", C.c_float), ("flags", C.c_int),
     ]
+
+
+ATTN_Q_PRESCALED = 1
 
 
 class AttnBwdArgs(C.Structure):
@@ -78,7 +81,23 @@ class AttnBwdArgs(C.Structure):
         ("k_ptr", C.c_void_p), ("k_qt", C.c_void_p), ("k_order", C.c_void_p),
         ("batch", C.c_int), ("heads", C.c_int), ("nq", C.c_int), ("nk", C.c_int), ("nk_pad", C.c_int),
         ("n_qtiles", C.c_int), ("n_ktiles", C.c_int), ("scale", C.c_float),
-        ("k_wg", C.c_void_p),
+        ("k_wg", C.c_void_p), ("flags", C.c_int),
+    ]
+
+
+class AttnBwd2Args(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("q_bstride", C.c_int64), ("q_ld", C.c_int64),
+        ("k", C.c_void_p), ("v", C.c_void_p), ("kv_bstride", C.c_int64), ("kv_ld", C.c_int64),
+        ("d_o", C.c_void_p), ("o_bstride", C.c_int64), ("o_ld", C.c_int64),
+        ("lse", C.c_void_p), ("delta", C.c_void_p), ("dvmean", C.c_void_p),
+        ("dq", C.c_void_p), ("dq_bstride", C.c_int64), ("dq_ld", C.c_int64), ("dq_f32", C.c_int),
+        ("dk", C.c_void_p), ("dv", C.c_void_p), ("dkv_bstride", C.c_int64), ("dkv_ld", C.c_int64),
+        ("qmask", C.c_void_p), ("keyinfo", C.c_void_p), ("ktile_flags", C.c_void_p),
+        ("q_ptr", C.c_void_p), ("q_kt", C.c_void_p), ("q_order", C.c_void_p), ("n_qtiles128", C.c_int), ("n_ktiles64", C.c_int),
+        ("k_wg", C.c_void_p), ("k_qt", C.c_void_p), ("n_qtiles64", C.c_int), ("n_kblocks256", C.c_int),
+        ("batch", C.c_int), ("heads", C.c_int), ("nq", C.c_int), ("nk", C.c_int), ("nk_pad", C.c_int),
+        ("scale", C.c_float), ("flags", C.c_int),
     ]
 
 
@@ -111,6 +130,8 @@ SIGNATURES = {
     "mca_attn_fwd": (_I, [C.POINTER(AttnFwdArgs), _P]),
     "mca_attn_bwd_prep": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mca_attn_bwd": (_I, [C.POINTER(AttnBwdArgs), _P]),
+    "mca_attn_bwd_dq": (_I, [C.POINTER(AttnBwd2Args), _P]),
+    "mca_attn_bwd_dkv": (_I, [C.POINTER(AttnBwd2Args), _P]),
     "mca_contrastive_workspace_bytes": (_I64, [_I, _I]),
     "mca_contrastive_fwd_bwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "mca_grad_sqnorm": (_I, [_P, _I64, _P, _P]),

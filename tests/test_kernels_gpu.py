@@ -332,7 +332,14 @@ def dense_attention(q, k, v, allowed, pad, scale):
     return torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v)
 
 
-def _attention_case(H, st, b, heads, pool, seed, drop_first):
+C2 = 0.125 * 1.4426950408889634          # scale * log2(e): what the engine folds into the forward copy of W_q
+
+
+def _attention_case(H, st, b, heads, pool, seed, drop_first, prescaled=True, spike=False):
+    """prescaled: the q operand in memory is q' = bf16(q * scale * log2 e) (MCA_ATTN_Q_PRESCALED, the production form); the
+    dense reference sees q = q' / (scale * log2 e), and dq is the gradient w.r.t. that q.  spike: a few keys 40x larger, so
+    that the lazy softmax reference of the forward kernel has to move mid-row (at a row's later tiles, up and from a very
+    negative start) - cdna guide rule 26: a rare data-dependent branch needs an input that forces it."""
     eng = importlib.import_module("mca-paper_amd.engine")
     N, D = st.n_tokens, heads * 64
     dev = "cuda"
@@ -353,12 +360,18 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first):
             ln[0] = 0
         pad[:, off:off + n] = torch.arange(n, device=dev)[None] >= ln[:, None]
         off += n
-    qkv = bf(torch.randn(b, N, 3 * D, device=dev, generator=g))
+    qkv = torch.randn(b, N, 3 * D, device=dev, generator=g)
+    if spike:
+        for j in (3, 70, 131, N - 2):
+            qkv[:, j, D:2 * D] *= 40.0
+    qkv = bf(qkv)
+    qdiv = C2 if prescaled else 1.0          # what the stored q operand has to be divided by to get the reference's q
     if pool:
-        qsrc = bf(torch.randn(nq, D, device=dev, generator=g))
-        q4 = qsrc.float().view(1, nq, heads, 64).permute(0, 2, 1, 3).expand(b, -1, -1, -1)
+        qsrc = bf(torch.randn(nq, D, device=dev, generator=g) * qdiv)
+        q4 = (qsrc.float() / qdiv).view(1, nq, heads, 64).permute(0, 2, 1, 3).expand(b, -1, -1, -1)
     else:
-        q4 = qkv[:, :, :D].float().view(b, N, heads, 64).permute(0, 2, 1, 3)
+        qkv[:, :, :D] = bf(qkv[:, :, :D].float() * qdiv)
+        q4 = (qkv[:, :, :D].float() / qdiv).view(b, N, heads, 64).permute(0, 2, 1, 3)
     k4 = qkv[:, :, D:2 * D].float().view(b, N, heads, 64).permute(0, 2, 1, 3)
     v4 = qkv[:, :, 2 * D:].float().view(b, N, heads, 64).permute(0, 2, 1, 3)
     q4r, k4r, v4r = (t.double().clone().requires_grad_(True) for t in (q4, k4, v4))
@@ -389,6 +402,7 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first):
     a.q_ptr, a.q_kt, a.q_order = sf.q_ptr.data_ptr(), sf.q_kt.data_ptr(), sf.q_order.data_ptr()
     a.vmean = vmean.data_ptr()
     a.batch, a.heads, a.nq, a.nk, a.nk_pad, a.n_qtiles, a.n_ktiles, a.scale = b, heads, nq, N, nk_pad, sf.s.n_q, sf.s.n_k, 0.125
+    a.flags = H.ATTN_Q_PRESCALED if prescaled else 0
     H.call("mca_attn_fwd", C.byref(a), H.stream_ptr())
     torch.cuda.synchronize()
     got_o = o.float().view(b, nq, D)
@@ -421,6 +435,7 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first):
     ab.qmask, ab.keyinfo, ab.ktile_flags = qmask.data_ptr(), keyinfo.data_ptr(), kflags.data_ptr()
     ab.k_ptr, ab.k_qt, ab.k_order = sb.k_ptr.data_ptr(), sb.k_qt.data_ptr(), sb.k_order.data_ptr()
     ab.batch, ab.heads, ab.nq, ab.nk, ab.nk_pad, ab.n_qtiles, ab.n_ktiles, ab.scale = b, heads, nq, N, nk_pad, sb.s.n_q, sb.s.n_k, 0.125
+    ab.flags = a.flags
     H.call("mca_attn_bwd", C.byref(ab), H.stream_ptr())
     torch.cuda.synchronize()
     rdq = q4r.grad.permute(0, 2, 1, 3).reshape(b, nq, D)
@@ -429,6 +444,35 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first):
     e_q, e_k, e_v = rel(dq, rdq), rel(dkv[:, :, D:2 * D].float(), rdk), rel(dkv[:, :, 2 * D:].float(), rdv)
     assert e_q < 1.5e-2 and e_k < 1.5e-2 and e_v < 1.5e-2, f"attention backward rel err dq {e_q} dk {e_k} dv {e_v}"
 
+    # ---- the same backward in two passes without atomics (production path): dq written once (bf16 and fp32 forms)
+    for dq_f32 in (False, True):
+        dq2 = torch.full((b, nq, D), 7.0, device=dev, dtype=torch.float32 if dq_f32 else torch.bfloat16)          # no pre-zeroing needed
+        dkv2 = torch.zeros(b, N, 3 * D, dtype=torch.bfloat16, device=dev)
+        a2 = H.AttnBwd2Args()
+        a2.q, a2.q_bstride, a2.q_ld = a.q, a.q_bstride, a.q_ld
+        a2.k, a2.v, a2.kv_bstride, a2.kv_ld = a.k, a.v, a.kv_bstride, a.kv_ld
+        a2.d_o, a2.o_bstride, a2.o_ld = d_o.data_ptr(), nq * D, D
+        a2.lse, a2.delta, a2.dvmean = lse.data_ptr(), delta.data_ptr(), dvmean.data_ptr()
+        a2.dq, a2.dq_bstride, a2.dq_ld, a2.dq_f32 = dq2.data_ptr(), nq * D, D, int(dq_f32)
+        a2.dk, a2.dv, a2.dkv_bstride, a2.dkv_ld = dkv2.data_ptr() + D * 2, dkv2.data_ptr() + 2 * D * 2, N * 3 * D, 3 * D
+        a2.qmask, a2.keyinfo, a2.ktile_flags = qmask.data_ptr(), keyinfo.data_ptr(), kflags.data_ptr()
+        a2.q_ptr, a2.q_kt, a2.q_order, a2.n_qtiles128, a2.n_ktiles64 = sf.q_ptr.data_ptr(), sf.q_kt.data_ptr(), sf.q_order.data_ptr(), sf.s.n_q, sf.s.n_k
+        a2.k_wg, a2.k_qt, a2.n_qtiles64, a2.n_kblocks256 = sb.k_wg.data_ptr(), sb.k_qt.data_ptr(), sb.s.n_q, sb.s.n_k
+        a2.batch, a2.heads, a2.nq, a2.nk, a2.nk_pad, a2.scale, a2.flags = b, heads, nq, N, nk_pad, 0.125, a.flags
+        H.call("mca_attn_bwd_dq", C.byref(a2), H.stream_ptr())
+        H.call("mca_attn_bwd_dkv", C.byref(a2), H.stream_ptr())
+        torch.cuda.synchronize()
+        e_q, e_k, e_v = rel(dq2.float(), rdq), rel(dkv2[:, :, D:2 * D].float(), rdk), rel(dkv2[:, :, 2 * D:].float(), rdv)
+        assert e_q < 1.5e-2 and e_k < 1.5e-2 and e_v < 1.5e-2, f"two-pass backward rel err dq {e_q} dk {e_k} dv {e_v} (dq_f32={dq_f32})"
+        assert (dkv2[:, :, :D] == 0).all()
+        # bitwise reproducible: a second launch gives the same bits
+        dq3 = torch.empty_like(dq2); dkv3 = torch.zeros_like(dkv2)
+        a2.dq, a2.dk, a2.dv = dq3.data_ptr(), dkv3.data_ptr() + D * 2, dkv3.data_ptr() + 2 * D * 2
+        H.call("mca_attn_bwd_dq", C.byref(a2), H.stream_ptr())
+        H.call("mca_attn_bwd_dkv", C.byref(a2), H.stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(dq2, dq3) and torch.equal(dkv2, dkv3)
+
 
 @pytest.mark.parametrize("variant,pool,drop", [("mca", False, False), ("mca", False, True), ("zorro", False, True),
                                                ("mca", True, True), ("zorro", True, False)])
@@ -436,6 +480,25 @@ def test_attention_small(H, variant, pool, drop):
     S = importlib.import_module("mca-paper_amd.structure")
     st = S.FusionStructure([70, 45, 30], 8, (3, 2), fcl=variant == "mca", zorro=variant == "zorro")
     _attention_case(H, st, b=3, heads=2, pool=pool, seed=11, drop_first=drop)
+
+
+@pytest.mark.parametrize("form", ["unscaled", "first-form"])
+def test_attention_other_forms(H, form):
+    """the un-prescaled entry of the production forward kernel, and the first-form forward kernel (knob 13) kept for A/B and
+    the conservative cross-check: same contract."""
+    S = importlib.import_module("mca-paper_amd.structure")
+    st = S.FusionStructure([70, 45, 30], 8, (3, 2), fcl=True)
+    with H.knobs(k13=1 if form == "first-form" else 0):
+        _attention_case(H, st, b=3, heads=2, pool=False, seed=11, drop_first=True, prescaled=False)
+
+
+@pytest.mark.parametrize("prescaled", [True, False])
+def test_attention_lazy_reference_moves(H, prescaled):
+    """keys 40x larger than their neighbours in the first, second and third key tile of a row and at the very end: the lazy
+    reference of the forward softmax has to move at a row's first tile, grow later, and start from scores far below zero."""
+    S = importlib.import_module("mca-paper_amd.structure")
+    st = S.FusionStructure([300, 100, 60], 8, (3, 2), fcl=True)
+    _attention_case(H, st, b=2, heads=2, pool=False, seed=17, drop_first=True, prescaled=prescaled, spike=True)
 
 
 @pytest.mark.parametrize("variant,pool", [("mca", False), ("zorro", False), ("mca", True)])

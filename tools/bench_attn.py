@@ -1,9 +1,11 @@
-"""Times the layer attention kernels (fwd, bwd) on the CMU structure at b=32, H=8."""
+"""Times the layer attention kernels (fwd, bwd) on the CMU structure at b=32, H=8 (or LONG with argv[2] == long)."""
 import importlib, os, sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 P = importlib.import_module("mca-paper_amd"); H = importlib.import_module("mca-paper_amd.hip"); E = importlib.import_module("mca-paper_amd.engine")
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-cfg = P.config.cmu_model_config(batch_size=b)
+long_seq = len(sys.argv) > 2 and sys.argv[2] == "long"
+cfg = P.config.cmu_model_config(batch_size=b, long_seq=long_seq)
+cfg["depth"] = 1
 torch.manual_seed(0)
 model = P.MCA(**cfg).cuda(); eng = model.engine
 ws = eng.workspace(b)
@@ -12,20 +14,24 @@ ws["padding"].zero_()
 H.call("mca_build_keyinfo", ws["padding"].data_ptr(), eng.kgroup.data_ptr(), ws["keyinfo"].data_ptr(), ws["kflags"].data_ptr(), b, N, eng.nk_pad, H.stream_ptr())
 a = ws["layers"][0]
 a["qkv"].copy_(torch.randn_like(a["qkv"].float()).bfloat16())
+a["qkv"][:, :D] *= 0.18          # q as the engine stores it (scale * log2 e folded in)
 ws["do"].copy_(torch.randn_like(ws["do"].float()).bfloat16())
 def fwd(): eng._attn_fwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], a["lse"], eng.qmask_attn, eng.sched_attn_f, ws, b, N)
 def bwd():
-    ws["dq32"].zero_()
-    eng._attn_bwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], ws["do"], a["lse"], ws["delta"], ws["dq32"], N*D, a["dqkv"], D, 2*D, 3*D, eng.qmask_attn, eng.sched_attn_b, ws, b, N)
+    eng._attn_bwd_layer(ws, a, b) if hasattr(eng, "_attn_bwd_layer") else (ws["dq32"].zero_(), eng._attn_bwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], ws["do"], a["lse"], ws["delta"], ws["dq32"], N*D, a["dqkv"], D, 2*D, 3*D, eng.qmask_attn, eng.sched_attn_b, ws, b, N))
 def timeit(fn, n=10):
     for _ in range(3): fn()
     torch.cuda.synchronize()
-    H.profile_start(("mca_attn_fwd", "mca_attn_bwd"))
+    H.profile_start(("mca_attn_fwd", "mca_attn_bwd", "mca_attn_bwd_dq", "mca_attn_bwd_dkv"))
     for _ in range(n): fn()
     return H.profile_stop()
-for nm, fn, knob in (("fwd", fwd, 0), ("bwd", bwd, 0), ("bwd no-atomics", bwd, 1)):
-    H.lib().mca_debug_set(6, knob)
-    r = timeit(fn)
+cases = [("fwd first form", fwd, {13: 2}), ("fwd", fwd, {}), ("bwd", bwd, {})]
+if os.environ.get("MCA_BENCH_ATTN_EXTRA"):
+    cases += [("bwd no-atomics", bwd, {6: 1})]
+for nm, fn, knobs in cases:
+    with H.knobs(**{f"k{k}": v for k, v in knobs.items()}):
+        r = timeit(fn)
     print(nm, end=" -> ")
     for k, (n, ms, fl) in r.items():
-        print(f"{k}: {ms/n*1e3:.1f} us  {fl/ms/1e9:.1f} TF/s algorithmic ({fl/ms/1e9/2500*100:.1f}% of MFMA peak)")
+        print(f"{k}: {ms/n*1e3:.1f} us  {fl/ms/1e9:.1f} TF/s algorithmic ({fl/ms/1e9/2500*100:.1f}% of MFMA peak)", end="  ")
+    print(flush=True)
