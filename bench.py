@@ -40,7 +40,8 @@ def pmc_traffic(kernel_key: str):
     committed for that kernel."""
     path = os.path.join(REPO, PMC_JSON)
     names = {"mca_gemm_nt": "gemm_nt_", "mca_gemm_tn_acc": "gemm_tn_", "mca_gemm_tn_acc_group": "gemm_tn_256x256_group_kernel",
-             "mca_attn_fwd/layer": "attn_fwd", "mca_attn_bwd/layer": "attn_bwd", "mca_gemm_nt_geglu_fwd": "gemm_nt_persist256_kernel<true>",
+             "mca_attn_fwd/layer": "attn_fwd", "mca_attn_bwd/layer": "attn_bwd_kernel", "mca_attn_bwd_dkv/layer": "attn_bwd_dkv",
+             "mca_attn_bwd_dq/layer": "attn_bwd_dq", "mca_gemm_nt_geglu_fwd": "gemm_nt_persist256_kernel<true>",
              "mca_gemm_nt_geglu_bwd": "gemm_nt_persist_kernel<3", "mca_gemm_nt_lnres": "gemm_nt_256_kernel<false, 1, 1, 2>"}
     if not os.path.exists(path) or kernel_key not in names:
         return None
@@ -192,7 +193,7 @@ def main():
             eng.overlap_wgrad, eng.micro_batches = False, 1
         step()
         eng.overlap_wgrad, eng.micro_batches = saved
-    timed = ("mca_attn_fwd", "mca_attn_bwd", "mca_gemm_nt", "mca_gemm_nt_lnres", "mca_gemm_nt_geglu_fwd", "mca_gemm_nt_geglu_bwd",
+    timed = ("mca_attn_fwd", "mca_attn_bwd", "mca_attn_bwd_dq", "mca_attn_bwd_dkv", "mca_gemm_nt", "mca_gemm_nt_lnres", "mca_gemm_nt_geglu_fwd", "mca_gemm_nt_geglu_bwd",
              "mca_gemm_tn_acc", "mca_gemm_tn_acc_group")
     kernel_timing = not args.no_kernel_timing and not args.graph
     if world > 1:

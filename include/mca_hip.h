@@ -276,7 +276,11 @@ int mca_grad_sqnorm(const float* g, int64_t n, float* sqnorm, mca_stream_t strea
 int mca_adamw_step(float* p, const float* g, float* m, float* v, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay,
                    float bias_corr1, float bias_corr2, float max_norm, const float* sqnorm,
-                   const int32_t* skip_flag, mca_stream_t stream);
+                   const int32_t* skip_flag, const float* hyper, mca_stream_t stream);
+/* hyper (may be NULL): three device floats {lr, bias_corr1, bias_corr2} that replace the scalar arguments, so that a step
+ * captured in a hipGraph takes this step's learning rate and Adam bias corrections at REPLAY time; written by
+ * mca_adamw_hyper, a one-thread kernel launched outside the graph (scalar arguments: no host buffer to race with).      */
+int mca_adamw_hyper(float* hyper, float lr, float bias_corr1, float bias_corr2, mca_stream_t stream);
 
 #ifdef __cplusplus
 }

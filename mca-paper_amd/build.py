@@ -27,13 +27,17 @@ def needs_build() -> bool:
 TRACE_OUT = os.path.join(HERE, "libmca_hip_trace.so")
 
 
-def build_variant(out_path: str, defines=()) -> str:
-    """An A/B build of the same ABI with extra -D defines (tools/ab_lib_*.py load it through MCA_HIP_LIB)."""
+def build_variant(out_path: str, defines=(), only=None) -> str:
+    """An A/B build of the same ABI with extra -D defines (tools/ab_lib_*.py load it through MCA_HIP_LIB).  only: the sources the
+    defines affect; every other object is taken from the product build directory (run build() first)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     bdir = os.path.join(HERE, "build_" + os.path.splitext(os.path.basename(out_path))[0])
     os.makedirs(bdir, exist_ok=True)
     procs, objs = [], []
     for src in SOURCES:
+        if only is not None and src not in only:
+            objs.append(os.path.join(HERE, "build", src.replace(".hip", ".o")))
+            continue
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
         objs.append(obj)
         cmd = [hipcc, *FLAGS, *[f"-D{d}" for d in defines], *EXTRA.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]

@@ -20,6 +20,7 @@
 #define BKEYS 256   // dkv pass: keys per workgroup
 #define BQ 64       // dkv pass: query rows per step
 #define MAX_QTILES 2048
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 // [rows][64 d] bf16 image (128-byte rows) serving BOTH ds_read_b128 row reads and ds_read_b64_tr_b16 transposed reads
 __device__ __forceinline__ int rt_off(int r, int c) {
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(mca_attn_bwd2_args 
   __shared__ __attribute__((aligned(16))) u16 lds[2 * 2 * AK * DH];   // K,V double-buffered: 32 KiB
   __shared__ __attribute__((aligned(16))) uint8_t kinfo[2][AK];
   __shared__ uint8_t flags_s[MAX_KTILES];
-  __shared__ uint32_t live_s[MAX_KTILES];
+  __shared__ uint32_t live_s[MAX_KTILES + 2];
   __shared__ int n_live_s;
   u16* Ks = lds;
   u16* Vs = lds + 2 * AK * DH;
@@ -135,40 +136,82 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(mca_attn_bwd2_args 
     for (int i0 = lb; i0 < le; i0 += 64) {
       const int i = i0 + lane;
       const uint32_t e = i < le ? a.q_kt[i] : 0u;
-      const bool keep = i < le && flags_s[e & 0x7fffffffu] != 0;
+      const uint8_t fl = i < le ? flags_s[e & 0x7fffffffu] : (uint8_t)0;
+      const bool keep = fl != 0;
       const unsigned long long m = __ballot(keep);
-      if (keep) live_s[n + __popcll(m & ((1ull << lane) - 1ull))] = e;
+      // bit 31 = no element-wise mask needed (structurally full AND every key of the tile valid in this sample)
+      if (keep) live_s[n + __popcll(m & ((1ull << lane) - 1ull))] = (e & 0x7fffffffu) | ((e >> 31) && fl == 2 ? 0x80000000u : 0u);
       n += __popcll(m);
     }
-    if (lane == 0) n_live_s = n;
+    if (lane == 0) { n_live_s = n; live_s[n] = 0u; live_s[n + 1] = 0u; }
   }
   __syncthreads();
   const int it_end = n_live_s;
   int it = 0;
   int buf = 0;
-  if (it < it_end) { gload((int)(live_s[0] & 0x7fffffffu)); swrite(0); }
+  uint32_t e_cur = __builtin_amdgcn_readfirstlane(live_s[0]), e_nxt = __builtin_amdgcn_readfirstlane(live_s[1]);
+  if (it < it_end) { gload((int)(e_cur & 0x7fffffffu)); swrite(0); }
   __syncthreads();
 
+  // row-fragment addresses (bytes, LDS address space) of this lane's K / V rows: buffer 0, key block 0 (block 1: +4096 bytes,
+  // buffer 1: +8192; the swizzles of both images depend on the row modulo 16 only)
+  unsigned kaddr[4], vaddr[4];
+  {
+    const unsigned kb_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const u16*)Ks;
+    const unsigned vb_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const u16*)Vs;
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+      kaddr[st] = kb_lds + 2u * (unsigned)rt_off(l31, 2 * st + lh);
+      vaddr[st] = vb_lds + 2u * (unsigned)row_off(l31, 2 * st + lh);
+    }
+  }
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
   while (it < it_end) {
-    const uint32_t ent = live_s[it];
-    const int kt = (int)(ent & 0x7fffffffu);
-    const bool need_mask = (ent >> 31) == 0 || (flags_s[kt] != 2);
+    const int kt = (int)(e_cur & 0x7fffffffu);
+    const bool need_mask = (e_cur >> 31) == 0;
     const int nit = it + 1;
-    if (nit < it_end) gload((int)(live_s[nit] & 0x7fffffffu));
+    if (nit < it_end) gload((int)(e_nxt & 0x7fffffffu));
+    const uint32_t e_nn_v = live_s[it + 2];
 
     const u16* ks = Ks + buf * AK * DH;
-    const u16* vs = Vs + buf * AK * DH;
+    // S^T - lse and dP^T - delta: sixteen row fragments (K and V, four k-steps, two key blocks) through a rolling window of
+    // eight registers sets: a fragment's register is re-requested as soon as its MFMA has issued, every MFMA waits for exactly
+    // its own fragment (counted lgkmcnt; the compiler's form was read, wait, MFMA sixteen times in a row)
     f32x16 s[2], dp[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++) {
-#pragma unroll
-      for (int st = 0; st < 4; st++) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + rt_off(kb * 32 + l31, 2 * st + lh));
-        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs + row_off(kb * 32 + l31, 2 * st + lh));
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], st == 0 ? sinit : s[kb], 0, 0, 0);
-        dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[st], st == 0 ? negdel : dp[kb], 0, 0, 0);
-      }
+    {
+      const unsigned bo = (unsigned)buf * (unsigned)(AK * DH * 2);
+      u32x4v f[8];
+      __builtin_amdgcn_sched_barrier(0);
+#define DQ_READ(I, ST, KB, ISV) DQ_DSREAD128(f[I], (ISV ? vaddr[ST] : kaddr[ST]) + bo, KB)
+#define DQ_DSREAD128(dst, addr, KB) do { if (KB) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(dst) : "v"(addr)); \
+                                         else asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); } while (0)
+      // fragment order = MFMA order: (st, K kb0), (st, V kb0), (st, K kb1), (st, V kb1)
+      DQ_READ(0, 0, 0, 0); DQ_READ(1, 0, 0, 1); DQ_READ(2, 0, 1, 0); DQ_READ(3, 0, 1, 1);
+      DQ_READ(4, 1, 0, 0); DQ_READ(5, 1, 0, 1); DQ_READ(6, 1, 1, 0); DQ_READ(7, 1, 1, 1);
+#define DQ_WAIT(N) do { asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define DQ_S(I, ST, KB) s[KB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&f[I]), qf[ST], ST == 0 ? sinit : s[KB], 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+#define DQ_P(I, ST, KB) dp[KB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&f[I]), dof[ST], ST == 0 ? negdel : dp[KB], 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+      DQ_WAIT(7); DQ_S(0, 0, 0); DQ_READ(0, 2, 0, 0);
+      DQ_WAIT(7); DQ_P(1, 0, 0); DQ_READ(1, 2, 0, 1);
+      DQ_WAIT(7); DQ_S(2, 0, 1); DQ_READ(2, 2, 1, 0);
+      DQ_WAIT(7); DQ_P(3, 0, 1); DQ_READ(3, 2, 1, 1);
+      DQ_WAIT(7); DQ_S(4, 1, 0); DQ_READ(4, 3, 0, 0);
+      DQ_WAIT(7); DQ_P(5, 1, 0); DQ_READ(5, 3, 0, 1);
+      DQ_WAIT(7); DQ_S(6, 1, 1); DQ_READ(6, 3, 1, 0);
+      DQ_WAIT(7); DQ_P(7, 1, 1); DQ_READ(7, 3, 1, 1);
+      DQ_WAIT(7); DQ_S(0, 2, 0);
+      DQ_WAIT(6); DQ_P(1, 2, 0);
+      DQ_WAIT(5); DQ_S(2, 2, 1);
+      DQ_WAIT(4); DQ_P(3, 2, 1);
+      DQ_WAIT(3); DQ_S(4, 3, 0);
+      DQ_WAIT(2); DQ_P(5, 3, 0);
+      DQ_WAIT(1); DQ_S(6, 3, 1);
+      DQ_WAIT(0); DQ_P(7, 3, 1);
+#undef DQ_S
+#undef DQ_P
+#undef DQ_WAIT
+#undef DQ_READ
+#undef DQ_DSREAD128
     }
     if (!PRESCALED) {
 #pragma unroll
@@ -227,6 +270,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(mca_attn_bwd2_args 
     __syncthreads();
     buf ^= 1;
     it = nit;
+    e_cur = e_nxt;
+    e_nxt = __builtin_amdgcn_readfirstlane(e_nn_v);
   }
 
   // ---- epilogue: dq = scale * dS K (gradient w.r.t. the unscaled q), one owner per element
@@ -281,6 +326,7 @@ extern "C" int mca_attn_bwd_dq(const mca_attn_bwd2_args* a, mca_stream_t stream)
 // 64-query steps the structure allows for the block; the key sits on the MFMA lane, so P and dS are directly the B operands
 // of the dV^T / dK^T products (guide, Appendix B "Attention backward").  Q / dO tiles in one LDS image for row AND column reads.
 // =====================================================================================================
+template <bool PRESCALED>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a, int dbg) {
   extern __shared__ __attribute__((aligned(16))) u16 lds[];
   u16* Qs = lds;                               // 2 x 64 x 64
@@ -299,9 +345,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
   const int key0 = kbi * BKEYS;
   const int mykey = key0 + wave * 32 + l31;
   int keyc = mykey; if (keyc > a.nk - 1) keyc = a.nk - 1;
-  const bool prescaled = (a.flags & MCA_ATTN_Q_PRESCALED) != 0;
-  const float c2 = prescaled ? 1.f : a.scale * 1.4426950408889634f, inv_c2 = 1.f / c2;
-  const float dk_scale = prescaled ? 0.6931471805599453f : a.scale;
+  // q pre-scaled by scale * log2(e): q.k is the log2-domain logit (no multiply per score), dK^T carries that factor
+  const float c2 = PRESCALED ? 1.f : a.scale * 1.4426950408889634f, inv_c2 = 1.f / c2;
+  const float dk_scale = PRESCALED ? 0.6931471805599453f : a.scale;
 
   const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
   const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
@@ -353,12 +399,26 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
   };
 
   if (n_it > 0) gload(first_qt);
+  // the K / V fragment loads are older than the first tile's: naming them as asm inputs here makes hipcc wait for them NOW
+  // (vmcnt counted against the first tile's three loads) instead of inside the loop, where its conservative vmcnt would make
+  // every step wait for the next tile's loads it has just issued
+#pragma unroll
+  for (int s4 = 0; s4 < 4; s4++) asm volatile("" :: "v"(kf[s4]), "v"(vf[s4]));
   for (int i = tid; i < n_it; i += 512) qlist[i] = a.k_qt[it_begin + i];
   if (tid < DH) dvm_s[tid] = a.dvmean[(int64_t)b * a.heads * DH + h * DH + tid];
   int buf = 0;
   if (n_it > 0) swrite(0);
   __syncthreads();
 
+  // row-fragment addresses (bytes, LDS address space) of this lane's Q / dO rows: buffer 0, sub-tile 0
+  unsigned qaddr[4], oaddr[4];
+  {
+    const unsigned q_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const u16*)Qs;
+    const unsigned o_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const u16*)Os;
+#pragma unroll
+    for (int st = 0; st < 4; st++) { qaddr[st] = q_lds + 2u * (unsigned)rt_off(l31, 2 * st + lh); oaddr[st] = o_lds + 2u * (unsigned)rt_off(l31, 2 * st + lh); }
+  }
+  const unsigned caddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)rowc + 16u * (unsigned)lh;
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
   for (int it = 0; it < n_it; it++) {
     const uint32_t ent = __builtin_amdgcn_readfirstlane(qlist[it]);          // wave-uniform: scalar branch on `full`
@@ -370,25 +430,41 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
       const u16* os = Os + buf * BQ * DH + sub * 32 * DH;
       const float* rc = rowc + buf * 192 + sub * 32;
       f32x16 s, dp;
+      {          // the row constants (accumulator start values) and the eight Q / dO row fragments of the sub-tile are requested
+                 // together, all by hand: a compiler-issued read in between would make hipcc wait lgkmcnt(0) at its first use,
+                 // i.e. for every fragment; every MFMA waits for exactly its own fragment
+        const unsigned so = (unsigned)buf * (unsigned)(BQ * DH * 2) + (unsigned)sub * (unsigned)(32 * DH * 2);
+        const unsigned co = caddr + (unsigned)(buf * 192 + sub * 32) * 4u;
+        u32x4v f[8], cl[4], cd[4];
+        __builtin_amdgcn_sched_barrier(0);
+#define KV_CREAD(DST, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(DST) : "v"(co))
+        KV_CREAD(cl[0], 0); KV_CREAD(cl[1], 32); KV_CREAD(cl[2], 64); KV_CREAD(cl[3], 96);
+        KV_CREAD(cd[0], 256); KV_CREAD(cd[1], 288); KV_CREAD(cd[2], 320); KV_CREAD(cd[3], 352);
+#undef KV_CREAD
+#define KV_READ(I, ADDR) asm volatile("ds_read_b128 %0, %1" : "=v"(f[I]) : "v"(ADDR + so))
+        KV_READ(0, qaddr[0]); KV_READ(1, oaddr[0]); KV_READ(2, qaddr[1]); KV_READ(3, oaddr[1]);
+        KV_READ(4, qaddr[2]); KV_READ(5, oaddr[2]); KV_READ(6, qaddr[3]); KV_READ(7, oaddr[3]);
+#define KV_WAIT(N) do { asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define KV_S(I, ST) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&f[I]), kf[ST], s, 0, 0, 0)
+#define KV_P(I, ST) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&f[I]), vf[ST], dp, 0, 0, 0)
+        KV_WAIT(7);          // fragment 0 is back, so are the eight older constant reads
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(rc + 8 * g + 4 * lh);
-        const f32x4 del4 = *reinterpret_cast<const f32x4*>(rc + 64 + 8 * g + 4 * lh);
+        for (int g = 0; g < 4; g++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) { s[4 * g + e] = lse4[e]; dp[4 * g + e] = del4[e]; }
-      }
-#pragma unroll
-      for (int st = 0; st < 4; st++) {
-        const bf16x8 qfrag = *reinterpret_cast<const bf16x8*>(qs + rt_off(l31, 2 * st + lh));
-        const bf16x8 ofrag = *reinterpret_cast<const bf16x8*>(os + rt_off(l31, 2 * st + lh));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfrag, kf[st], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofrag, vf[st], dp, 0, 0, 0);
+          for (int e = 0; e < 4; e++) { s[4 * g + e] = __uint_as_float(cl[g][e]); dp[4 * g + e] = __uint_as_float(cd[g][e]); }
+        KV_S(0, 0); KV_WAIT(6); KV_P(1, 0); KV_WAIT(5); KV_S(2, 1); KV_WAIT(4); KV_P(3, 1);
+        KV_WAIT(3); KV_S(4, 2); KV_WAIT(2); KV_P(5, 2); KV_WAIT(1); KV_S(6, 3); KV_WAIT(0); KV_P(7, 3);
+        __builtin_amdgcn_sched_barrier(0);
+#undef KV_READ
+#undef KV_WAIT
+#undef KV_S
+#undef KV_P
       }
       bf16x8 pb[2], sb[2];
       if (full && wave_keys_ok) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const float p0 = __builtin_amdgcn_exp2f(s[r] * c2), p1 = __builtin_amdgcn_exp2f(s[r + 1] * c2);
+          const float p0 = __builtin_amdgcn_exp2f(PRESCALED ? s[r] : s[r] * c2), p1 = __builtin_amdgcn_exp2f(PRESCALED ? s[r + 1] : s[r + 1] * c2);
           const uint32_t pp = pack2bf(p0, p1), ss = pack2bf(p0 * dp[r], p1 * dp[r + 1]);
           pb[r >> 3][r & 7] = (short)(pp & 0xffffu); pb[r >> 3][(r & 7) + 1] = (short)(pp >> 16);
           sb[r >> 3][r & 7] = (short)(ss & 0xffffu); sb[r >> 3][(r & 7) + 1] = (short)(ss >> 16);
@@ -401,7 +477,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
           for (int e = 0; e < 4; e += 2) {
             const int r = 4 * g + e;
             const uint32_t q0 = full ? 0xffffffffu : __float_as_uint(qm4[e]), q1 = full ? 0xffffffffu : __float_as_uint(qm4[e + 1]);
-            float p0 = __builtin_amdgcn_exp2f(s[r] * c2), p1 = __builtin_amdgcn_exp2f(s[r + 1] * c2);
+            float p0 = __builtin_amdgcn_exp2f(PRESCALED ? s[r] : s[r] * c2), p1 = __builtin_amdgcn_exp2f(PRESCALED ? s[r + 1] : s[r + 1] * c2);
             p0 = (q0 & keybit) ? p0 : 0.f; p1 = (q1 & keybit) ? p1 : 0.f;
             const uint32_t pp = pack2bf(p0, p1), ss = pack2bf(p0 * dp[r], p1 * dp[r + 1]);
             pb[r >> 3][r & 7] = (short)(pp & 0xffffu); pb[r >> 3][(r & 7) + 1] = (short)(pp >> 16);
@@ -465,10 +541,13 @@ extern "C" int mca_attn_bwd_dkv(const mca_attn_bwd2_args* a, mca_stream_t stream
   if (a->n_qtiles64 > MAX_QTILES) return MCA_E_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES) != hipSuccess)
       return MCA_E_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(a->n_kblocks256, a->heads, a->batch), dim3(512), DKV_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
+  const dim3 grid(a->n_kblocks256, a->heads, a->batch);
+  if (a->flags & MCA_ATTN_Q_PRESCALED) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(512), DKV_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
+  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(512), DKV_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
   return launch_status();
 }

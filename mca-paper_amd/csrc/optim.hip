@@ -31,8 +31,9 @@ extern "C" int mca_grad_sqnorm(const float* g, int64_t n, float* sqnorm, mca_str
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                      float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
                                                      float wd, float bc1, float bc2, float max_norm, const float* __restrict__ sqnorm,
-                                                     const int32_t* __restrict__ skip_flag) {
+                                                     const int32_t* __restrict__ skip_flag, const float* __restrict__ hyper) {
   if (skip_flag && *skip_flag != 0) return;          // a non-finite step (mca_nonfinite_flag) never reaches the weights
+  if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; }          // per-step values from device memory (graph replay)
   float clip = 1.f;
   if (max_norm > 0.f && sqnorm) {
     const float c = max_norm / (sqrtf(*sqnorm) + 1e-6f);       // torch.nn.utils.clip_grad_norm_
@@ -52,11 +53,20 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 extern "C" int mca_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                               float eps, float weight_decay, float bias_corr1, float bias_corr2, float max_norm,
-                              const float* sqnorm, const int32_t* skip_flag, mca_stream_t stream) {
+                              const float* sqnorm, const int32_t* skip_flag, const float* hyper, mca_stream_t stream) {
   if (!p || !g || !m || !v || n <= 0) return MCA_E_BADARG;
   int64_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, bias_corr1, bias_corr2, max_norm, sqnorm, skip_flag);
+                     weight_decay, bias_corr1, bias_corr2, max_norm, sqnorm, skip_flag, hyper);
+  return launch_status();
+}
+
+__global__ void adamw_hyper_kernel(float* __restrict__ hyper, float lr, float bc1, float bc2) {
+  if (threadIdx.x == 0) { hyper[0] = lr; hyper[1] = bc1; hyper[2] = bc2; }
+}
+extern "C" int mca_adamw_hyper(float* hyper, float lr, float bias_corr1, float bias_corr2, mca_stream_t stream) {
+  if (!hyper) return MCA_E_BADARG;
+  hipLaunchKernelGGL(adamw_hyper_kernel, dim3(1), dim3(64), 0, as_stream(stream), hyper, lr, bias_corr1, bias_corr2);
   return launch_status();
 }
 

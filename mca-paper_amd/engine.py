@@ -853,7 +853,8 @@ class FusionEngine:
         b = next(iter(first.values())).shape[0]
         need_grad = torch.is_grad_enabled() and not no_loss
         if self.check_finite:
-            self.poll_finite()                                         # a flagged EARLIER step raises here (no sync)
+            if not torch.cuda.is_current_stream_capturing():           # (hipEventQuery would invalidate a stream capture)
+                self.poll_finite()                                     # a flagged EARLIER step raises here (no sync)
             self._flag_inputs(batch)
         self.refresh_weights()
         native = all(isinstance(m.encoders[n], (EmbeddedSequenceEncoder, TabularEncoder)) for n in m.modality_types)
@@ -870,8 +871,9 @@ class FusionEngine:
         if self.check_finite:
             self._flag_tensors([pooled], 2)
             self._flag_host.copy_(self.finite_flag, non_blocking=True)
-            self._flag_event = torch.cuda.Event()
-            self._flag_event.record()
+            if not torch.cuda.is_current_stream_capturing():          # (a captured step: graph.GraphedStep records it after the replay)
+                self._flag_event = torch.cuda.Event()
+                self._flag_event.record()
         if no_loss:
             out = {k: pooled[:, s] for k, s in slots.items()}
             out["modality_sample_mask"] = sample_mask
@@ -890,10 +892,11 @@ class FusionEngine:
         names = [t.name for t in m.loss_terms]
         out["losses"] = {n: terms[i] for i, n in enumerate(names)}
         if m.fcl and not m.zorro:
-            fc = [i for i, n in enumerate(names) if "fcl" in n]
-            nf = [i for i, n in enumerate(names) if "fcl" not in n]
-            out["fcl_loss"] = torch.nan_to_num(terms[fc]).mean()
-            out["no-fcl_loss"] = torch.nan_to_num(terms[nf]).mean()
+            if getattr(self, "_fc_idx", None) is None:          # device index tensors, built once (a list index is an H2D copy)
+                self._fc_idx = torch.tensor([i for i, n in enumerate(names) if "fcl" in n], dtype=torch.long, device=self.device)
+                self._nf_idx = torch.tensor([i for i, n in enumerate(names) if "fcl" not in n], dtype=torch.long, device=self.device)
+            out["fcl_loss"] = torch.nan_to_num(terms.index_select(0, self._fc_idx)).mean()
+            out["no-fcl_loss"] = torch.nan_to_num(terms.index_select(0, self._nf_idx)).mean()
         out["loss"] = loss.reshape(())
         out["modality_sample_mask"] = sample_mask
         if self.check_finite and self.check_finite != "deferred":

@@ -135,7 +135,8 @@ SIGNATURES = {
     "mca_contrastive_workspace_bytes": (_I64, [_I, _I]),
     "mca_contrastive_fwd_bwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "mca_grad_sqnorm": (_I, [_P, _I64, _P, _P]),
-    "mca_adamw_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P]),
+    "mca_adamw_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
+    "mca_adamw_hyper": (_I, [_P, _F, _F, _F, _P]),
     "mca_nonfinite_flag": (_I, [C.POINTER(FiniteArgs), _P, _I, _P]),
 }
 # measurement hooks (include/mca_hip_debug.h): exported by the library, not part of the drop-in ABI

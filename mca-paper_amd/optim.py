@@ -34,23 +34,34 @@ class FusedAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(eng.flat)
         self.exp_avg_sq = torch.zeros_like(eng.flat)
         self.step_count = 0
+        # {lr, bias_corr1, bias_corr2} of the current step in device memory: a captured step (graph.GraphedStep) reads them at
+        # replay time; set by the one-thread kernel mca_adamw_hyper before every step (outside the graph)
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=eng.device)
+        self.hyper_external = False          # True: the graph driver sets the hyper-parameters and counts the steps
+
+    def set_hyper(self, step_count: int):
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        call("mca_adamw_hyper", ptr(self.hyper), float(g["lr"]), 1.0 - b1 ** step_count, 1.0 - b2 ** step_count, stream_ptr())
 
     @torch.no_grad()
     def step(self, closure=None):
         eng = self.model.engine
         g = self.param_groups[0]
-        self.step_count += 1
+        if not self.hyper_external:
+            self.step_count += 1
+            self.set_hyper(self.step_count)
         b1, b2 = g["betas"]
-        bc1 = 1.0 - b1 ** self.step_count
-        bc2 = 1.0 - b2 ** self.step_count
+        bc1 = 1.0 - b1 ** max(self.step_count, 1)
+        bc2 = 1.0 - b2 ** max(self.step_count, 1)
         max_norm = getattr(eng, "_pending_clip", 0.0) or 0.0
         sq = eng._ws.get("sqnorm")
         call("mca_adamw_step", ptr(eng.flat), ptr(eng.gflat), ptr(self.exp_avg), ptr(self.exp_avg_sq), eng.n_params,
              float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], bc1, bc2, max_norm, ptr(sq) if max_norm > 0 else None,
              ptr(eng.finite_flag) if eng.check_finite else None,          # a step flagged non-finite leaves the weights alone
-             stream_ptr())
+             ptr(self.hyper), stream_ptr())
         eng._pending_clip = 0.0
-        eng.flat.add_(0)                 # bump the version counter: bf16 weight copies are refreshed next forward
+        eng._weights_version = -1        # the parameters moved: bf16 weight copies are refreshed by the next forward
 
     def zero_grad(self, set_to_none: bool = True):
         # gradients live in the engine's flat buffer, which the next backward overwrites

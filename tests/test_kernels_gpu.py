@@ -482,23 +482,25 @@ def test_attention_small(H, variant, pool, drop):
     _attention_case(H, st, b=3, heads=2, pool=pool, seed=11, drop_first=drop)
 
 
-@pytest.mark.parametrize("form", ["unscaled", "first-form"])
+@pytest.mark.parametrize("form", ["unscaled", "second-form", "second-form-unscaled"])
 def test_attention_other_forms(H, form):
-    """the un-prescaled entry of the production forward kernel, and the first-form forward kernel (knob 13) kept for A/B and
-    the conservative cross-check: same contract."""
+    """the un-prescaled entry of the production forward kernel, and the lazy-reference second form of the forward (knob 13 = 2,
+    opt-in: A/B measurements): same contract."""
     S = importlib.import_module("mca-paper_amd.structure")
     st = S.FusionStructure([70, 45, 30], 8, (3, 2), fcl=True)
-    with H.knobs(k13=1 if form == "first-form" else 0):
-        _attention_case(H, st, b=3, heads=2, pool=False, seed=11, drop_first=True, prescaled=False)
+    with H.knobs(k13=2 if form.startswith("second") else 0):
+        _attention_case(H, st, b=3, heads=2, pool=False, seed=11, drop_first=True, prescaled=form == "second-form")
 
 
-@pytest.mark.parametrize("prescaled", [True, False])
-def test_attention_lazy_reference_moves(H, prescaled):
-    """keys 40x larger than their neighbours in the first, second and third key tile of a row and at the very end: the lazy
-    reference of the forward softmax has to move at a row's first tile, grow later, and start from scores far below zero."""
+@pytest.mark.parametrize("prescaled,form", [(True, 0), (False, 0), (True, 2), (False, 2)])
+def test_attention_spiked_keys(H, prescaled, form):
+    """keys 40x larger than their neighbours in the first, second and third key tile of a row and at the very end: the running
+    maximum of the forward softmax jumps mid-row and starts from scores far below zero (for the second form: its lazy
+    reference has to move at a row's first tile and grow later)."""
     S = importlib.import_module("mca-paper_amd.structure")
     st = S.FusionStructure([300, 100, 60], 8, (3, 2), fcl=True)
-    _attention_case(H, st, b=2, heads=2, pool=False, seed=17, drop_first=True, prescaled=prescaled, spike=True)
+    with H.knobs(k13=form):
+        _attention_case(H, st, b=2, heads=2, pool=False, seed=17, drop_first=True, prescaled=prescaled, spike=True)
 
 
 @pytest.mark.parametrize("variant,pool", [("mca", False), ("zorro", False), ("mca", True)])
@@ -589,6 +591,6 @@ def test_clip_adamw(H):
         H.call("mca_grad_sqnorm", gd.data_ptr(), n, sq.data_ptr(), H.stream_ptr())
         assert abs(float(sq.sqrt()) - float(gn)) < 1e-4 * float(gn)
         H.call("mca_adamw_step", p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.01,
-               1 - 0.9 ** step, 1 - 0.999 ** step, 2.0, sq.data_ptr(), None, H.stream_ptr())
+               1 - 0.9 ** step, 1 - 0.999 ** step, 2.0, sq.data_ptr(), None, None, H.stream_ptr())
         err = (p.cpu() - p_ref.detach()).abs().max()
         assert err < 5e-6, f"step {step}: {err}"

@@ -195,7 +195,8 @@ def test_reference_state_dir_resume_third_step(P):
     out = model(to_device(io["train_batches"][2], "cuda"))
     opt.zero_grad(); out["loss"].backward(); optim.clip_grad_norm_(model, 2.0); opt.step()
     torch.cuda.synchronize()
-    assert abs(float(out["loss"]) - float(io["loss_step3"])) < 2e-3 * abs(float(io["loss_step3"])) + 1e-3
+    # the loss is a difference of temperature-scaled logits of magnitude O(10^2..10^3) here: 0.5 % of its value is ~1e-4 of them
+    assert abs(float(out["loss"]) - float(io["loss_step3"])) < 5e-3 * abs(float(io["loss_step3"])) + 1e-3
     worst = 0.0
     for n, p in model.named_parameters():
         d_ref, d_nat = io["state_step3"][n] - before[n], p.detach().cpu() - before[n]
@@ -378,3 +379,57 @@ def test_dp2_native_equals_single_process_objective(P, tmp_path):
             continue
         errs.append((rel_err(got[0]["grads"][n], g), n))
     assert max(errs)[0] < 1e-2, max(errs)
+
+
+# ------------------------------------------------------------------------------------------------ hipGraph replay
+def test_graphed_step_matches_eager(P):
+    """graph.GraphedStep (the whole step as one hipGraph) against the eager loop on the same batches with a changing learning
+    rate: the replay takes THIS step's lr and Adam bias corrections from device memory, new inputs go through the static
+    buffers, and the finite flag still stops a bad step."""
+    optim = importlib.import_module("mca-paper_amd.optim")
+    graph = importlib.import_module("mca-paper_amd.graph")
+    cfg = small_config("tab")
+    sd = P.params.init_state_dict(cfg, seed=3)
+    batches = [to_device(P.data.synthetic_batch(cfg, 4, seed=40 + i, p_drop=0.2), "cuda") for i in range(5)]
+    lrs = [1e-3, 2e-3, 0.0, 1e-3, 3e-3]
+    runs = []
+    for graphed in (False, True):
+        m = P.MCA(**copy.deepcopy(cfg)); m.load_state_dict(sd, strict=False); m = m.cuda()
+        m.engine.check_finite = "deferred"
+        opt = optim.FusedAdamW(m, lr=lrs[0], weight_decay=0.0)
+        losses, snaps = [], []
+        if graphed:
+            # the capture's warm-up steps move the weights and the moments: put them back before the comparison starts
+            w0, m0, v0 = m.engine.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()
+            g = graph.GraphedStep(m, opt, batches[0], clip=2.0, warmup=2)
+            m.engine.flat.copy_(w0); opt.exp_avg.copy_(m0); opt.exp_avg_sq.copy_(v0); opt.step_count = 0
+            m.engine.invalidate_weights()
+        for i, bt in enumerate(batches):
+            opt.param_groups[0]["lr"] = lrs[i]
+            if graphed:
+                losses.append(float(g.step(bt)))
+            else:
+                out = m(bt); opt.zero_grad(); out["loss"].backward(); optim.clip_grad_norm_(m, 2.0); opt.step()
+                losses.append(float(out["loss"].detach()))
+            snaps.append(m.engine.flat.clone())
+        torch.cuda.synchronize()
+        m.engine.assert_finite()
+        runs.append((losses, snaps, m, opt, g if graphed else None))
+    (le, se, _, _, _), (lg, sg, mg, og, g) = runs
+    # the same kernels on the same data: the first steps agree to fp32-atomic noise.  Later ones drift apart faster than that:
+    # Adam's early updates are ~lr * sign(g), so a gradient element at the noise level flips a whole lr of weight
+    assert abs(le[0] - lg[0]) <= 1e-5 * abs(le[0]) and abs(le[1] - lg[1]) <= 1e-4 * abs(le[1]), (le, lg)
+    for a, b_ in zip(le, lg):
+        assert abs(a - b_) <= 2e-2 * abs(a), (le, lg)
+    assert rel_err(sg[0], se[0]) < 1e-5 and rel_err(sg[-1], se[-1]) < 5e-3
+    # lr = 0 (weight decay 0) at the third step: the replay read THIS step's learning rate, the weights did not move
+    assert torch.equal(sg[2], sg[1]) and not torch.equal(sg[3], sg[2])
+    # a non-finite batch through the graph: the device flag stops the fused AdamW, the next poll raises
+    bad = copy.deepcopy(batches[0]); bad["audio"]["tokens"][0, 0, 0] = float("nan")
+    before = mg.engine.flat.clone()
+    og.param_groups[0]["lr"] = 1e-3
+    g.step(bad)
+    torch.cuda.synchronize()
+    assert torch.equal(mg.engine.flat, before)
+    with pytest.raises(Exception, match="not finite"):
+        mg.engine.assert_finite()

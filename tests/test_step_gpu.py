@@ -327,6 +327,41 @@ def test_forward_bitwise_deterministic_at_cmu_size(P, b):
                 assert torch.equal(x, y), f"tensor {i} differs between two forwards of the same inputs"
 
 
+@pytest.mark.parametrize("variant", ["mca", "mma"])
+def test_attention_backward_bitwise_deterministic_at_cmu_size(P, variant):
+    """The two-pass attention backward has one owner per output element: with the whole chip busy (b = 32) two launches on
+    the same operands agree BIT FOR BIT (dq, dk, dv).  A mis-counted wait in the hand-pipelined fragment reads would show
+    here as a few differing elements that every tolerance lets through."""
+    b = 32
+    cfg = P.config.cmu_model_config(batch_size=b, zorro=variant == "mma")
+    cfg["depth"] = 1
+    torch.manual_seed(43)
+    model = P.MCA(**cfg).cuda()
+    eng = model.engine
+    eng.check_finite = False
+    data = importlib.import_module("mca-paper_amd.data")
+    batch = data.synthetic_batch(cfg, b, seed=1234, lengths="uniform", p_drop=0.2, device="cuda")
+    out = model(batch)
+    out["loss"].backward()
+    ws = eng.workspace(b)
+    a = ws["layers"][0]
+    N, D = eng.N, eng.D
+    snaps = []
+    for rep in range(3):
+        a["dqkv"].fill_(7.0)
+        eng._attn_bwd2(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], ws["do"], a["lse"], ws["delta"],
+                       a["dqkv"].data_ptr(), N * 3 * D, 3 * D, False, a["dqkv"], D, 2 * D, 3 * D, eng.qmask_attn, eng.sched_attn_f,
+                       eng.sched_attn_b, ws, b, N)
+        torch.cuda.synchronize()
+        snaps.append(a["dqkv"].clone())
+    assert torch.isfinite(snaps[0].float()).all()
+    # dvmean (gradient of the uniform rows' mean(V)) is summed with atomics by mca_attn_bwd_prep: dv may differ in rounding
+    # when a sample has dropped modalities; dq and dk have no such input
+    for s_ in snaps[1:]:
+        assert torch.equal(s_[:, :2 * D], snaps[0][:, :2 * D])
+        assert (s_[:, 2 * D:].float() - snaps[0][:, 2 * D:].float()).abs().max() <= 1e-2 * snaps[0][:, 2 * D:].float().abs().max()
+
+
 @pytest.mark.parametrize("kind,b", [("cmu", 32), ("mma", 32), ("tcga", 16)])
 def test_full_size_gradients_new_vs_conservative_kernels(P, kind, b):
     """Whole-chip cross-check of the pipelined kernels (b = 32, every CU busy): one forward + backward with the production

@@ -18,14 +18,21 @@ a["qkv"][:, :D] *= 0.18          # q as the engine stores it (scale * log2 e fol
 ws["do"].copy_(torch.randn_like(ws["do"].float()).bfloat16())
 def fwd(): eng._attn_fwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], a["lse"], eng.qmask_attn, eng.sched_attn_f, ws, b, N)
 def bwd():
-    eng._attn_bwd_layer(ws, a, b) if hasattr(eng, "_attn_bwd_layer") else (ws["dq32"].zero_(), eng._attn_bwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], ws["do"], a["lse"], ws["delta"], ws["dq32"], N*D, a["dqkv"], D, 2*D, 3*D, eng.qmask_attn, eng.sched_attn_b, ws, b, N))
+    if eng.attn_bwd_two_pass:
+        eng._attn_bwd2(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], ws["do"], a["lse"], ws["delta"], a["dqkv"].data_ptr(), N*3*D, 3*D, False,
+                       a["dqkv"], D, 2*D, 3*D, eng.qmask_attn, eng.sched_attn_f, eng.sched_attn_b, ws, b, N)
+    else:
+        ws["dq32"].zero_()
+        eng._attn_bwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], ws["do"], a["lse"], ws["delta"], ws["dq32"], N*D, a["dqkv"], D, 2*D, 3*D, eng.qmask_attn, eng.sched_attn_b, ws, b, N)
 def timeit(fn, n=10):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     H.profile_start(("mca_attn_fwd", "mca_attn_bwd", "mca_attn_bwd_dq", "mca_attn_bwd_dkv"))
     for _ in range(n): fn()
     return H.profile_stop()
-cases = [("fwd first form", fwd, {13: 2}), ("fwd", fwd, {}), ("bwd", bwd, {})]
+cases = [("fwd", fwd, {}), ("fwd second form", fwd, {13: 2}), ("bwd", bwd, {})]
+if os.environ.get("MCA_BENCH_ATTN_ONLY"):
+    cases = [c for c in cases if c[0] == os.environ["MCA_BENCH_ATTN_ONLY"]]
 if os.environ.get("MCA_BENCH_ATTN_EXTRA"):
     cases += [("bwd no-atomics", bwd, {6: 1})]
 for nm, fn, knobs in cases:

@@ -17,10 +17,10 @@ nat = run_native_step(P, cfg, sd, batch, lr=1e-4, clip=2.0)
 rels = sorted((abs(float(nat["grads"][n].norm()) - g) / g, n) for n, g in rec["grad_norms"].items() if g > 1e-12 and not n.endswith("logit_scale"))
 print(f"pooled {rel_err(nat['pooled'], rec['pooled']):.2e} loss {nat['loss']:.5f} (ref {float(rec['loss']):.5f}) grad-norm err median {rels[len(rels)//2][0]:.4f} max {rels[-1][0]:.4f} ({rels[-1][1]}) 2nd {rels[-2][0]:.4f} ({rels[-2][1]})")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for name, env in (("prescale + lazy fwd + two-pass bwd (default)", {}),
-                  ("prescale + lazy fwd + one-pass bwd", {"MCA_ATTN_BWD_ONE_PASS": "1"}),
-                  ("no prescale + lazy fwd + one-pass bwd", {"MCA_Q_PRESCALE": "0", "MCA_ATTN_BWD_ONE_PASS": "1"}),
-                  ("no prescale + first-form fwd + one-pass bwd (round 1)", {"MCA_Q_PRESCALE": "0", "MCA_ATTN_BWD_ONE_PASS": "1", "K13": "1"}),
-                  ("no prescale + first-form fwd + two-pass bwd", {"MCA_Q_PRESCALE": "0", "K13": "1"})):
+for name, env in (("prescale + first-form fwd + two-pass bwd (default)", {}),
+                  ("prescale + first-form fwd + one-pass bwd", {"MCA_ATTN_BWD_ONE_PASS": "1"}),
+                  ("prescale + lazy second-form fwd + two-pass bwd", {"K13": "2"}),
+                  ("no prescale + first-form fwd + one-pass bwd (round 1)", {"MCA_Q_PRESCALE": "0", "MCA_ATTN_BWD_ONE_PASS": "1"}),
+                  ("no prescale + lazy second-form fwd + one-pass bwd", {"MCA_Q_PRESCALE": "0", "MCA_ATTN_BWD_ONE_PASS": "1", "K13": "2"})):
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
     print(f"{name:58s}: {out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-800:]}", flush=True)
