@@ -198,6 +198,22 @@ typedef struct {
 /* dim_head is fixed at 64; query tile 128 rows, key tile 64.                                     */
 int mca_attn_fwd(const mca_attn_fwd_args* args, mca_stream_t stream);
 
+/* MX-fp8 operands of the fusion attention forward (BASELINE configs[4], "fp8 MFMA attention"): OCP e4m3 elements with one
+ * E8M0 power-of-two scale byte per 32 elements along the contraction (d for Q and K; keys 0..31 | 32..63 of a 64-key tile
+ * for V^T), the operand format of v_mfma_scale_f32_32x32x64_f8f6f4.  npad = n_ktiles * 64 token rows per (sample, head), rows >= n are zero.
+ *   q8, k8 : [batch][heads][npad][64]            qs, ks : [batch][heads][npad][2]
+ *   v8t    : [batch][heads][n_ktiles][64 d][64]  V transposed per 64-key tile; position p of a row holds key
+ *            32 (p >> 5) + 8 ((p >> 2) & 3) + 4 ((p >> 4) & 1) + (p & 3) of the tile (the order in which the S^T
+ *            accumulators of the forward kernel hold a query's keys);      vs : [batch][heads][n_ktiles][64 d][2]          */
+typedef struct { uint8_t* q8; uint8_t* qs; uint8_t* k8; uint8_t* ks; uint8_t* v8t; uint8_t* vs; int n_ktiles; } mca_attn_fp8_operands;
+/* q | k | v (bf16, strides as in mca_attn_fwd_args; q pre-scaled by scale * log2 e) -> the operands above              */
+int mca_attn_quant_mxfp8(const uint16_t* q, int64_t q_bstride, int64_t q_ld, const uint16_t* k, const uint16_t* v,
+                         int64_t kv_bstride, int64_t kv_ld, const mca_attn_fp8_operands* f, int batch, int heads, int n,
+                         mca_stream_t stream);
+/* mca_attn_fwd with Q K^T and P V on the block-scaled fp8 matrix instruction (self-attention, MCA_ATTN_Q_PRESCALED only;
+ * the q / k / v pointers of args are not read).  o (bf16) and lse as mca_attn_fwd; the backward stays in bf16.            */
+int mca_attn_fwd_fp8(const mca_attn_fwd_args* args, const mca_attn_fp8_operands* f, mca_stream_t stream);
+
 /* delta[b,h,i] = sum_d dO*O ; dvmean[b,h*64+d] = (1/nk) * sum over uniform rows i of dO          */
 int mca_attn_bwd_prep(const uint16_t* o, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld,
                       const float* lse, float* delta, float* dvmean,

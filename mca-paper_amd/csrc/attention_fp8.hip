@@ -1,0 +1,338 @@
+// Fusion attention forward with MX-fp8 operands (BASELINE configs[4]: "fp8 MFMA attention"; reference arithmetic
+// model.py:87-99): Q K^T and P V on the block-scaled matrix instruction v_mfma_scale_f32_32x32x64_f8f6f4 (OCP e4m3 elements,
+// one E8M0 power-of-two scale per 32 elements along the contraction; 2x the bf16 rate per MI355X_MICROARCH.md, measured
+// 4.5-4.8 PFLOP/s by tools/probe_fp8.py).  Operand layout of the instruction as probed (tools/probe_fp8.py for the pairing,
+// tools/probe_fp8_scale.py for the scales): lane l holds row (A) / column (B) l & 31; its bytes 0..15 are contraction elements
+// 16 (l >> 5) .. +15 (scale block 0 = K 0..31) and its bytes 16..31 elements 32 + 16 (l >> 5) .. +15 (scale block 1); byte j
+// of lane half h meets byte j of the other operand's half h.  The scale of block 0 is byte 0 of the scale VGPR of lane
+// (l & 31), that of block 1 of lane 32 + (l & 31).
+//
+//   mca_attn_quant_mxfp8   q | k | v (bf16, as the QKV GEMM wrote them; q already carries scale * log2 e) ->
+//                          Q8, K8 [b][h][token][64] e4m3 + scale bytes [b][h][token][2] (blocks of 32 along d), and
+//                          V8T [b][h][key tile][d][64 positions] e4m3 + scales [..][d][2] (blocks = keys 0..31 | 32..63 of the
+//                          tile): V TRANSPOSED per 64-key tile, the keys inside each 32-key block PERMUTED into the order the
+//                          S^T accumulators hand P to the P.V product (position p <-> key 32 (p >> 5) + 8 ((p >> 2) & 3) +
+//                          4 ((p >> 4) & 1) + (p & 3)), so that the P.V A operand is two 16-byte row reads and P goes from
+//                          the accumulators to the B operand with 16 conversions.
+//   mca_attn_fwd_fp8       the forward kernel of attention_fwd.hip (128-query workgroups, 64-key tiles, static tile skipping,
+//                          exact running maximum, uniform-row semantics) on those operands: 4 matrix instructions per
+//                          32 x 64 block instead of 16, K / V tiles of 4 KiB each instead of 8, no transposed LDS reads.
+//                          P is fed as 128 * 2^(S - m) (unit scale; the sum carries the same factor), e4m3 range down to
+//                          2^-16 of the row maximum.
+// The backward stays in bf16 (attention_bwd2.hip) with the log-sum-exp this forward wrote.
+#include "common.h"
+
+#define AQ 128
+#define AK 64
+#define DH 64
+#define MAX_KTILES 512
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------
+// quantisation
+// ---------------------------------------------------------------------------------------------------------
+// 16 floats of one 32-element block half -> 16 e4m3 bytes with the block's power-of-two scale; amax over the 32-element block
+// = this lane and its xor-1 neighbour.  Scale exponent e = floor(log2(amax)) - 7: |x| / 2^e < 256 <= 448 (no saturation
+// needed; v_cvt_pk_fp8_f32 returns NaN above 448).  Returns the E8M0 byte (e + 127).
+__device__ __forceinline__ uint32_t quant_block_half(const float (&x)[16], uint4& out) {
+  float am = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; i++) am = fmaxf(am, fabsf(x[i]));
+  am = fmaxf(am, __shfl_xor(am, 1, WAVE));
+  const uint32_t E = (__float_as_uint(am) >> 23) & 0xffu;          // biased exponent of amax (0 for zero / subnormal)
+  const uint32_t sb = E > 7u ? E - 7u : 0u;                        // E8M0 scale byte: 2^(sb - 127)
+  const float mult = __uint_as_float((254u - sb) << 23);           // 2^(127 - sb)
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int v = __builtin_amdgcn_cvt_pk_fp8_f32(x[4 * i] * mult, x[4 * i + 1] * mult, 0, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(x[4 * i + 2] * mult, x[4 * i + 3] * mult, v, true);
+    w[i] = (uint32_t)v;
+  }
+  out = make_uint4(w[0], w[1], w[2], w[3]);
+  return sb;
+}
+
+__global__ __launch_bounds__(256) void attn_quant_mxfp8_kernel(const u16* __restrict__ q, int64_t q_bstride, int64_t q_ld,
+                                                                const u16* __restrict__ k, const u16* __restrict__ v,
+                                                                int64_t kv_bstride, int64_t kv_ld, uint8_t* __restrict__ q8,
+                                                                uint8_t* __restrict__ qs, uint8_t* __restrict__ k8,
+                                                                uint8_t* __restrict__ ks, uint8_t* __restrict__ v8t,
+                                                                uint8_t* __restrict__ vs, int heads, int n, int ntiles) {
+  __shared__ u16 vt[AK][DH + 2];          // V tile, row-major, padded: the transposed gather below walks a column
+  const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int r = tid >> 2, c = tid & 3;          // row of the tile, 16-element quarter of the 64-wide row
+  const int tok = kt * AK + r;
+  const bool live = tok < n;
+  const int64_t rowi = ((int64_t)b * heads + h) * ((int64_t)ntiles * AK) + tok;
+  // ---- q and k: blocks of 32 along d
+  for (int which = 0; which < 2; which++) {
+    const u16* src = which == 0 ? q + (int64_t)b * q_bstride + (int64_t)(live ? tok : 0) * q_ld + h * DH + 16 * c
+                                : k + (int64_t)b * kv_bstride + (int64_t)(live ? tok : 0) * kv_ld + h * DH + 16 * c;
+    float x[16];
+    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(src), a1 = *reinterpret_cast<const bf16x8*>(src + 8);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { x[i] = live ? bf2f((u16)a0[i]) : 0.f; x[8 + i] = live ? bf2f((u16)a1[i]) : 0.f; }
+    uint4 o;
+    const uint32_t sb = quant_block_half(x, o);
+    uint8_t* dst = (which == 0 ? q8 : k8) + rowi * DH + 16 * c;
+    *reinterpret_cast<uint4*>(dst) = o;
+    if ((c & 1) == 0) (which == 0 ? qs : ks)[rowi * 2 + (c >> 1)] = (uint8_t)sb;
+  }
+  // ---- v: transposed per tile, keys permuted, blocks of 32 along the (permuted) key positions
+  {
+    const u16* src = v + (int64_t)b * kv_bstride + (int64_t)(live ? tok : 0) * kv_ld + h * DH + 16 * c;
+    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(src), a1 = *reinterpret_cast<const bf16x8*>(src + 8);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { vt[r][16 * c + i] = live ? (u16)a0[i] : (u16)0; vt[r][16 * c + 8 + i] = live ? (u16)a1[i] : (u16)0; }
+  }
+  __syncthreads();
+  {
+    const int d = r;          // this thread: row d of V^T, positions 16 c .. 16 c + 15 = 32-key block c >> 1, lane half c & 1
+    float x[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; jj++) {
+      const int key = (c >> 1) * 32 + (jj >> 2) * 8 + 4 * (c & 1) + (jj & 3);
+      x[jj] = bf2f(vt[key][d]);
+    }
+    uint4 o;
+    const uint32_t sb = quant_block_half(x, o);
+    const int64_t ti = (((int64_t)b * heads + h) * ntiles + kt) * DH + d;
+    *reinterpret_cast<uint4*>(v8t + ti * AK + 16 * c) = o;
+    if ((c & 1) == 0) vs[ti * 2 + (c >> 1)] = (uint8_t)sb;
+  }
+}
+
+extern "C" int mca_attn_quant_mxfp8(const uint16_t* q, int64_t q_bstride, int64_t q_ld, const uint16_t* k, const uint16_t* v,
+                                    int64_t kv_bstride, int64_t kv_ld, const mca_attn_fp8_operands* f, int batch, int heads,
+                                    int n, mca_stream_t stream) {
+  if (!q || !k || !v || !f || !f->q8 || !f->qs || !f->k8 || !f->ks || !f->v8t || !f->vs || batch <= 0 || heads <= 0 || n <= 0)
+    return MCA_E_BADARG;
+  if (q_ld % 8 || kv_ld % 8 || q_bstride % 8 || kv_bstride % 8 || (uintptr_t)q % 16 || (uintptr_t)k % 16 || (uintptr_t)v % 16) return MCA_E_ALIGN;
+  if ((uintptr_t)f->q8 % 16 || (uintptr_t)f->k8 % 16 || (uintptr_t)f->v8t % 16) return MCA_E_ALIGN;
+  const int ntiles = (n + AK - 1) / AK;
+  if (f->n_ktiles != ntiles) return MCA_E_BADARG;
+  if (heads > 65535 || batch > 65535) return MCA_E_UNSUPPORTED;
+  hipLaunchKernelGGL(attn_quant_mxfp8_kernel, dim3(ntiles, heads, batch), dim3(256), 0, as_stream(stream), q, q_bstride, q_ld, k, v,
+                     kv_bstride, kv_ld, f->q8, f->qs, f->k8, f->ks, f->v8t, f->vs, heads, n, ntiles);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------
+// [64 rows][64 bytes] tile image: 16-byte chunk c (0..3) of row r at c ^ ((r >> 2) & 3): the 16 rows of a ds_read_b128 lane
+// group then cover all 64 banks (64-byte rows: four rows per 256-byte bank row)
+__device__ __forceinline__ int t8_off(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
+
+__global__ __launch_bounds__(256) void attn_fwd8_kernel(mca_attn_fwd_args a, mca_attn_fp8_operands f, int dbg) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * 2 * AK * DH];   // K8, V8T double-buffered: 16 KiB
+  __shared__ __attribute__((aligned(16))) uint8_t sc_s[2][2][AK * 2];     // [buffer][K | V][row][half] scale bytes
+  __shared__ __attribute__((aligned(16))) uint8_t kinfo[2][AK];
+  __shared__ uint8_t flags_s[MAX_KTILES];
+  __shared__ uint32_t live_s[MAX_KTILES];
+  __shared__ int n_live_s;
+  uint8_t* Ks = lds;
+  uint8_t* Vs = lds + 2 * AK * DH;
+
+  const int lin0 = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+  const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y * gridDim.z));
+  const int qt = a.q_order[lin % (int)gridDim.x];
+  const int h = (lin / (int)gridDim.x) % (int)gridDim.y, b = lin / (int)(gridDim.x * gridDim.y);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int q0 = qt * AQ + wave * 32;
+  int qrow = q0 + l31;
+  const bool qvalid = qrow < a.nq;
+  if (qrow > a.nq - 1) qrow = a.nq - 1;
+  const int ntiles = f.n_ktiles;
+  const int64_t bh = (int64_t)b * a.heads + h;
+
+  // Q8 fragment (B operand of S^T = K Q^T): lane = query, bytes 16 lh .. +15 of both 32-element blocks of its row; lane half lh
+  // supplies the scale of block lh
+  v8i qf;
+  int qscale;
+  {
+    const int64_t rowi = bh * ((int64_t)ntiles * AK) + qrow;
+    const uint4 lo = *reinterpret_cast<const uint4*>(f.q8 + rowi * DH + 16 * lh), hi = *reinterpret_cast<const uint4*>(f.q8 + rowi * DH + 32 + 16 * lh);
+    qf[0] = lo.x; qf[1] = lo.y; qf[2] = lo.z; qf[3] = lo.w; qf[4] = hi.x; qf[5] = hi.y; qf[6] = hi.z; qf[7] = hi.w;
+    qscale = f.qs[rowi * 2 + lh];
+  }
+  const uint32_t qm = a.qmask[qrow];
+
+  f32x16 o[2];
+#pragma unroll
+  for (int n = 0; n < 2; n++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[n][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const uint8_t* k8b = f.k8 + bh * ((int64_t)ntiles * AK) * DH;
+  const uint8_t* ksb = f.ks + bh * ((int64_t)ntiles * AK) * 2;
+  const uint8_t* v8b = f.v8t + bh * (int64_t)ntiles * DH * AK;
+  const uint8_t* vsb = f.vs + bh * (int64_t)ntiles * DH * 2;
+  const uint8_t* kinfo_g = a.keyinfo + (int64_t)b * a.nk_pad;
+  {
+    const uint8_t* flags_g = a.ktile_flags + (int64_t)b * a.n_ktiles;
+    for (int i = tid; i < a.n_ktiles; i += 256) flags_s[i] = flags_g[i];
+  }
+  __syncthreads();
+
+  // staging: a K8 / V8T tile is 4 KiB = 256 chunks of 16 B: one of each per thread; the 128 + 128 scale bytes and the 64 key
+  // group bytes by the first threads
+  const int srow = tid >> 2, scol = tid & 3;
+  uint4 rk, rv;
+  uint32_t rsk = 0, rsv = 0, rinfo = 0;
+  auto gload = [&](int kt) {
+    rk = *reinterpret_cast<const uint4*>(k8b + ((int64_t)kt * AK + srow) * DH + 16 * scol);
+    rv = *reinterpret_cast<const uint4*>(v8b + ((int64_t)kt * DH + srow) * AK + 16 * scol);
+    if (tid < 32) { rsk = *reinterpret_cast<const uint32_t*>(ksb + (int64_t)kt * AK * 2 + tid * 4); rsv = *reinterpret_cast<const uint32_t*>(vsb + (int64_t)kt * DH * 2 + tid * 4); }
+    if (tid < 16) rinfo = *reinterpret_cast<const uint32_t*>(kinfo_g + kt * AK + tid * 4);
+  };
+  auto swrite = [&](int buf) {
+    *reinterpret_cast<uint4*>(Ks + buf * AK * DH + t8_off(srow, scol)) = rk;
+    *reinterpret_cast<uint4*>(Vs + buf * AK * DH + t8_off(srow, scol)) = rv;
+    if (tid < 32) { *reinterpret_cast<uint32_t*>(&sc_s[buf][0][tid * 4]) = rsk; *reinterpret_cast<uint32_t*>(&sc_s[buf][1][tid * 4]) = rsv; }
+    if (tid < 16) *reinterpret_cast<uint32_t*>(&kinfo[buf][tid * 4]) = rinfo;
+  };
+
+  if (wave == 0) {
+    const int lb = a.q_ptr[qt], le = a.q_ptr[qt + 1];
+    int n = 0;
+    for (int i0 = lb; i0 < le; i0 += 64) {
+      const int i = i0 + lane;
+      const uint32_t e = i < le ? a.q_kt[i] : 0u;
+      const bool keep = i < le && flags_s[e & 0x7fffffffu] != 0;
+      const unsigned long long m = __ballot(keep);
+      if (keep) live_s[n + __popcll(m & ((1ull << lane) - 1ull))] = e;
+      n += __popcll(m);
+    }
+    if (lane == 0) n_live_s = n;
+  }
+  __syncthreads();
+  const int it_end = n_live_s;
+  int it = 0, buf = 0;
+  if (it < it_end) { gload((int)(live_s[0] & 0x7fffffffu)); swrite(0); }
+  __syncthreads();
+
+  while (it < it_end) {
+    const uint32_t ent = live_s[it];
+    const int kt = (int)(ent & 0x7fffffffu);
+    const bool need_mask = (ent >> 31) == 0 || (flags_s[kt] != 2);
+    const int nit = it + 1;
+    if (nit < it_end) gload((int)(live_s[nit] & 0x7fffffffu));
+
+    const uint8_t* ks = Ks + buf * AK * DH;
+    const uint8_t* vs = Vs + buf * AK * DH;
+    // ---- S^T = K Q^T: one block-scaled MFMA per 32-key block (A = K8 row of this lane's key, its 16 bytes of each d block)
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      const int row = kb * 32 + l31;
+      const uint4 lo = *reinterpret_cast<const uint4*>(ks + t8_off(row, lh)), hi = *reinterpret_cast<const uint4*>(ks + t8_off(row, 2 + lh));
+      v8i kf;
+      kf[0] = lo.x; kf[1] = lo.y; kf[2] = lo.z; kf[3] = lo.w; kf[4] = hi.x; kf[5] = hi.y; kf[6] = hi.z; kf[7] = hi.w;
+      const int kscale = sc_s[buf][0][row * 2 + lh];
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[kb][r] = 0.f;
+      s[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, s[kb], 0, 0, 0, kscale, 0, qscale);
+    }
+    if (need_mask) {
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const uint32_t info4 = *reinterpret_cast<const uint32_t*>(&kinfo[buf][kb * 32 + 8 * g + 4 * lh]);
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const uint32_t grp = (info4 >> (8 * e)) & 0xffu;
+            const bool ok = (qm >> grp) & 1u;
+            s[kb][4 * g + e] = ok ? s[kb][4 * g + e] : -INFINITY;
+          }
+        }
+    }
+    // ---- online softmax, exact running maximum (q carries scale * log2 e: S is the log2-domain logit)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+    const float m7 = m_use - 7.f;          // P is fed as 128 * 2^(S - m): e4m3 keeps 2^-16 of the row maximum; l carries the 128 too
+    float rs = 0.f;
+    v8i pf;                                 // P^T as the B operand: byte j of this lane half = key 32 (j >> 4) + 8 ((j >> 2) & 3) + 4 lh + (j & 3)
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const float p0 = __builtin_amdgcn_exp2f(s[kb][4 * g] - m7), p1 = __builtin_amdgcn_exp2f(s[kb][4 * g + 1] - m7);
+        const float p2 = __builtin_amdgcn_exp2f(s[kb][4 * g + 2] - m7), p3 = __builtin_amdgcn_exp2f(s[kb][4 * g + 3] - m7);
+        rs += (p0 + p1) + (p2 + p3);
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(p2, p3, w, true);
+        pf[kb * 4 + g] = w;
+      }
+    rs += __shfl_xor(rs, 32, WAVE);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) o[n][r] *= alpha;
+    // ---- O^T += V^T P^T: A = V8T row d (this lane half's 16 positions of each 32-key block), unit scale for P
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+      const int row = n * 32 + l31;
+      const uint4 lo = *reinterpret_cast<const uint4*>(vs + t8_off(row, lh)), hi = *reinterpret_cast<const uint4*>(vs + t8_off(row, 2 + lh));
+      v8i vf;
+      vf[0] = lo.x; vf[1] = lo.y; vf[2] = lo.z; vf[3] = lo.w; vf[4] = hi.x; vf[5] = hi.y; vf[6] = hi.z; vf[7] = hi.w;
+      const int vscale = sc_s[buf][1][row * 2 + lh];
+      o[n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf, o[n], 0, 0, 0, vscale, 0, 127);
+    }
+
+    if (nit < it_end) swrite(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+    it = nit;
+  }
+
+  const bool uniform = !(l_run > 0.f);
+  const float inv = uniform ? 0.f : 1.f / l_run;
+  if (qvalid) {
+    if (lh == 0) a.lse[bh * a.nq + qrow] = uniform ? INFINITY : m_run + log2f(l_run) - 7.f;
+    u16* op = a.o + (int64_t)b * a.o_bstride + (int64_t)qrow * a.o_ld + h * DH;
+    const float* vm = a.vmean + (int64_t)b * a.heads * DH + h * DH;
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int d = n * 32 + 8 * g + 4 * lh;
+        float v0, v1, v2, v3;
+        if (uniform) { v0 = vm[d]; v1 = vm[d + 1]; v2 = vm[d + 2]; v3 = vm[d + 3]; }
+        else { v0 = o[n][4 * g] * inv; v1 = o[n][4 * g + 1] * inv; v2 = o[n][4 * g + 2] * inv; v3 = o[n][4 * g + 3] * inv; }
+        uint2 pk; pk.x = pack2bf(v0, v1); pk.y = pack2bf(v2, v3);
+        *reinterpret_cast<uint2*>(op + d) = pk;
+      }
+  }
+}
+
+extern "C" int mca_attn_fwd_fp8(const mca_attn_fwd_args* a, const mca_attn_fp8_operands* f, mca_stream_t stream) {
+  if (!a || !f || !a->o || !a->lse || !a->qmask || !a->keyinfo || !a->ktile_flags || !a->q_ptr || !a->q_kt || !a->q_order || !a->vmean)
+    return MCA_E_BADARG;
+  if (!f->q8 || !f->qs || !f->k8 || !f->ks || !f->v8t || !f->vs) return MCA_E_BADARG;
+  if (a->batch <= 0 || a->heads <= 0 || a->nq <= 0 || a->nk <= 0) return MCA_E_BADARG;
+  if (a->nq != a->nk) return MCA_E_UNSUPPORTED;          // self-attention only: the query rows are tokens of the same quantised block
+  if (!(a->flags & MCA_ATTN_Q_PRESCALED)) return MCA_E_UNSUPPORTED;
+  if (a->n_qtiles != (a->nq + AQ - 1) / AQ || a->n_ktiles != (a->nk + AK - 1) / AK || f->n_ktiles != a->n_ktiles) return MCA_E_BADARG;
+  if (a->nk_pad < a->n_ktiles * AK || a->nk_pad % 4 || (uintptr_t)a->keyinfo % 4) return MCA_E_BADARG;
+  if (a->o_ld % 4 || a->o_bstride % 4 || (uintptr_t)a->o % 8 || (uintptr_t)f->q8 % 16 || (uintptr_t)f->k8 % 16 || (uintptr_t)f->v8t % 16 ||
+      (uintptr_t)f->ks % 4 || (uintptr_t)f->vs % 4)
+    return MCA_E_ALIGN;
+  if (a->heads > 65535 || a->batch > 65535 || a->n_ktiles > MAX_KTILES) return MCA_E_UNSUPPORTED;
+  hipLaunchKernelGGL(attn_fwd8_kernel, dim3(a->n_qtiles, a->heads, a->batch), dim3(256), 0, as_stream(stream), *a, *f, mca_knobs[9]);
+  return launch_status();
+}

@@ -27,7 +27,7 @@ import torch
 
 from . import hip
 from .encoders import EmbeddedSequenceEncoder, NativeEncoder, TabularEncoder
-from .hip import AttnBwd2Args, AttnBwdArgs, AttnFwdArgs, LossTerm, call, ptr, stream_ptr
+from .hip import AttnBwd2Args, AttnBwdArgs, AttnFp8Operands, AttnFwdArgs, LossTerm, call, ptr, stream_ptr
 
 LN_EPS = 1e-5
 FWD_BQ, FWD_BK = 128, 64
@@ -79,6 +79,7 @@ class FusionEngine:
         self.scale = model.dim_head ** -0.5
         self.q_scale = self.scale * 1.4426950408889634          # folded into the forward bf16 copy of every to_q.weight
         self.attn_flags = hip.ATTN_Q_PRESCALED
+        self.attn_dtype = "bf16"
         if os.environ.get("MCA_Q_PRESCALE", "1") == "0":        # A/B: plain W_q copy, the kernels scale the scores themselves
             self.q_scale, self.attn_flags = 0.0, 0
         self.nk_pad = _pad_to(self.N, 256)
@@ -206,6 +207,29 @@ class FusionEngine:
         d = dst[dst_row0:, dst_col0:]
         rp, cp = (c, r) if transpose else (r, c)
         self._cast_list.append(hip.CastDesc(ptr(src), ptr(d), src.stride(0), r, c, dst.stride(0), rp, cp, int(transpose), float(scale)))
+
+    def set_attention_dtype(self, dtype: str):
+        """'bf16' (default) or 'fp8': the fusion layers' forward attention computes Q K^T and P V on the block-scaled fp8 matrix
+        instruction from MX-fp8 copies of q, k, v (one quantisation pass per layer, mca_attn_quant_mxfp8); pooling attention
+        and the whole backward stay in bf16 (BASELINE configs[4])."""
+        if dtype not in ("bf16", "fp8"):
+            raise ValueError(dtype)
+        if dtype == "fp8" and not (self.attn_flags & hip.ATTN_Q_PRESCALED):
+            raise ValueError("fp8 attention needs the pre-scaled q operand (MCA_Q_PRESCALE=1)")
+        self.attn_dtype = dtype
+
+    def _fp8_operands(self, ws, b):
+        """one set of MX-fp8 operand buffers per workspace (forward only: every layer reuses it)"""
+        if "fp8" not in ws:
+            nt = (self.N + 63) // 64
+            u8 = lambda *s: torch.zeros(*s, dtype=torch.uint8, device=self.device)
+            bufs = dict(q8=u8(b, self.H, nt * 64, 64), qs=u8(b, self.H, nt * 64, 2), k8=u8(b, self.H, nt * 64, 64), ks=u8(b, self.H, nt * 64, 2),
+                        v8t=u8(b, self.H, nt, 64, 64), vs=u8(b, self.H, nt, 64, 2))
+            f = AttnFp8Operands()
+            f.q8, f.qs, f.k8, f.ks, f.v8t, f.vs = (bufs[k].data_ptr() for k in ("q8", "qs", "k8", "ks", "v8t", "vs"))
+            f.n_ktiles = nt
+            ws["fp8"] = (bufs, f)
+        return ws["fp8"][1]
 
     def invalidate_weights(self):
         """Call after writing parameters through an alias autograd's version counters cannot see (``p.data.op_()``, a raw
@@ -392,7 +416,12 @@ class FusionEngine:
         a.n_qtiles, a.n_ktiles, a.scale, a.flags = sched.s.n_q, sched.s.n_k, self.scale, self.attn_flags
         call("mca_attn_vmean", a.v, a.kv_bstride, a.kv_ld, ws["vmean"].data_ptr(), b, N, self.H, stream_ptr())
         hip.set_tag("pool" if nq != N else "layer")
-        call("mca_attn_fwd", C.byref(a), stream_ptr(), flops=4.0 * 64 * sched.s.allowed_pairs * self.H * b)
+        if self.attn_dtype == "fp8" and nq == N:
+            f = self._fp8_operands(ws, b)
+            call("mca_attn_quant_mxfp8", a.q, a.q_bstride, a.q_ld, a.k, a.v, a.kv_bstride, a.kv_ld, C.byref(f), b, self.H, N, stream_ptr())
+            call("mca_attn_fwd_fp8", C.byref(a), C.byref(f), stream_ptr(), flops=4.0 * 64 * sched.s.allowed_pairs * self.H * b)
+        else:
+            call("mca_attn_fwd", C.byref(a), stream_ptr(), flops=4.0 * 64 * sched.s.allowed_pairs * self.H * b)
         hip.set_tag("")
 
     def _attn_bwd2(self, q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, d_o, lse, delta, dq_ptr, dq_bstride, dq_ld, dq_f32, dkv,

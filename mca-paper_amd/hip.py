@@ -85,6 +85,11 @@ class AttnBwdArgs(C.Structure):
     ]
 
 
+class AttnFp8Operands(C.Structure):
+    _fields_ = [("q8", C.c_void_p), ("qs", C.c_void_p), ("k8", C.c_void_p), ("ks", C.c_void_p), ("v8t", C.c_void_p), ("vs", C.c_void_p),
+                ("n_ktiles", C.c_int)]
+
+
 class AttnBwd2Args(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("q_bstride", C.c_int64), ("q_ld", C.c_int64),
@@ -128,6 +133,8 @@ SIGNATURES = {
     "mca_build_keyinfo": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "mca_attn_vmean": (_I, [_P, _I64, _I64, _P, _I, _I, _I, _P]),
     "mca_attn_fwd": (_I, [C.POINTER(AttnFwdArgs), _P]),
+    "mca_attn_quant_mxfp8": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, C.POINTER(AttnFp8Operands), _I, _I, _I, _P]),
+    "mca_attn_fwd_fp8": (_I, [C.POINTER(AttnFwdArgs), C.POINTER(AttnFp8Operands), _P]),
     "mca_attn_bwd_prep": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mca_attn_bwd": (_I, [C.POINTER(AttnBwdArgs), _P]),
     "mca_attn_bwd_dq": (_I, [C.POINTER(AttnBwd2Args), _P]),

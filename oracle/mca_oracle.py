@@ -33,7 +33,12 @@ GLOBAL_TOKEN = -2   # model.py:311
 # --------------------------------------------------------------------------------------------------
 class Prec:
     def __init__(self, mode: str = "fp32"):
-        assert mode in ("fp32", "fp64", "bf16emu")
+        assert mode in ("fp32", "fp64", "bf16emu", "fp8emu")
+        # fp8emu = bf16emu + MX-fp8 (e4m3, power-of-two scale per 32 elements) operands of Q K^T and P V in the SELF-attention
+        # layers, as mca_attn_quant_mxfp8 / mca_attn_fwd_fp8 compute them (BASELINE configs[4]); gradients straight-through
+        self.fp8 = mode == "fp8emu"
+        if self.fp8:
+            mode = "bf16emu"
         self.mode = mode
         self.dtype = torch.float64 if mode == "fp64" else torch.float32
 
@@ -59,6 +64,42 @@ class _RoundBoth(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g.to(torch.bfloat16).to(g.dtype)
+
+
+def mx_e4m3(x: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    """OCP MX-fp8 round trip along ``dim`` (length a multiple of 32): per 32-element block one power-of-two scale
+    2^(floor(log2(amax)) - 7) and e4m3 elements (|x| / scale < 256: no saturation), as mca_attn_quant_mxfp8 does.
+    Returns the de-quantised values; straight-through gradient."""
+    xd = x.detach().movedim(dim, -1)
+    shp = xd.shape
+    xb = xd.reshape(*shp[:-1], shp[-1] // 32, 32).to(torch.float32)
+    am = xb.abs().amax(-1, keepdim=True)
+    e = torch.floor(torch.log2(am.clamp_min(2.0 ** -126))) - 7.0
+    e = torch.where(am > 0, e.clamp_min(-127.0), torch.full_like(e, -127.0))
+    sc = torch.exp2(e)
+    q = (xb / sc).to(torch.float8_e4m3fn).to(torch.float32) * sc
+    q = q.reshape(shp).movedim(-1, dim).to(x.dtype)
+    return x + (q - x.detach())
+
+
+def fp8_attention_core(q2, k, v, blocked):
+    """q2 (b,h,n,64) already in the log2 domain (scale * log2 e folded in), k, v (b,h,n,64), blocked (b,1|h,n,n) bool.
+    MX-fp8 Q, K (blocks of 32 along d) and V (blocks of 32 consecutive keys), P fed as e4m3(128 * 2^(S - m)), row sum of the
+    unrounded P; a row with every key blocked is uniform over all n keys (reference semantics)."""
+    b, h, n, d = q2.shape
+    n_pad = (n + 31) // 32 * 32
+    q8, k8 = mx_e4m3(q2, -1), mx_e4m3(k, -1)
+    v8 = mx_e4m3(torch.nn.functional.pad(v, (0, 0, 0, n_pad - n)), 2)[:, :, :n, :]
+    s2 = torch.einsum("bhid,bhjd->bhij", q8, k8)
+    s2 = s2.masked_fill(blocked, float("-inf"))
+    m = s2.max(dim=-1, keepdim=True).values
+    uniform = torch.isinf(m) & (m < 0)
+    e = torch.exp2(s2 - torch.where(uniform, torch.zeros_like(m), m))
+    l = e.sum(-1, keepdim=True)
+    e128 = 128.0 * e
+    p8 = e128 + ((e128.detach().to(torch.float8_e4m3fn).to(e.dtype)) - e128.detach())
+    out = torch.einsum("bhij,bhjd->bhid", p8, v8) / (128.0 * l.clamp_min(1e-30))
+    return torch.where(uniform, v.mean(dim=2, keepdim=True).expand_as(out), out)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -266,7 +307,14 @@ def attention(x, ctx, wq, wkv, wo, attn_mask, kpm, heads, P: Prec):
     if kpm is not None:
         sim = sim.masked_fill(kpm[:, None, None, :], neg)
     attn = sim.softmax(dim=-1)
-    if P.mode == "bf16emu":
+    if P.fp8 and ctx is None:
+        blocked = torch.zeros(b, 1, n, n, dtype=torch.bool, device=x.device)
+        if attn_mask is not None:
+            blocked = blocked | attn_mask[None, None]
+        if kpm is not None:
+            blocked = blocked | kpm[:, None, None, :]
+        out = fp8_attention_core(P.r(q * 1.4426950408889634), k, v, blocked)
+    elif P.mode == "bf16emu":
         # the HIP path feeds P (un-normalised) to the PV MFMA in bf16 and divides by the fp32 row sum
         m = sim.max(dim=-1, keepdim=True).values
         e = torch.exp(sim - m)

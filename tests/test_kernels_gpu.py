@@ -517,6 +517,98 @@ def test_attention_long_sequence_shape(H):
     _attention_case(H, st, b=1, heads=2, pool=False, seed=13, drop_first=False)
 
 
+# ------------------------------------------------------------------------------------------- fp8 attention
+@pytest.mark.parametrize("shape", ["small", "cmu", "long"])
+def test_attention_fp8_forward(H, shape):
+    """BASELINE configs[4]: Q K^T and P V on the block-scaled fp8 matrix instruction.  Checked against (a) the oracle's
+    emulation of the same MX-fp8 arithmetic (oracle.fp8_attention_core: e4m3 elements, one power-of-two scale per 32 elements
+    along d for Q and K and per 32 consecutive keys for V, P as e4m3(128 * 2^(S - m))): STATED TOLERANCE 1e-2 rel-L2 (accumulation
+    order and the fp32 exp2 are the only differences) and (b) the exact fp64 attention: what e4m3 operands cost on these
+    inputs (unit-variance q, k rows spread over 6 octaves: logits of +-20, a stress case) is 7-10 %; the kernel must be within
+    1.05 x the emulation's own distance + 1e-3 and below 0.12.
+    The quantised operands themselves are compared value for value."""
+    from oracle import mca_oracle as O
+    S = importlib.import_module("mca-paper_amd.structure")
+    eng = importlib.import_module("mca-paper_amd.engine")
+    if shape == "small":
+        st, b, heads = S.FusionStructure([70, 45, 30], 8, (3, 2), fcl=True), 3, 2
+    elif shape == "cmu":
+        st, b, heads = S.FusionStructure([1500, 450, 450, 50], 88, (4, 3, 2), fcl=True), 2, 2
+    else:
+        st, b, heads = S.FusionStructure([1500, 1500, 1500, 1500], 88, (4, 3, 2), fcl=True), 1, 2          # N = 6088
+    dev = "cuda"
+    N, D = st.n_tokens, heads * 64
+    g = torch.Generator(device=dev).manual_seed(21)
+    sf = eng._Sched(st.attn_schedule(128, 64), dev)
+    qmask = torch.from_numpy(st.qmask_attn.astype(np.uint32).view(np.int32)).to(dev)
+    kgroup = torch.from_numpy(st.kgroup).to(dev)
+    allowed = torch.from_numpy(~st.dense_attn_mask()).to(dev)
+    pad = torch.zeros(b, N, dtype=torch.bool, device=dev)
+    off = 0
+    for mi, n in enumerate(st.token_dims):
+        ln = torch.randint(1, n + 1, (b,), generator=g, device=dev)
+        if mi == 0:
+            ln[0] = 0                                   # a dropped modality: uniform rows
+        pad[:, off:off + n] = torch.arange(n, device=dev)[None] >= ln[:, None]
+        off += n
+    qkv = torch.randn(b, N, 3 * D, device=dev, generator=g)
+    qkv[:, :, D:2 * D] *= torch.exp2(torch.randint(-3, 4, (b, N, 1), device=dev, generator=g).float())          # rows of very different magnitude
+    qkv = bf(qkv)
+    qkv[:, :, :D] = bf(qkv[:, :, :D].float() * C2)          # q as the engine stores it
+    nk_pad = (N + 255) // 256 * 256
+    nt = (N + 63) // 64
+    keyinfo = torch.empty(b, nk_pad, dtype=torch.uint8, device=dev)
+    kflags = torch.empty(b, nt, dtype=torch.uint8, device=dev)
+    H.call("mca_build_keyinfo", pad.to(torch.uint8).data_ptr(), kgroup.data_ptr(), keyinfo.data_ptr(), kflags.data_ptr(), b, N, nk_pad, H.stream_ptr())
+    vmean = torch.empty(b, D, device=dev)
+    vptr = qkv.data_ptr() + 2 * D * 2
+    H.call("mca_attn_vmean", vptr, N * 3 * D, 3 * D, vmean.data_ptr(), b, N, heads, H.stream_ptr())
+    u8 = lambda *s_: torch.zeros(*s_, dtype=torch.uint8, device=dev)
+    q8, qs, k8, ks, v8t, vs = u8(b, heads, nt * 64, 64), u8(b, heads, nt * 64, 2), u8(b, heads, nt * 64, 64), u8(b, heads, nt * 64, 2), u8(b, heads, nt, 64, 64), u8(b, heads, nt, 64, 2)
+    f = H.AttnFp8Operands()
+    f.q8, f.qs, f.k8, f.ks, f.v8t, f.vs, f.n_ktiles = q8.data_ptr(), qs.data_ptr(), k8.data_ptr(), ks.data_ptr(), v8t.data_ptr(), vs.data_ptr(), nt
+    H.call("mca_attn_quant_mxfp8", qkv.data_ptr(), N * 3 * D, 3 * D, qkv.data_ptr() + D * 2, vptr, N * 3 * D, 3 * D, C.byref(f), b, heads, N, H.stream_ptr())
+    torch.cuda.synchronize()
+    # ---- operands, value for value
+    q4 = qkv[:, :, :D].float().view(b, N, heads, 64).permute(0, 2, 1, 3)
+    k4 = qkv[:, :, D:2 * D].float().view(b, N, heads, 64).permute(0, 2, 1, 3)
+    v4 = qkv[:, :, 2 * D:].float().view(b, N, heads, 64).permute(0, 2, 1, 3)
+    deq = lambda x8, xs: x8.view(torch.float8_e4m3fn).float().view(*x8.shape[:-1], 2, 32) * torch.exp2(xs.float() - 127.0)[..., None]
+    assert torch.equal(deq(q8, qs).flatten(-2)[:, :, :N], O.mx_e4m3(q4, -1))
+    assert torch.equal(deq(k8, ks).flatten(-2)[:, :, :N], O.mx_e4m3(k4, -1))
+    pp = torch.arange(64, device=dev)          # position -> key inside a 64-key tile (include/mca_hip.h, mca_attn_fp8_operands)
+    pos = (torch.arange(0, nt * 64, 64, device=dev)[:, None] + (32 * (pp >> 5) + 8 * ((pp >> 2) & 3) + 4 * ((pp >> 4) & 1) + (pp & 3))[None]).reshape(-1)
+    vp = torch.nn.functional.pad(v4, (0, 0, 0, nt * 64 - N))[:, :, pos, :]                    # (b, h, positions, d)
+    want_v = O.mx_e4m3(vp, 2).view(b, heads, nt, 64, 64).transpose(-1, -2)                    # (b, h, tile, d, position)
+    assert torch.equal(deq(v8t, vs).flatten(-2), want_v)
+    # ---- forward
+    o = torch.zeros(b * N, D, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(b, heads, N, device=dev)
+    a = H.AttnFwdArgs()
+    a.q, a.q_bstride, a.q_ld = qkv.data_ptr(), N * 3 * D, 3 * D
+    a.k, a.v, a.kv_bstride, a.kv_ld = qkv.data_ptr() + D * 2, vptr, N * 3 * D, 3 * D
+    a.o, a.o_bstride, a.o_ld, a.lse = o.data_ptr(), N * D, D, lse.data_ptr()
+    a.qmask, a.keyinfo, a.ktile_flags = qmask.data_ptr(), keyinfo.data_ptr(), kflags.data_ptr()
+    a.q_ptr, a.q_kt, a.q_order = sf.q_ptr.data_ptr(), sf.q_kt.data_ptr(), sf.q_order.data_ptr()
+    a.vmean = vmean.data_ptr()
+    a.batch, a.heads, a.nq, a.nk, a.nk_pad, a.n_qtiles, a.n_ktiles, a.scale = b, heads, N, N, nk_pad, sf.s.n_q, sf.s.n_k, 0.125
+    a.flags = H.ATTN_Q_PRESCALED
+    H.call("mca_attn_fwd_fp8", C.byref(a), C.byref(f), H.stream_ptr())
+    torch.cuda.synchronize()
+    got = o.float().view(b, N, heads, 64).permute(0, 2, 1, 3)
+    blocked = (~allowed)[None, None] | pad[:, None, None, :]
+    emu = O.fp8_attention_core(q4, k4, v4, blocked)
+    exact = dense_attention((q4 / C2).double(), k4.double(), v4.double(), allowed, pad, 0.125)
+    e_emu, e_exact, e_floor = rel(got, emu), rel(got, exact.float()), rel(emu, exact.float())
+    assert e_emu < 1e-2, f"fp8 forward vs its emulation: {e_emu}"
+    assert e_exact < 0.12 and e_exact < 1.05 * e_floor + 1e-3, f"fp8 forward vs exact attention: {e_exact} (emulation itself: {e_floor})"
+    uni = blocked.all(-1)[:, 0]                                                               # (b, N)
+    assert torch.equal(torch.isinf(lse[:, 0]), uni) and uni.any()
+    fin = ~uni
+    lse_ref = torch.logsumexp((torch.einsum("bhid,bhjd->bhij", O.mx_e4m3(q4, -1), O.mx_e4m3(k4, -1)).masked_fill(blocked, float("-inf")) * 0.6931471805599453)[:, 0], -1) * 1.4426950408889634
+    assert (lse[:, 0][fin] - lse_ref[fin]).abs().max() < 2e-2
+
+
 # ------------------------------------------------------------------------------------------------ loss
 @pytest.mark.parametrize("variant,world", [("mca", 1), ("bimodal", 1), ("zorro", 1), ("mca", 2), ("bimodal", 4)])
 def test_contrastive_loss(H, variant, world):

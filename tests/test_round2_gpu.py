@@ -393,7 +393,7 @@ def test_graphed_step_matches_eager(P):
     batches = [to_device(P.data.synthetic_batch(cfg, 4, seed=40 + i, p_drop=0.2), "cuda") for i in range(5)]
     lrs = [1e-3, 2e-3, 0.0, 1e-3, 3e-3]
     runs = []
-    for graphed in (False, True):
+    for graphed in (False, False, True):
         m = P.MCA(**copy.deepcopy(cfg)); m.load_state_dict(sd, strict=False); m = m.cuda()
         m.engine.check_finite = "deferred"
         opt = optim.FusedAdamW(m, lr=lrs[0], weight_decay=0.0)
@@ -415,21 +415,33 @@ def test_graphed_step_matches_eager(P):
         torch.cuda.synchronize()
         m.engine.assert_finite()
         runs.append((losses, snaps, m, opt, g if graphed else None))
-    (le, se, _, _, _), (lg, sg, mg, og, g) = runs
-    # the same kernels on the same data: the first steps agree to fp32-atomic noise.  Later ones drift apart faster than that:
-    # Adam's early updates are ~lr * sign(g), so a gradient element at the noise level flips a whole lr of weight
-    assert abs(le[0] - lg[0]) <= 1e-5 * abs(le[0]) and abs(le[1] - lg[1]) <= 1e-4 * abs(le[1]), (le, lg)
-    for a, b_ in zip(le, lg):
-        assert abs(a - b_) <= 2e-2 * abs(a), (le, lg)
-    assert rel_err(sg[0], se[0]) < 1e-5 and rel_err(sg[-1], se[-1]) < 5e-3
+    (le, se, _, _, _), (le2, se2, _, _, _), (lg, sg, mg, og, g) = runs
+    # the same kernels on the same data.  The yardstick is the eager loop against ITSELF: the fp32-atomic accumulation order of
+    # the weight gradients differs from run to run, and Adam's early updates (~lr * sign(g)) turn a gradient element at the
+    # noise level into a whole lr of weight, so two eager runs already drift apart; the replay must stay within 3x that drift
+    drift_l = [abs(a - b_) / abs(a) for a, b_ in zip(le, le2)]
+    drift_w = [rel_err(a, b_) for a, b_ in zip(se, se2)]
+    print("graph test: eager-eager loss drift", drift_l, "weights", drift_w)
+    print("graph test: graph-eager loss drift", [abs(a - b_) / abs(a) for a, b_ in zip(le, lg)], "weights", [rel_err(a, b_) for a, b_ in zip(se, sg)])
+    assert abs(le[0] - lg[0]) <= 1e-5 * abs(le[0]), (le, lg)
+    for i in range(len(le)):
+        assert abs(le[i] - lg[i]) <= 3 * drift_l[i] * abs(le[i]) + 2e-3 * abs(le[i]), (i, le, le2, lg)
+        assert rel_err(sg[i], se[i]) <= 3 * drift_w[i] + 1e-3, (i, rel_err(sg[i], se[i]), drift_w[i])
     # lr = 0 (weight decay 0) at the third step: the replay read THIS step's learning rate, the weights did not move
     assert torch.equal(sg[2], sg[1]) and not torch.equal(sg[3], sg[2])
     # a non-finite batch through the graph: the device flag stops the fused AdamW, the next poll raises
     bad = copy.deepcopy(batches[0]); bad["audio"]["tokens"][0, 0, 0] = float("nan")
-    before = mg.engine.flat.clone()
+    before, m_before, v_before = mg.engine.flat.clone(), og.exp_avg.clone(), og.exp_avg_sq.clone()
     og.param_groups[0]["lr"] = 1e-3
     g.step(bad)
     torch.cuda.synchronize()
-    assert torch.equal(mg.engine.flat, before)
+    assert torch.equal(og.exp_avg, m_before) and torch.equal(og.exp_avg_sq, v_before)
+    # the weights: untouched except the table encoder's embedding rows, which its FORWARD renormalises in place
+    # (nn.Embedding(max_norm=...), encoders.py TabularEncoder) whatever happens to the step afterwards
+    moved = mg.engine.flat != before
+    emb = mg.encoders["video"].token_encoder.embedding.weight
+    i0 = (emb.data_ptr() - mg.engine.flat.data_ptr()) // 4
+    moved[i0:i0 + emb.numel()] = False
+    assert not bool(moved.any())
     with pytest.raises(Exception, match="not finite"):
         mg.engine.assert_finite()

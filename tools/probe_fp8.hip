@@ -115,3 +115,21 @@ extern "C" int probe_fp8_rate(int mode, int blocks, int threads, int iters, floa
   hipEventDestroy(e0); hipEventDestroy(e1);
   return 0;
 }
+
+// scale semantics: D = mfma_scale(A, B, 0, scale_a = sa[lane], scale_b = sb[lane]) with the byte selectors as compiled (0);
+// SEL = 1 compiles the byte-1 selector for both
+template <int SEL>
+__global__ void scale_kernel(const int* A, const int* B, const int* sa, const int* sb, float* out) {
+  const int lane = threadIdx.x;
+  v8i a, b;
+  for (int i = 0; i < 8; i++) { a[i] = A[lane * 8 + i]; b[i] = B[lane * 8 + i]; }
+  f32x16 c;
+  for (int i = 0; i < 16; i++) c[i] = 0.f;
+  const f32x16 d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, SEL, sa[lane], SEL, sb[lane]);
+  for (int i = 0; i < 16; i++) out[lane * 16 + i] = d[i];
+}
+extern "C" int probe_fp8_scale(const int* A, const int* B, const int* sa, const int* sb, float* out, int sel) {
+  if (sel) hipLaunchKernelGGL(scale_kernel<1>, dim3(1), dim3(64), 0, 0, A, B, sa, sb, out);
+  else hipLaunchKernelGGL(scale_kernel<0>, dim3(1), dim3(64), 0, 0, A, B, sa, sb, out);
+  return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+}
