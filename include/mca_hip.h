@@ -173,7 +173,8 @@ int mca_nonfinite_flag(const mca_finite_args* args, int32_t* flag, int bit, mca_
 int mca_build_keyinfo(const uint8_t* padding, const uint8_t* kgroup, uint8_t* keyinfo,
                       uint8_t* ktile_flags, int batch, int nk, int nk_pad, mca_stream_t stream);
 
-/* vmean[b, h*64+d] = mean over ALL nk keys of V  (value of a fully-masked softmax row)          */
+/* vmean[b, h*64+d] = mean over ALL nk keys of V  (value of a fully-masked softmax row); fixed summation order:
+ * bitwise reproducible                                                                            */
 int mca_attn_vmean(const uint16_t* V, int64_t kv_bstride, int64_t kv_ld, float* vmean,
                    int batch, int nk, int heads, mca_stream_t stream);
 

@@ -160,7 +160,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
     FW_STAMP();
     const uint32_t ent = live_s[it];
     const int kt = (int)(ent & 0x7fffffffu);
+#ifdef ABL_NOMASK
+    const bool need_mask = false;
+#else
     const bool need_mask = (ent >> 31) == 0 || (flags_s[kt] != 2);
+#endif
     const int nit = it + 1;
     if (nit < it_end) gload((int)(live_s[nit] & 0x7fffffffu));
 
@@ -654,30 +658,29 @@ extern "C" int mca_build_keyinfo(const uint8_t* padding, const uint8_t* kgroup, 
   return launch_status();
 }
 
-// vmean[b, c] = (1/nk) sum_j V[b, j, c]   c in [0, heads*64).  grid (key slabs, b): each wavefront sums whole
-// 16-byte pieces of rows (8 columns per lane), partial sums go out as one atomic per column per workgroup.
-__global__ __launch_bounds__(256) void vmean_kernel(const u16* __restrict__ V, int64_t bstride, int64_t ld,
-                                                     float* __restrict__ vmean, int nk, int cols, int keys_per_block) {
-  __shared__ float red[4][512];
-  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int k0 = blockIdx.x * keys_per_block;
-  int k1 = k0 + keys_per_block; if (k1 > nk) k1 = nk;
-  const float inv = 1.f / (float)nk;
-  for (int c0 = 0; c0 < cols; c0 += 512) {
-    const int c = c0 + lane * 8;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (c < cols)
-      for (int j = k0 + wave; j < k1; j += 4) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(V + (int64_t)b * bstride + (int64_t)j * ld + c);
+// vmean[b, c] = (1/nk) sum_j V[b, j, c]   c in [0, heads*64).  grid (64-column chunks, b), 512 threads: 8 lanes cover the 64
+// columns of a row (16 bytes each), 64 row groups stride the keys; the partial sums meet in LDS in a FIXED order, so the result
+// is bitwise reproducible (it is the output of every query row without a valid key: an atomic here made the whole step's
+// gradients differ from run to run at the 1e-3 level).
+__global__ __launch_bounds__(512) void vmean_kernel(const u16* __restrict__ V, int64_t bstride, int64_t ld,
+                                                     float* __restrict__ vmean, int nk, int cols) {
+  __shared__ float red[64][65];
+  const int b = blockIdx.y, c0 = blockIdx.x * 64;
+  const int cl = threadIdx.x & 7, rg = threadIdx.x >> 3;
+  const u16* base = V + (int64_t)b * bstride + c0 + cl * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int j = rg; j < nk; j += 64) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + (int64_t)j * ld);
 #pragma unroll
-        for (int e = 0; e < 8; e++) acc[e] += bf2f((u16)v[e]);
-      }
+    for (int e = 0; e < 8; e++) acc[e] += bf2f((u16)v[e]);
+  }
 #pragma unroll
-    for (int e = 0; e < 8; e++) red[wave][lane * 8 + e] = acc[e];
-    __syncthreads();
-    for (int i = threadIdx.x; i < 512 && c0 + i < cols; i += 256)
-      atomicAdd(vmean + (int64_t)b * cols + c0 + i, (red[0][i] + red[1][i] + red[2][i] + red[3][i]) * inv);
-    __syncthreads();
+  for (int e = 0; e < 8; e++) red[rg][cl * 8 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float t = 0.f;
+    for (int r = 0; r < 64; r++) t += red[r][threadIdx.x];
+    vmean[(int64_t)b * cols + c0 + threadIdx.x] = t * (1.f / (float)nk);
   }
 }
 extern "C" int mca_attn_vmean(const uint16_t* V, int64_t kv_bstride, int64_t kv_ld, float* vmean, int batch, int nk,
@@ -685,9 +688,7 @@ extern "C" int mca_attn_vmean(const uint16_t* V, int64_t kv_bstride, int64_t kv_
   if (!V || !vmean || batch <= 0 || nk <= 0 || heads <= 0) return MCA_E_BADARG;
   const int cols = heads * DH;
   if (kv_ld % 8 || kv_bstride % 8 || (uintptr_t)V % 16) return MCA_E_ALIGN;
-  if (hipMemsetAsync(vmean, 0, (size_t)batch * cols * sizeof(float), as_stream(stream)) != hipSuccess) return MCA_E_LAUNCH;
-  const int kpb = 64;
-  hipLaunchKernelGGL(vmean_kernel, dim3((nk + kpb - 1) / kpb, batch), dim3(256), 0, as_stream(stream), V, kv_bstride, kv_ld,
-                     vmean, nk, cols, kpb);
+  if (batch > 65535) return MCA_E_UNSUPPORTED;
+  hipLaunchKernelGGL(vmean_kernel, dim3(heads, batch), dim3(512), 0, as_stream(stream), V, kv_bstride, kv_ld, vmean, nk, cols);
   return launch_status();
 }

@@ -344,10 +344,10 @@ def test_micro_batch_split_matches_unsplit(P, variant):
         assert rel_err(g1[n], g0[n]) <= tol, (n, rel_err(g1[n], g0[n]))
 
 
-@pytest.mark.parametrize("b", [8, 32])
-def test_forward_bitwise_deterministic_at_cmu_size(P, b):
-    """Nothing in the forward accumulates in an order-dependent way (mca_attn_vmean only matters for rows with no valid key),
-    so repeated forwards must agree BIT FOR BIT.  This is the test that catches a mis-counted s_waitcnt in a pipelined
+@pytest.mark.parametrize("b,lengths,p_drop", [(8, "full", 0.0), (32, "full", 0.0), (32, "uniform", 0.2)])
+def test_forward_bitwise_deterministic_at_cmu_size(P, b, lengths, p_drop):
+    """Nothing in the forward accumulates in an order-dependent way (mca_attn_vmean, the value of rows with no valid key -
+    dropped modalities - sums in a fixed order since round 2), so repeated forwards must agree BIT FOR BIT.  This is the test that catches a mis-counted s_waitcnt in a pipelined
     kernel: a stale-LDS race shows up as a small fraction of wrong elements that every tolerance-based check lets through,
     and only with the whole chip busy (b = 32)."""
     cfg = P.config.cmu_model_config(batch_size=b)
@@ -355,7 +355,7 @@ def test_forward_bitwise_deterministic_at_cmu_size(P, b):
     model = P.MCA(**cfg).cuda()
     model.engine.check_finite = False
     data = importlib.import_module("mca-paper_amd.data")
-    batch = data.synthetic_batch(cfg, b, seed=1234, lengths="full", device="cuda")
+    batch = data.synthetic_batch(cfg, b, seed=1234, lengths=lengths, p_drop=p_drop, device="cuda")
     ref = None
     for _ in range(4):
         with torch.no_grad():

@@ -11,6 +11,12 @@ model = P.MCA(**cfg).cuda(); eng = model.engine
 ws = eng.workspace(b)
 N, D, Hh = eng.N, eng.D, eng.H
 ws["padding"].zero_()
+if os.environ.get("MCA_BENCH_ATTN_PAD"):          # the bench's padding (uniform lengths, 20 % of the modalities dropped) instead of none
+    g = torch.Generator(device="cuda").manual_seed(7)
+    for mi, n in enumerate(eng.st.token_dims):
+        ln = torch.randint(1, n + 1, (b,), device="cuda", generator=g)
+        ln[torch.rand(b, device="cuda", generator=g) < 0.2] = 0
+        ws["padding"][:, eng.offsets[mi]:eng.offsets[mi] + n] = (torch.arange(n, device="cuda")[None] >= ln[:, None]).to(ws["padding"].dtype)
 H.call("mca_build_keyinfo", ws["padding"].data_ptr(), eng.kgroup.data_ptr(), ws["keyinfo"].data_ptr(), ws["kflags"].data_ptr(), b, N, eng.nk_pad, H.stream_ptr())
 a = ws["layers"][0]
 a["qkv"].copy_(torch.randn_like(a["qkv"].float()).bfloat16())
@@ -27,10 +33,12 @@ def bwd():
 def timeit(fn, n=10):
     for _ in range(3): fn()
     torch.cuda.synchronize()
-    H.profile_start(("mca_attn_fwd", "mca_attn_bwd", "mca_attn_bwd_dq", "mca_attn_bwd_dkv"))
+    H.profile_start(("mca_attn_fwd", "mca_attn_fwd_fp8", "mca_attn_quant_mxfp8", "mca_attn_bwd", "mca_attn_bwd_dq", "mca_attn_bwd_dkv"))
     for _ in range(n): fn()
     return H.profile_stop()
-cases = [("fwd", fwd, {}), ("fwd second form", fwd, {13: 2}), ("bwd", bwd, {})]
+def fwd8():
+    eng.set_attention_dtype("fp8"); fwd(); eng.set_attention_dtype("bf16")
+cases = [("fwd", fwd, {}), ("fwd second form", fwd, {13: 2}), ("fwd fp8", fwd8, {}), ("bwd", bwd, {})]
 if os.environ.get("MCA_BENCH_ATTN_ONLY"):
     cases = [c for c in cases if c[0] == os.environ["MCA_BENCH_ATTN_ONLY"]]
 if os.environ.get("MCA_BENCH_ATTN_EXTRA"):
