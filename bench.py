@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-protocol", default="short", choices=["short", "full"])
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--sample-every", type=int, default=10, help="record per-kernel HIP events on every n-th timed step")
+    ap.add_argument("--sample-every", type=int, default=20, help="record per-kernel HIP events on every n-th timed step (a sampled step runs its kernels one at a time and costs ~1.3 steps)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -366,9 +366,13 @@ class FusionEngine:
     @staticmethod
     def gemm_nt(A, B, C, M, N, K, bias=None, residual=None, res_period=0):
         """C[M,N] = A[M,K] B[N,K]^T (+bias) (+residual)."""
+        if hip.PROFILE is not None:          # live timing (bench.py): one key per problem shape, so an average is over equal launches
+            hip.set_tag(f"{M}x{N}x{K}{'' if C.dtype == torch.bfloat16 else ' f32'}{' +res' if residual is not None else ''}")
         call("mca_gemm_nt", ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), C.stride(0), int(C.dtype == torch.bfloat16),
              ptr(bias), ptr(residual), residual.stride(0) if residual is not None else 0, res_period, M, N, K, stream_ptr(),
              flops=2.0 * M * N * K)
+        if hip.PROFILE is not None:
+            hip.set_tag("")
 
     @staticmethod
     def gemm_tn_acc(A, B, Cgrad, R, N, K):
