@@ -265,7 +265,8 @@ def test_infer_script_reproduces_reference_embeddings(P, tmp_path):
 def test_long_config_at_batch_128(P):
     """BASELINE configs[4]: 4 x 1500 tokens + 88 fusion tokens (N = 6088), batch 128 on one GPU (779,264 tokens; ~135 GB of
     activations, every row offset beyond 2^31 bytes).  Size-independent properties: repeated forwards agree bit for bit,
-    the loss is finite, every parameter gets a finite, non-zero gradient, and the samples of the batch do not interact
+    the fp8 form of the forward attention agrees with the bf16 form within the stated tolerance, the loss is finite, every
+    parameter gets a finite, non-zero gradient, and the samples of the batch do not interact
     before the loss (rows 0..1 of the b = 128 pass equal a b = 2 pass of the same samples)."""
     optim = importlib.import_module("mca-paper_amd.optim")
     b = 128
@@ -282,13 +283,18 @@ def test_long_config_at_batch_128(P):
     with torch.no_grad():
         o1 = model(batch); p1 = eng.workspace(b)["pooled"].clone(); l1 = o1["loss"].clone()
         o2 = model(batch); p2 = eng.workspace(b)["pooled"].clone(); l2 = o2["loss"].clone()
-    # rows with no valid key take mean(V), summed with fp32 atomics (order-dependent): bit-exactness holds for every other row
-    present = eng.workspace(b)["present_cur"]
-    full = (present == 15).nonzero().flatten()
-    assert len(full) > 8
+    # nothing in the forward is order-dependent (mean(V) of rows with no valid key sums in a fixed order): bit for bit
     R = eng.R
-    assert torch.equal(p1.view(b, R, -1)[full], p2.view(b, R, -1)[full])
-    assert abs(float(l1) - float(l2)) <= 2e-4 * abs(float(l1))
+    assert torch.equal(p1, p2) and torch.equal(l1, l2)
+    # the fp8 form of the forward attention (configs[4] names it) at full size: STATED TOLERANCE 1e-2 rel-L2 on the pooled
+    # embeddings against the bf16 form (5 layers of e4m3 operands; measured value printed), loss within 2 %
+    eng.set_attention_dtype("fp8")
+    with torch.no_grad():
+        o8 = model(batch); p8 = eng.workspace(b)["pooled"].clone(); l8 = o8["loss"].clone()
+    eng.set_attention_dtype("bf16")
+    e8 = rel_err(p8, p1)
+    print("long config: fp8 vs bf16 pooled rel-L2", e8, "loss", float(l8), float(l1))
+    assert torch.isfinite(p8).all() and e8 < 1e-2 and abs(float(l8) - float(l1)) <= 2e-2 * abs(float(l1))
     out = model(batch)
     opt.zero_grad(); out["loss"].backward(); optim.clip_grad_norm_(model, 2.0); opt.step()
     torch.cuda.synchronize()
@@ -308,10 +314,7 @@ def test_long_config_at_batch_128(P):
     ps = m2.engine.workspace(2)["pooled"].view(2, R, -1)
     pr2 = m2.engine.workspace(2)["present_cur"]
     for i in range(2):
-        if int(pr2[i]) == 15:
-            assert torch.equal(ps[i], pb[i])
-        else:
-            assert rel_err(ps[i], pb[i]) < 1e-4
+        assert torch.equal(ps[i], pb[i])
 
 
 # ------------------------------------------------------------------------------------------------ data parallel
