@@ -199,6 +199,20 @@ typedef struct {
 /* dim_head is fixed at 64; query tile 128 rows, key tile 64.                                     */
 int mca_attn_fwd(const mca_attn_fwd_args* args, mca_stream_t stream);
 
+/* ---- EAO baseline (model.py:481-596): every modality alone and every combination of modalities is one SEGMENT of a
+ * super-sequence; the attention kernels' key groups make the attention block-diagonal over segments.
+ * dst[b, r, :] (+)= src[b, r, :], r < rows: replicates a modality's encoded token block into its segments (accumulate = 0)
+ * and sums the gradients of the replicas back (accumulate = 1); strides in floats.                                        */
+int mca_rows_copy_add(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride, int64_t rows, int cols,
+                      int batch, int accumulate, mca_stream_t stream);
+/* MeanTokenProjectionPool without token types / projection (model.py:255-276): out[b, s, :] = mean of the un-padded rows
+ * seg_start[s] .. seg_start[s+1]-1 of x[b] (zeros if none); counts[b, s] = their number.  Fixed summation order.          */
+int mca_segment_mean_fwd(const float* x, const uint8_t* padding, const int32_t* seg_start, int n_seg, float* out,
+                         int32_t* counts, int batch, int n_tokens, int cols, mca_stream_t stream);
+/* dx[b, r, :] = padded(b, r) ? 0 : d_out[b, seg_of_row[r], :] / counts[b, seg_of_row[r]]                                  */
+int mca_segment_mean_bwd(const float* d_out, const uint8_t* padding, const uint8_t* seg_of_row, const int32_t* counts,
+                         int n_seg, float* dx, int batch, int n_tokens, int cols, mca_stream_t stream);
+
 /* MX-fp8 operands of the fusion attention forward (BASELINE configs[4], "fp8 MFMA attention"): OCP e4m3 elements with one
  * E8M0 power-of-two scale byte per 32 elements along the contraction (d for Q and K; keys 0..31 | 32..63 of a 64-key tile
  * for V^T), the operand format of v_mfma_scale_f32_32x32x64_f8f6f4.  npad = n_ktiles * 64 token rows per (sample, head), rows >= n are zero.

@@ -26,7 +26,7 @@ def main():
     config = P.config.training_config(sys.argv[1])
     torch.manual_seed(0)                                                        # infer_accel_gpu.py:28 (seeds the predrop draws)
     model_config = P.config.get_model_config(config)
-    model = P.MCA(**model_config).to(device)
+    model = P.build_model(model_config).to(device)          # infer_accel_gpu.py:50-53
     if config.restart:
         missing, unexpected = P.checkpoint.load_model(model, config.restart, strict=False)
         if missing or unexpected:          # embeddings from partly random weights are worse than no embeddings

@@ -5,15 +5,13 @@ has a hyphen), or use the root-level shims ``model.py`` / ``encoders.py``.
 """
 from . import checkpoint, config, data, encoders, metrics, params, structure  # noqa: F401
 from .encoders import MultimodalCollator, collators, encoders_dict  # noqa: F401
-from .model import MCA  # noqa: F401
+from .model import MCA, EAO  # noqa: F401
 
 
 
 def build_model(model_config: dict):
     """``EAO(**model_config) if model_config['eao'] else MCA(**model_config)`` (train_accel_gpu.py:51-54)."""
-    if model_config.get("eao"):
-        raise NotImplementedError("EAO baseline model (model.py:481-596) is not built natively yet (SURVEY.md section 8f #4)")
-    return MCA(**model_config)
+    return EAO(**model_config) if model_config.get("eao") else MCA(**model_config)
 
 
-__all__ = ["build_model", "MCA", "encoders_dict", "collators", "MultimodalCollator", "config", "data", "params", "structure"]
+__all__ = ["build_model", "MCA", "EAO", "encoders_dict", "collators", "MultimodalCollator", "config", "data", "params", "structure"]

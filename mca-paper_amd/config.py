@@ -102,6 +102,14 @@ def cmu_model_config(batch_size: int = 8, zorro: bool = False, long_seq: bool = 
                 mean_pool=False)
 
 
+def cmu_eao_model_config(batch_size: int = 8) -> Dict[str, Any]:
+    """configs/CMU_config1_EAO.yaml of the reference: the EAO baseline on the CMU modalities (pairs of modalities as
+    combinations, pairwise + fusion-channel losses, mean pooling)."""
+    return dict(dim=512, depth=5, heads=8, dim_head=64, ff_mult=4, num_fusion_tokens=88, encoder_configs=copy.deepcopy(CMU_ENCODERS),
+                batch_size=batch_size, fcl=True, fcl_root=[0, 1], bimodal_contrastive=True, non_fusion_fcl=True,
+                fusion_combos=[2], zorro=False, eao=True, no_fusion=True, mean_pool=True)
+
+
 def tcga_model_config(batch_size: int = 8) -> Dict[str, Any]:
     return dict(dim=512, depth=5, heads=8, dim_head=64, ff_mult=4, num_fusion_tokens=88,
                 encoder_configs=copy.deepcopy(TCGA_ENCODERS), batch_size=batch_size, fcl=True, fcl_root=[0, 1, 2, 3],

@@ -735,3 +735,118 @@ extern "C" int mca_nonfinite_flag(const mca_finite_args* args, int32_t* flag, in
   hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)blocks, (unsigned)args->count), dim3(256), 0, as_stream(stream), *args, flag, bit);
   return launch_status();
 }
+
+// =====================================================================================================
+// EAO baseline ("everything at once", reference model.py:481-596): every modality alone and every modality combination is one
+// SEGMENT of a super-sequence (block-diagonal attention = the key-group masks of the fusion kernels); the token blocks of a
+// modality are replicated into its segments, and the pooled token of a segment is the mean of its un-padded rows
+// (MeanTokenProjectionPool without token types and without projection, model.py:255-276).
+// =====================================================================================================
+// dst[b, r, :] (+)= src[b, r, :]   rows x cols contiguous per sample (16-byte pieces)
+__global__ __launch_bounds__(256) void rows_copy_add_kernel(const float4* __restrict__ src, int64_t src_bstride4, float4* __restrict__ dst,
+                                                             int64_t dst_bstride4, int64_t per_sample4, int64_t total4, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / per_sample4, r = i - b * per_sample4;
+    float4 v = src[b * src_bstride4 + r];
+    float4* d = dst + b * dst_bstride4 + r;
+    if (accumulate) { const float4 o = *d; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    *d = v;
+  }
+}
+extern "C" int mca_rows_copy_add(const float* src, int64_t src_bstride, float* dst, int64_t dst_bstride, int64_t rows, int cols,
+                                 int batch, int accumulate, mca_stream_t stream) {
+  if (!src || !dst || rows < 0 || cols <= 0 || batch <= 0) return MCA_E_BADARG;
+  if (cols % 4 || src_bstride % 4 || dst_bstride % 4 || (uintptr_t)src % 16 || (uintptr_t)dst % 16) return MCA_E_ALIGN;
+  if (rows == 0) return MCA_OK;
+  const int64_t per4 = rows * cols / 4, total4 = per4 * batch;
+  hipLaunchKernelGGL(rows_copy_add_kernel, dim3(stream_grid(total4)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(src),
+                     src_bstride / 4, reinterpret_cast<float4*>(dst), dst_bstride / 4, per4, total4, accumulate);
+  return launch_status();
+}
+
+// out[b, s, :] = mean over the un-padded rows of segment s (zeros when there is none: model.py:267-268); counts[b, s] = their
+// number.  grid (segments, batch), 512 threads = 8 row groups x 64 lanes (4 columns each, columns strided by 256); the row
+// groups meet in LDS in a fixed order: bitwise reproducible.
+__global__ __launch_bounds__(512) void segment_mean_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ padding,
+                                                                const int32_t* __restrict__ seg_start, float* __restrict__ out,
+                                                                int32_t* __restrict__ counts, int n_tokens, int cols) {
+  __shared__ float red[8][1024];
+  __shared__ int cnt_s[8];
+  const int s = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int r0 = seg_start[s], r1 = seg_start[s + 1];
+  const uint8_t* pad = padding + (int64_t)b * n_tokens;
+  const float* xb = x + (int64_t)b * n_tokens * cols;
+  float4 acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int cnt = 0;
+  for (int r = r0 + rg; r < r1; r += 8) {
+    if (pad[r]) continue;
+    cnt++;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int c = lane * 4 + 256 * k;
+      if (c < cols) {
+        const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)r * cols + c);
+        acc[k].x += v.x; acc[k].y += v.y; acc[k].z += v.z; acc[k].w += v.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int c = lane * 4 + 256 * k;
+    if (c < cols) { red[rg][c] = acc[k].x; red[rg][c + 1] = acc[k].y; red[rg][c + 2] = acc[k].z; red[rg][c + 3] = acc[k].w; }
+  }
+  if (lane == 0) cnt_s[rg] = cnt;
+  __syncthreads();
+  int total = 0;
+#pragma unroll
+  for (int g = 0; g < 8; g++) total += cnt_s[g];
+  const float inv = total > 0 ? 1.f / (float)total : 0.f;
+  for (int c = threadIdx.x; c < cols; c += 512) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; g++) t += red[g][c];
+    out[((int64_t)b * gridDim.x + s) * cols + c] = t * inv;
+  }
+  if (threadIdx.x == 0) counts[(int64_t)b * gridDim.x + s] = total;
+}
+extern "C" int mca_segment_mean_fwd(const float* x, const uint8_t* padding, const int32_t* seg_start, int n_seg, float* out,
+                                    int32_t* counts, int batch, int n_tokens, int cols, mca_stream_t stream) {
+  if (!x || !padding || !seg_start || !out || !counts || n_seg <= 0 || batch <= 0 || n_tokens <= 0 || cols <= 0) return MCA_E_BADARG;
+  if (cols % 4 || (uintptr_t)x % 16) return MCA_E_ALIGN;
+  if (cols > 1024 || batch > 65535) return MCA_E_UNSUPPORTED;
+  hipLaunchKernelGGL(segment_mean_fwd_kernel, dim3(n_seg, batch), dim3(512), 0, as_stream(stream), x, padding, seg_start, out, counts,
+                     n_tokens, cols);
+  return launch_status();
+}
+
+// dx[b, r, :] = padded(b, r) ? 0 : d_out[b, seg(r), :] / counts[b, seg(r)]          one wavefront per row
+__global__ __launch_bounds__(256) void segment_mean_bwd_kernel(const float* __restrict__ d_out, const uint8_t* __restrict__ padding,
+                                                                const uint8_t* __restrict__ seg_of_row, const int32_t* __restrict__ counts,
+                                                                int n_seg, float* __restrict__ dx, int64_t rows_total, int n_tokens, int cols) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows_total; row += (int64_t)gridDim.x * 4) {
+    const int64_t b = row / n_tokens;
+    const int r = (int)(row - b * n_tokens);
+    const int s = seg_of_row[r];
+    const bool live = padding[row] == 0;
+    const float inv = live ? 1.f / (float)counts[b * n_seg + s] : 0.f;
+    const float* g = d_out + (b * n_seg + s) * (int64_t)cols;
+    for (int c = lane * 4; c < cols; c += 256) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live) { v = *reinterpret_cast<const float4*>(g + c); v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv; }
+      *reinterpret_cast<float4*>(dx + row * cols + c) = v;
+    }
+  }
+}
+extern "C" int mca_segment_mean_bwd(const float* d_out, const uint8_t* padding, const uint8_t* seg_of_row, const int32_t* counts,
+                                    int n_seg, float* dx, int batch, int n_tokens, int cols, mca_stream_t stream) {
+  if (!d_out || !padding || !seg_of_row || !counts || !dx || n_seg <= 0 || batch <= 0 || n_tokens <= 0 || cols <= 0) return MCA_E_BADARG;
+  if (cols % 4 || (uintptr_t)d_out % 16 || (uintptr_t)dx % 16) return MCA_E_ALIGN;
+  const int64_t rows = (int64_t)batch * n_tokens;
+  int64_t blocks = (rows + 3) / 4; if (blocks > 65535 * 16) blocks = 65535 * 16;
+  hipLaunchKernelGGL(segment_mean_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d_out, padding, seg_of_row, counts,
+                     n_seg, dx, rows, n_tokens, cols);
+  return launch_status();
+}

@@ -62,7 +62,9 @@ class _Sched:
 class FusionEngine:
     def __init__(self, model):
         self.model = model
-        p0 = model.fusion_tokens
+        p0 = next(model.parameters())
+        # EAO baseline (model.EAO): segments instead of fusion tokens, mean pooling instead of attentive pooling
+        self.eao = model.attn_pool is None
         if p0.device.type != "cuda":
             raise hip.MCAHipError("the MCA step runs only on a HIP device: move the model to cuda first "
                                   "(there is no CPU fallback)")
@@ -121,15 +123,18 @@ class FusionEngine:
         m = self.model
         order: List[torch.nn.Parameter] = []
         marks: List[int] = []                        # bucket boundaries (indices into `order`)
-        order += [m.loss.loss_fn.logit_scale, m.return_tokens, m.attn_pool.to_out.weight, m.attn_pool.to_q.weight,
-                  m.attn_pool.to_kv.weight, m.norm.gamma]
+        order += [m.loss.loss_fn.logit_scale]
+        if not self.eao:
+            order += [m.return_tokens, m.attn_pool.to_out.weight, m.attn_pool.to_q.weight, m.attn_pool.to_kv.weight]
+        order += [m.norm.gamma]
         marks.append(len(order))
         for i in reversed(range(self.L)):
             ly = m.layers[i]
             order += [ly.ff.feedforward[2].weight, ly.ff.feedforward[0].weight, ly.attn.to_out.weight,
                       ly.attn.to_q.weight, ly.attn.to_kv.weight, ly.norm.gamma]
             marks.append(len(order))
-        order.append(m.fusion_tokens)
+        if not self.eao:
+            order.append(m.fusion_tokens)
         for name in m.modality_types:
             order += list(m.encoders[name].parameters())
         marks.append(len(order))
@@ -170,8 +175,11 @@ class FusionEngine:
         self.qmask_pool = _dev(st.qmask_pool.astype(np.uint32).view(np.int32), dev)
         self.sched_attn_f = _Sched(st.attn_schedule(FWD_BQ, FWD_BK), dev)
         self.sched_attn_b = _Sched(st.attn_schedule(BWD_BQ, BWD_BK), dev)
-        self.sched_pool_f = _Sched(st.pool_schedule(FWD_BQ, FWD_BK), dev)
-        self.sched_pool_b = _Sched(st.pool_schedule(BWD_BQ, BWD_BK), dev)
+        if self.eao:
+            self.seg_start = _dev(st.seg_start, dev)
+        else:
+            self.sched_pool_f = _Sched(st.pool_schedule(FWD_BQ, FWD_BK), dev)
+            self.sched_pool_b = _Sched(st.pool_schedule(BWD_BQ, BWD_BK), dev)
         terms = self.model.loss_terms
         arr = (LossTerm * len(terms))()
         for i, t in enumerate(terms):
@@ -270,9 +278,10 @@ class FusionEngine:
             self._cast(w2, w["w2"])
             self._cast(w2, w["w2T"], transpose=True)
         ap = m.attn_pool
-        self._cast(ap.to_q.weight.data, self.wp["q"], scale=self.q_scale); self._cast(ap.to_q.weight.data, self.wp["qT"], transpose=True)
-        self._cast(ap.to_kv.weight.data, self.wp["kv"]); self._cast(ap.to_kv.weight.data, self.wp["kvT"], transpose=True)
-        self._cast(ap.to_out.weight.data, self.wp["o"]); self._cast(ap.to_out.weight.data, self.wp["oT"], transpose=True)
+        if ap is not None:
+            self._cast(ap.to_q.weight.data, self.wp["q"], scale=self.q_scale); self._cast(ap.to_q.weight.data, self.wp["qT"], transpose=True)
+            self._cast(ap.to_kv.weight.data, self.wp["kv"]); self._cast(ap.to_kv.weight.data, self.wp["kvT"], transpose=True)
+            self._cast(ap.to_out.weight.data, self.wp["o"]); self._cast(ap.to_out.weight.data, self.wp["oT"], transpose=True)
         for name in m.modality_types:
             enc = m.encoders[name]
             if isinstance(enc, EmbeddedSequenceEncoder):
@@ -307,9 +316,12 @@ class FusionEngine:
                              dxo_b=bf(T, D), dx1_b=bf(T, D), dh=bf(T, 2 * Ip), dqkv=bf(T, 3 * D))
                         for _ in range(self.L)]
         ws["xn"], ws["x1n"] = f32(T, D), f32(T, D)
-        ws["mf"], ws["rf"], ws["t_b"], ws["kvp"] = f32(T), f32(T), bf(T, D), bf(T, 2 * D)
+        ws["mf"], ws["rf"] = f32(T), f32(T)
+        ws["t_b"], ws["kvp"] = (None, None) if self.eao else (bf(T, D), bf(T, 2 * D))          # operands of the attentive pooling
         ws["rt_b"], ws["qp"], ws["op"], ws["lse_p"] = bf(R, D), bf(R, D), bf(b * R, D), f32(b, H, R)
         ws["pooled"] = f32(b * R, D)
+        if self.eao:
+            ws["seg_counts"] = torch.zeros(b, R, dtype=torch.int32, device=dev)
         ws["vmean"], ws["dvmean"], ws["delta"], ws["delta_p"] = f32(b, D), f32(b, D), f32(b, H, N), f32(b, H, R)
         ws["keyinfo"], ws["kflags"] = u8(b, self.nk_pad), u8(b, (N + 63) // 64)
         ws["padding"] = u8(b, N)
@@ -325,7 +337,7 @@ class FusionEngine:
             ws["dq32"] = ws["dq32_all"][0]
         ws["dq32_zero_event"] = torch.cuda.Event()
         ws["dpool_b"], ws["dop"], ws["dqp32"], ws["dqp_sum"], ws["dqp_b"] = bf(b * R, D), bf(b * R, D), f32(b * R, D), f32(R, D), bf(R, D)
-        ws["dkvp"], ws["drt"] = bf(T, 2 * D), f32(R, D)
+        ws["dkvp"], ws["drt"] = (None if self.eao else bf(T, 2 * D)), f32(R, D)
         ws["enc"] = {}
         for mi, name in enumerate(self.model.modality_types):
             enc = self.model.encoders[name]
@@ -561,6 +573,12 @@ class FusionEngine:
                  b * self.F, D, stream_ptr())
             if foreign:
                 ws["padding"].view(b, N)[:, N - self.F:] = 0
+        if self.eao:
+            # the token block and the padding bytes of a modality, replicated into every combination segment that holds it
+            pad2 = ws["padding"].view(b, N)
+            for src, dst, n in self.st.copies:
+                call("mca_rows_copy_add", x0.data_ptr() + src * D * 4, N * D, x0.data_ptr() + dst * D * 4, N * D, n, D, b, 0, stream_ptr())
+                pad2[:, dst:dst + n].copy_(pad2[:, src:src + n])
         ws["present_cur"] = present
         bits = ((present[:, None] >> self._mod_shifts) & 1).to(torch.bool)          # (b, M): one small op for every modality
         return {name: bits[:, mi] for mi, name in enumerate(m.modality_types)}
@@ -622,6 +640,12 @@ class FusionEngine:
             else:
                 self.gemm_nt(a["g"], w["w2"], xout, T, D, Ip, residual=ws["x1n"])
         xl = ws["x"][self.L]
+        if self.eao:
+            # final norm (fp32 out), then the mean of every segment's un-padded rows (model.py:563-570, 255-276)
+            self.ln_fwd(xl, m.norm.gamma, T, D, ws["mf"], ws["rf"], y=ws["xn"], ldy=D)
+            call("mca_segment_mean_fwd", ptr(ws["xn"]), ptr(ws["padding"]), ptr(self.seg_start), R, ptr(ws["pooled"]),
+                 ptr(ws["seg_counts"]), b, N, D, stream_ptr())
+            return ws["pooled"]
         self.ln_fwd(xl, m.norm.gamma, T, D, ws["mf"], ws["rf"], y_bf16=ws["t_b"], cols_pad=D)
         self.gemm_nt(ws["t_b"], self.wp["kv"], ws["kvp"], T, 2 * D, D)
         call("mca_f32_to_bf16", ptr(m.return_tokens.data), D, ptr(ws["rt_b"]), D, R, D, 1.0, stream_ptr())
@@ -718,6 +742,8 @@ class FusionEngine:
 
         if self.L and self.zero_dq_once and not self.attn_bwd_two_pass:          # all dQ accumulators zeroed beside the pooling backward (inline when nothing runs on the side stream)
             on_side(lambda: (ws["dq32_all"].zero_(), ws["dq32_zero_event"].record(torch.cuda.current_stream())))
+        if self.eao:
+            return self._backward_part_eao(ws, dpool, bucket_ready, on_side)
         # pooled = op @ Wo^T + return_tokens
         call("mca_reduce_rows", ptr(dpool), D, R * D, R, ptr(G(m.return_tokens)), D, b * R, D, stream_ptr())
         call("mca_f32_to_bf16", ptr(dpool), D, ptr(ws["dpool_b"]), D, b * R, D, 1.0, stream_ptr())
@@ -745,6 +771,24 @@ class FusionEngine:
         self.ln_bwd(dx, D, ws["x"][self.L], m.norm.gamma, ws["mf"], ws["rf"], T, D, G(m.norm.gamma), dx=dx_other, dx_bf16=top)
         dx, dx_other = dx_other, dx
         on_side(lambda: bucket_ready(0))
+        self._backward_layers_and_encoders(ws, dx, dx_other, bucket_ready, on_side)
+
+    def _backward_part_eao(self, ws, dpool, bucket_ready, on_side):
+        """EAO: d pooled (b, segments, D) -> mean-pool backward -> final norm backward -> the shared layer / encoder chain."""
+        m, D, N, R, b, T = self.model, self.D, self.N, self.R, ws["b"], ws["T"]
+        dx, dx_other = ws["dxa"], ws["dxb"]
+        call("mca_segment_mean_bwd", ptr(dpool), ptr(ws["padding"]), ptr(self.kgroup), ptr(ws["seg_counts"]), R, ptr(dx), b, N, D,
+             stream_ptr())
+        top = ws["layers"][self.L - 1]["dxo_b"] if self.L else ws["dx_b"]
+        self.ln_bwd(dx, D, ws["x"][self.L], m.norm.gamma, ws["mf"], ws["rf"], T, D, self.grad_of(m.norm.gamma), dx=dx_other, dx_bf16=top)
+        dx, dx_other = dx_other, dx
+        on_side(lambda: bucket_ready(0))
+        self._backward_layers_and_encoders(ws, dx, dx_other, bucket_ready, on_side)
+
+    def _backward_layers_and_encoders(self, ws, dx, dx_other, bucket_ready, on_side):
+        m, D, N, H, Ip, I, R, b, T = self.model, self.D, self.N, self.H, self.Ip, self.I, self.R, ws["b"], ws["T"]
+        G = self.grad_of
+        tn = self.gemm_tn_acc
         for bi, i in enumerate(reversed(range(self.L))):
             ly, w, a = m.layers[i], self.wl[i], ws["layers"][i]
             g = ly.norm.gamma
@@ -799,6 +843,9 @@ class FusionEngine:
             self.ln_bwd(dx_other, D, ws["x"][i], g, a["m1"], a["r1"], T, D, G(g), dx=dx, dx_bf16=below)  # dx = d x_in
             on_side(lambda bi=bi: bucket_ready(bi + 1))
         # dx = gradient w.r.t. the packed encoder output (b, N, D)
+        if self.eao:          # the gradients of a modality's replicas, summed into the segment its encoder wrote
+            for src, dst, n in self.st.copies:
+                call("mca_rows_copy_add", dx.data_ptr() + dst * D * 4, N * D, dx.data_ptr() + src * D * 4, N * D, n, D, b, 1, stream_ptr())
         if self.F:
             call("mca_reduce_rows", dx.data_ptr() + (N - self.F) * D * 4, D, N * D, self.F, ptr(G(m.fusion_tokens)), D,
                  b * self.F, D, stream_ptr())

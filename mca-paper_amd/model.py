@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from .encoders import encoders_dict, NativeEncoder
-from .structure import FusionStructure, loss_terms, FUSION_TOKEN, GLOBAL_TOKEN
+from .structure import FusionStructure, EAOStructure, loss_terms, FUSION_TOKEN, GLOBAL_TOKEN
 
 
 class LayerNorm(nn.Module):
@@ -173,4 +173,72 @@ class MCA(nn.Module):
                 slots["fusion"] = M
         elif not self.no_fusion:
             slots["fusion"] = M
+        return slots
+
+
+class EAO(MCA):
+    """``EAO(**model_config)``: the paper's "everything at once" baseline (model.py:481-596) on the native engine.
+
+    The reference runs its layer stack once per modality and once per modality combination and mean-pools each pass
+    (``mean_pool=True``: ``MeanTokenProjectionPool(None, projection=False)``, model.py:530-532, 255-276); here the passes are the
+    segments of one block-diagonal super-sequence (``structure.EAOStructure``), so the whole model is ONE pass of the same HIP
+    kernels.  Same constructor keywords, module tree and state_dict keys (``encoders.*``, ``layers.*``, ``norm.*``,
+    ``token_types``, ``loss.loss_fn.logit_scale``); module creation order = the reference's, so the same seed gives the same
+    weights.  As in the reference (model.py:500-503) ``num_fusion_tokens`` is forced to 0, ``no_fusion`` to its default True
+    and ``fcl_root`` to the first combination.  ``mean_pool=False`` is refused: the reference's own EAO cannot run it
+    (``self.pool_mask`` is never defined, model.py:566)."""
+
+    def __init__(self, encoder_configs, dim, depth, dim_head=64, heads=8, ff_mult=4, num_fusion_tokens=16,
+                 batch_size=8, return_padding=False, return_logits=False, bimodal_contrastive=False,
+                 non_fusion_fcl=False, fcl=False, fcl_root=(1, 2, 3, 4, 5), fusion_combos=(4, 5), zorro=False,
+                 no_fusion=True, mean_pool=True, **kwargs):
+        nn.Module.__init__(self)
+        if not mean_pool:
+            raise NotImplementedError("EAO(mean_pool=False): the reference's EAO reads self.pool_mask, which it never defines "
+                                      "(model.py:566): only the mean-pooled form exists")
+        if dim_head != 64:
+            raise NotImplementedError("the gfx950 attention kernels are specialised for dim_head = 64")
+        self.extra_kwargs = dict(kwargs)
+        self.batch_size = batch_size
+        self.dim, self.depth, self.heads, self.dim_head = dim, depth, heads, dim_head
+        self.bimodal_contrastive, self.non_fusion_fcl = bimodal_contrastive, non_fusion_fcl
+        self.modality_types = list(encoder_configs.keys())
+        self.token_dims = [encoder_configs[m]["max_tokens"] for m in self.modality_types]
+        self.structure = EAOStructure(self.token_dims, tuple(fusion_combos), fcl=fcl, zorro=zorro)
+        st = self.structure
+        self.fusion_combos = st.combos
+        self.no_fusion, self.zorro, self.fcl = True, zorro, fcl          # the loss is built with no_fusion (model.py:538)
+        self.fcl_root = None
+        self.num_fusion_tokens = 0
+        self.fusion_token = -1
+        self.return_token_types = st.return_token_types
+        self.max_return_tokens = len(st.return_token_types)
+        self.register_buffer("return_token_types_tensor", torch.tensor(st.return_token_types), persistent=False)
+        self.encoders = nn.ModuleDict({name: encoders_dict[cfg["type"]](**cfg) for name, cfg in encoder_configs.items()})
+        for name, enc in self.encoders.items():
+            ed = getattr(enc, "embedding_dim", dim)
+            if ed != dim:
+                raise ValueError(f"encoder {name}: embedding_dim {ed} != model dim {dim}")
+            ne = getattr(enc, "num_embeddings", None)
+            if getattr(enc, "kind", "") == "tabular" and ne is not None and ne != encoder_configs[name]["max_tokens"]:
+                raise ValueError(f"encoder {name}: num_embeddings {ne} != max_tokens {encoder_configs[name]['max_tokens']}")
+        self.layers = nn.ModuleList([MCALayer(dim, dim_head, heads, ff_mult) for _ in range(depth)])
+        self.norm = LayerNorm(dim)
+        self.register_buffer("token_types", torch.from_numpy(st.token_types.copy()))
+        self.return_tokens = None
+        self.fusion_tokens = None
+        self.attn_pool = None                      # MeanTokenProjectionPool(None, projection=False): no parameters
+        self.loss = MCAPretrainingLoss()
+        self.loss_terms = loss_terms(self.modality_types, st, bimodal_contrastive, non_fusion_fcl)
+        self._engine = None
+        self._dp_wrapper = None
+        self.register_load_state_dict_post_hook(MCA._after_load_state_dict)
+
+    def output_slots(self) -> Dict[object, int]:
+        """model.py:181-189 with no_fusion: the modalities, and the combinations when the fusion-channel loss is on."""
+        M = len(self.modality_types)
+        slots: Dict[object, int] = {m: i for i, m in enumerate(self.modality_types)}
+        if self.fcl and not self.zorro:
+            for c, combo in enumerate(self.fusion_combos):
+                slots[combo] = M + c
         return slots

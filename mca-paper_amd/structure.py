@@ -222,6 +222,67 @@ class FusionStructure:
 
 
 # --------------------------------------------------------------------------------------------------
+# EAO baseline: one SEGMENT per modality and per combination                    (model.py:481-596)
+# --------------------------------------------------------------------------------------------------
+class EAOStructure:
+    """The reference's ``EAO.forward`` (model.py:573-596) runs the SAME layer stack once per modality and once per
+    combination of modalities, each time on the concatenation of those modalities' tokens with the padding mask as the only
+    attention mask, and mean-pools the un-padded tokens of the pass.  Here all passes are segments of one super-sequence:
+
+      * segment s < M holds modality s alone, segment M + c the modalities of ``combos[c]`` (ascending);
+      * ``kgroup[j]`` = segment of token j, ``qmask[i]`` = 1 << segment(i): attention is block-diagonal over segments, which
+        is what separate passes compute (LayerNorm, the linear layers and GEGLU act row by row);
+      * ``copies``: (source offset, destination offset, rows) of every replica of a modality block; the encoders write
+        segment m (= the first M segments, offsets as in the fusion model), the replicas are copies and their gradients
+        are summed back.
+    Duck-types the fields of ``FusionStructure`` the engine and ``loss_terms`` read."""
+
+    def __init__(self, token_dims: Sequence[int], fusion_combos_powers: Sequence[int], fcl: bool, zorro: bool):
+        self.token_dims = list(token_dims)
+        M = len(self.token_dims)
+        self.combos = combos_of(M, fusion_combos_powers)
+        self.fcl, self.zorro, self.no_fusion = bool(fcl), bool(zorro), True
+        self.num_fusion_tokens = 0
+        self.segments: List[List[int]] = [[m] for m in range(M)] + [sorted(c) for c in self.combos]
+        if len(self.segments) > MAX_GROUPS:
+            raise NotImplementedError(f"{len(self.segments)} EAO passes exceed the {MAX_GROUPS} key groups of the HIP kernels")
+        single_off = np.concatenate([[0], np.cumsum(self.token_dims)]).astype(int)
+        seg_start, kgroup, types, copies = [0], [], [], []
+        for s, mods in enumerate(self.segments):
+            for m in mods:
+                n = self.token_dims[m]
+                if s >= M:
+                    copies.append((int(single_off[m]), len(kgroup), n))
+                kgroup += [s] * n
+                types += [m] * n
+            seg_start.append(len(kgroup))
+        self.seg_start = np.asarray(seg_start, np.int32)
+        self.copies = copies
+        self.kgroup = np.asarray(kgroup, np.uint8)
+        self.qmask_attn = (np.uint32(1) << self.kgroup.astype(np.uint32)).astype(np.uint32)
+        self.qmask_pool = np.zeros(len(self.segments), np.uint32)          # no attentive pooling
+        self.token_types_expanded = np.asarray(types, np.int64)
+        # the reference's own (unexpanded) token_types buffer: state_dict key `token_types` (model.py:528,540-547)
+        self.token_types = np.asarray([m for m, n in enumerate(self.token_dims) for _ in range(n)], np.int64)
+        self.return_token_types = list(range(M))
+
+    @property
+    def n_tokens(self) -> int:
+        return len(self.kgroup)
+
+    @property
+    def n_return(self) -> int:          # pooled slots: one per segment
+        return len(self.segments)
+
+    @property
+    def n_modalities(self) -> int:
+        return len(self.token_dims)
+
+    def attn_schedule(self, bq: int = 128, bk: int = 64) -> TileSchedule:
+        return build_schedule(self.qmask_attn, self.kgroup, bq, bk)
+
+
+# --------------------------------------------------------------------------------------------------
 # loss schedule: which pooled slots are contrasted and which samples count   (model.py:132-233)
 # --------------------------------------------------------------------------------------------------
 @dataclass

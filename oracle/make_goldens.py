@@ -118,13 +118,13 @@ def perturb_(model, seed):
                 p[::2].mul_(0.1)
 
 
-def run_case(refmodel, cfg, batch, seed, lr, clip, steps=2):
+def run_case(refmodel, cfg, batch, seed, lr, clip, steps=2, cls="MCA"):
     torch.manual_seed(seed)
     torch.save_real = getattr(torch, "save_real", torch.save)
     real_save = torch.save
     torch.save = lambda *a, **k: None
     try:
-        model = refmodel.MCA(**cfg)
+        model = getattr(refmodel, cls)(**cfg)
         perturb_(model, seed + 1)
         init_sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
         model.train()
@@ -156,8 +156,9 @@ def run_case(refmodel, cfg, batch, seed, lr, clip, steps=2):
             opt.step()
             rec[f"state_step{s + 1}"] = {k: v.detach().clone() for k, v in model.state_dict().items()
                                          if k in dict(model.named_parameters())}
-        rec["attn_mask"] = model.attn_mask.clone()
-        rec["pool_mask"] = model.pool_mask.clone()
+        if cls == "MCA":
+            rec["attn_mask"] = model.attn_mask.clone()
+            rec["pool_mask"] = model.pool_mask.clone()
         rec["token_types"] = model.token_types.clone()
         rec["return_token_types"] = list(model.return_token_types)
         rec["loss_names"] = list(out["losses"].keys())
@@ -182,6 +183,63 @@ def make_tiny(refmodel):
         cfg = tiny_model_config(variant)
         batch = tiny_batch(seed, drop)
         rec = run_case(refmodel, cfg, batch, seed, lr=1e-3, clip=2.0)
+        torch.save(rec, os.path.join(GOLD, f"tiny_{name}.pt"))
+        print(f"tiny_{name}: loss {float(rec['outputs']['loss']):.6f} terms {len(rec['outputs']['losses'])} "
+              f"nan {sum(int(torch.isnan(v)) for v in rec['outputs']['losses'].values())} gn {float(rec['grad_norm']):.4f}")
+
+
+EAO_CASES = {
+    # name: (fcl, bimodal, non_fusion_fcl, fusion_combos, drop map, seed)
+    "eao_fcl": (True, True, True, [2], {}, 31),
+    "eao_fcl_drop": (True, True, True, [2], {"seqA": [1], "tab": [2, 3]}, 32),
+    "eao_nofcl_drop": (False, False, False, [3, 2], {"seqB": [0, 2]}, 33),
+}
+
+
+def make_eao(refmodel):
+    """The reference's EAO baseline (model.py:481-596) on the tiny configs: outputs, losses, gradients, two AdamW steps; and
+    the CMU_config1_EAO shape at b = 2 with the build's own initialiser (pooled embeddings, losses, gradient norms)."""
+    # (the CMU-shaped model first: the reference's default logit_scale is ONE module-level Parameter shared by every loss
+    # instance, so a model trained earlier in this process would move the 'initial' temperature recorded below)
+    import importlib
+    sys.path.insert(0, REPO)
+    pkg = importlib.import_module("mca-paper_amd")
+    cfg = pkg.config.cmu_eao_model_config(batch_size=2)
+    torch.manual_seed(43)
+    real_save = torch.save
+    torch.save = lambda *a, **k: None
+    try:
+        model = refmodel.EAO(**cfg)
+        sd = pkg.params.init_state_dict(cfg, seed=43)
+        assert set(sd.keys()) == set(model.state_dict().keys()), set(sd.keys()) ^ set(model.state_dict().keys())
+        ref_sd = model.state_dict()
+        sums = {k: (float(v.double().sum()), float(v.double().abs().sum()), tuple(v.shape)) for k, v in ref_sd.items() if v.dtype.is_floating_point}
+        same = all(torch.equal(v, ref_sd[k]) for k, v in sd.items())
+        model.load_state_dict(sd)
+        batch = pkg.data.synthetic_batch(cfg, batch_size=2, seed=1234, p_drop=0.3, lengths="uniform")
+        out = model(batch)
+        out["loss"].backward()
+    finally:
+        torch.save = real_save
+    names = list(cfg["encoder_configs"].keys())
+    rec = {
+        "case": "eao", "seed": 43, "data_seed": 1234, "p_drop": 0.3, "same_seed_init_equal": same, "init_checksums": sums,
+        "pooled": torch.stack([out[n] for n in names] + [out[k] for k in model.fusion_combos], 1).detach(),
+        "losses": {k: v.detach() for k, v in out["losses"].items()},
+        "loss": out["loss"].detach(),
+        "sample_mask": {k: v for k, v in out["modality_sample_mask"].items()},
+        "grad_norms": {n: float(p.grad.norm()) for n, p in model.named_parameters()},
+        "grad_slices": {n: p.grad.flatten()[:64].clone() for n, p in model.named_parameters()},
+        "state_keys": list(model.state_dict().keys()),
+    }
+    torch.save(rec, os.path.join(GOLD, "cmu_eao_b2.pt"))
+    print(f"cmu_eao: loss {float(rec['loss']):.5f}, {len(rec['losses'])} terms, pooled {tuple(rec['pooled'].shape)}, same-seed init equal: {same}")
+    for name, (fcl, bimodal, nff, combos, drop, seed) in EAO_CASES.items():
+        cfg = tiny_model_config("mca")
+        cfg.update(fcl=fcl, bimodal_contrastive=bimodal, non_fusion_fcl=nff, fusion_combos=combos, eao=True, no_fusion=True,
+                   mean_pool=True, fcl_root=[0, 1])
+        batch = tiny_batch(seed, drop)
+        rec = run_case(refmodel, cfg, batch, seed, lr=1e-3, clip=2.0, cls="EAO")
         torch.save(rec, os.path.join(GOLD, f"tiny_{name}.pt"))
         print(f"tiny_{name}: loss {float(rec['outputs']['loss']):.6f} terms {len(rec['outputs']['losses'])} "
               f"nan {sum(int(torch.isnan(v)) for v in rec['outputs']['losses'].values())} gn {float(rec['grad_norm']):.4f}")
@@ -396,6 +454,7 @@ if __name__ == "__main__":
     ap.add_argument("--init", action="store_true")
     ap.add_argument("--tiny", action="store_true")
     ap.add_argument("--ckpt", action="store_true")
+    ap.add_argument("--eao", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     refmodel, refenc = import_reference()
@@ -406,7 +465,9 @@ if __name__ == "__main__":
     if a.ckpt:
         make_ckpt(refmodel)
         make_unrunnable(refmodel)
-    if a.tiny or not (a.cmu or a.init or a.collators or a.tcga or a.ckpt):
+    if a.eao:
+        make_eao(refmodel)
+    if a.tiny or not (a.cmu or a.init or a.collators or a.tcga or a.ckpt or a.eao):
         make_tiny(refmodel)
     if a.init:
         make_init_parity(refmodel)

@@ -503,6 +503,76 @@ def mca_forward(S: Structure, sd: Dict[str, torch.Tensor], batch, mode="fp32", n
 
 
 # --------------------------------------------------------------------------------------------------
+# EAO baseline                                                              (model.py:481-596, 235-280)
+# --------------------------------------------------------------------------------------------------
+class EAOStructure(Structure):
+    """EAO.__init__ (model.py:482-538): no fusion tokens, the loss built with the default no_fusion=True and the first
+    combination as the (unused) root; everything else as MCA."""
+
+    def __init__(self, cfg: dict):
+        enc = cfg["encoder_configs"]
+        self.modalities = list(enc.keys())
+        M = len(self.modalities)
+        self.fcl = bool(cfg.get("fcl", False))
+        self.zorro = bool(cfg.get("zorro", False))
+        self.no_fusion = True                                            # MCAPretrainingLoss(no_fusion=True), model.py:538
+        self.bimodal = bool(cfg.get("bimodal_contrastive", False))
+        self.non_fusion_fcl = bool(cfg.get("non_fusion_fcl", False))
+        self.combos = fusion_combos_of(M, cfg.get("fusion_combos", [4, 5]))
+        self.num_fusion_tokens = 0                                       # model.py:501
+        self.token_dims = [enc[m]["max_tokens"] for m in self.modalities]
+        self.token_types = token_types_of(self.token_dims, 0)
+        self.attn_mask = self.pool_mask = None
+        self.heads = int(cfg.get("heads", 8))
+        self.dim_head = int(cfg.get("dim_head", 64))
+        self.depth = int(cfg["depth"])
+        self.dim = int(cfg["dim"])
+        self.do_fcl = self.fcl and not self.zorro
+        self.enc_cfg = enc
+        # one pass per modality, then one per combination (model.py:586); a frozenset of small ints iterates ascending
+        self.passes = [[i] for i in range(M)] + [sorted(c) for c in self.combos]
+
+
+def mean_token_pool(tokens, padding):
+    """MeanTokenProjectionPool(None, projection=False).forward (model.py:255-276): per sample the mean of the un-padded rows,
+    zeros when there is none."""
+    keep = (~padding).to(tokens.dtype)[..., None]
+    cnt = keep.sum(dim=1)
+    return (tokens * keep).sum(dim=1) / cnt.clamp_min(1.0)
+
+
+def eao_forward(S: EAOStructure, sd, batch, mode="fp32", no_loss=False):
+    """EAO.forward (model.py:573-596): the layer stack + final norm + mean pool, once per pass, padding mask only."""
+    P = Prec(mode)
+    toks, masks = [], []
+    for m in S.modalities:
+        c = S.enc_cfg[m]
+        pfx = f"encoders.{m}."
+        if c["type"] == "EmbeddedSequenceEncoder":
+            t, a = embedded_sequence_encoder(sd, pfx, batch[m], P)
+        elif c["type"] == "TabularEncoder":
+            t, a = tabular_encoder(sd, pfx, batch[m], P, c)
+        else:
+            raise NotImplementedError(c["type"])
+        toks.append(t)
+        masks.append(a.to(torch.bool))
+    sample_mask = {m: ((a == 0).sum(dim=1) != 0) for m, a in zip(S.modalities, masks)}
+    pooled = []
+    for mods in S.passes:
+        x = torch.cat([toks[i] for i in mods], dim=1)
+        pad = torch.cat([masks[i] for i in mods], dim=1)
+        for i in range(S.depth):
+            x = mca_layer(x, sd, f"layers.{i}.", None, pad, S.heads, P)
+        x = layer_norm(x, sd["norm.gamma"].to(P.dtype))
+        pooled.append(mean_token_pool(x, pad))
+    pooled = torch.stack(pooled, dim=1)
+    out = pretraining_loss(S, pooled, sample_mask, sd["loss.loss_fn.logit_scale"], no_loss)
+    out["modality_sample_mask"] = sample_mask
+    out["pooled"] = pooled
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
 # parameters: names/shapes/initialisation follow the reference modules (SURVEY.md §8b)
 # --------------------------------------------------------------------------------------------------
 PARAM_BUFFERS = ("positional_encoder.pe", ".index", "fusion_mask", "token_types", "attn_mask", "pool_mask", ".beta")
@@ -520,7 +590,7 @@ def train_step(S: Structure, sd, batch, mode="fp32", lr=1e-4, clip=2.0, opt_stat
     for p in params.values():
         p.requires_grad_(True)
         p.grad = None
-    out = mca_forward(S, sd, batch, mode)
+    out = eao_forward(S, sd, batch, mode) if isinstance(S, EAOStructure) else mca_forward(S, sd, batch, mode)
     out["loss"].backward()
     grads = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in params.items()}
     plist = [p for p in params.values() if p.grad is not None]

@@ -158,7 +158,7 @@ def test_every_reference_training_yaml_is_accepted(pkg, golden_dir, tmp_path):
     assert len(census) == 145
     import pytest
     seen = set()
-    n_built = 0
+    n_built = n_eao = 0
     refused = []
     for name, ent in sorted(census.items()):
         y = dict(ent["settings"]); y["encoder_configs"] = ent["encoder_configs"]; y["modality_config"] = ent["modality_config"]
@@ -173,17 +173,21 @@ def test_every_reference_training_yaml_is_accepted(pkg, golden_dir, tmp_path):
         if sig in seen:
             continue
         seen.add(sig)
-        # not native: the EAO baseline (12 YAMLs) and MCA(mean_pool=True) (10 `_j*` YAMLs), which the reference
-        # itself cannot run: MeanTokenProjectionPool.forward evaluates `if self.token_types` on an N-element tensor
-        # (model.py:264; recorded from a run of the reference in tests/golden/ref_unrunnable.json)
-        if mc["eao"] or mc["mean_pool"]:
+        # not native: MCA(mean_pool=True) (the `_j*` YAMLs), which the reference itself cannot run:
+        # MeanTokenProjectionPool.forward evaluates `if self.token_types` on an N-element tensor (model.py:264; recorded from
+        # a run of the reference in tests/golden/ref_unrunnable.json).  The EAO baseline (12 YAMLs) builds natively.
+        if mc["mean_pool"] and not mc["eao"]:
             with pytest.raises(NotImplementedError):
                 pkg.build_model(mc)
             refused.append(name)
             continue
         model = pkg.build_model(mc)
-        assert model.structure.n_tokens == sum(e["max_tokens"] for e in mc["encoder_configs"].values()) + model.structure.num_fusion_tokens
+        if mc["eao"]:
+            assert type(model).__name__ == "EAO" and model.structure.n_return == len(mc["encoder_configs"]) + len(model.fusion_combos)
+            n_eao += 1
+        else:
+            assert model.structure.n_tokens == sum(e["max_tokens"] for e in mc["encoder_configs"].values()) + model.structure.num_fusion_tokens
         n_built += 1
-    assert n_built >= 8 and len(refused) >= 2
+    assert n_built >= 9 and n_eao >= 1 and len(refused) >= 1
     unrunnable = json.load(open(os.path.join(golden_dir, "ref_unrunnable.json")))
     assert unrunnable["MCA(mean_pool=True).forward"]["type"] == "RuntimeError"

@@ -24,12 +24,14 @@ def _close(a, b, rtol, atol, what):
 def test_tiny_case(case):
     rec = torch.load(os.path.join(GOLDEN, f"tiny_{case}.pt"), weights_only=False)
     cfg = rec["config"]
-    S = O.Structure(cfg)
+    eao = bool(cfg.get("eao"))          # the EAO baseline (reference model.py:481-596): oracle.eao_forward
+    S = O.EAOStructure(cfg) if eao else O.Structure(cfg)
     # static structure, bit-exact
-    assert torch.equal(S.attn_mask, rec["attn_mask"])
-    assert torch.equal(S.pool_mask, rec["pool_mask"])
+    if not eao:
+        assert torch.equal(S.attn_mask, rec["attn_mask"])
+        assert torch.equal(S.pool_mask, rec["pool_mask"])
+        assert S.ret_types == rec["return_token_types"]
     assert torch.equal(S.token_types, rec["token_types"])
-    assert S.ret_types == rec["return_token_types"]
     assert [t[0] for t in O.loss_schedule(S)] == rec["loss_names"]
 
     sd = {k: v.clone() for k, v in rec["init_state"].items()}
@@ -71,11 +73,12 @@ def test_tiny_case(case):
     O.train_step(S, sd, rec["batch"], "fp32", lr=rec["lr"], clip=rec["clip"], opt_state=None)
 
 
-@pytest.mark.parametrize("case", CASES[:2])
+@pytest.mark.parametrize("case", ["bimodal_drop", "mca_fcl", "eao_fcl_drop"])
 def test_two_steps(case):
     """second AdamW step exercises non-zero moments."""
     rec = torch.load(os.path.join(GOLDEN, f"tiny_{case}.pt"), weights_only=False)
-    S = O.Structure(rec["config"])
+    eao = bool(rec["config"].get("eao"))
+    S = O.EAOStructure(rec["config"]) if eao else O.Structure(rec["config"])
     sd = {k: v.clone() for k, v in rec["init_state"].items()}
     params = [sd[k] for k in sd if O.is_param(k)]
     for p in params:
@@ -84,7 +87,7 @@ def test_two_steps(case):
     for s in range(2):
         for p in params:
             p.grad = None
-        out = O.mca_forward(S, sd, rec["batch"], "fp32")
+        out = (O.eao_forward if eao else O.mca_forward)(S, sd, rec["batch"], "fp32")
         out["loss"].backward()
         torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], rec["clip"])
         opt.step()

@@ -71,8 +71,6 @@ def main():
     config = P.config.training_config(sys.argv[1], make_output_dir=rank == 0)
     torch.manual_seed(config.seed)
     model_config = P.config.get_model_config(config)
-    if model_config["eao"]:
-        raise NotImplementedError("EAO baseline model is outside the native hot path (SURVEY.md section 2 #13)")
     modality_config = config.get("modality_config", config.get("modality_configs", {}))
 
     # ---- data
@@ -104,7 +102,7 @@ def main():
         eval_batches = eval_dl
 
     # ---- model, optimizer, schedule
-    model = P.MCA(**model_config).to(device)
+    model = P.build_model(model_config).to(device)          # EAO(**model_config) if model_config['eao'] else MCA(...), train_accel_gpu.py:51-54
     opt = optim.FusedAdamW(model, lr=config.lr)
     dp = dpmod.DataParallelMCA(model) if world > 1 else None
     total_steps = config.epochs * steps_per_epoch
