@@ -85,8 +85,12 @@ def cpu_baseline(P, workload: str, variant: str, protocol: str):
     model, phys = host_cpu()
     long_seq = workload == "long"
     b = 1 if long_seq else 8
-    cfg = P.config.cmu_model_config(batch_size=b, zorro=variant == "mma", long_seq=long_seq)
-    S = O.Structure(cfg)
+    if variant == "eao":
+        cfg = P.config.cmu_eao_model_config(batch_size=b)
+        S = O.EAOStructure(cfg)
+    else:
+        cfg = P.config.cmu_model_config(batch_size=b, zorro=variant == "mma", long_seq=long_seq)
+        S = O.Structure(cfg)
     sd0 = P.params.init_state_dict(cfg, seed=43)
     batch = P.data.synthetic_batch(cfg, b, seed=1234, lengths="uniform")
 
@@ -107,7 +111,7 @@ def cpu_baseline(P, workload: str, variant: str, protocol: str):
     threads = phys if protocol == "full" else min(phys, 16)
     v, spent = run(threads, warm, timed)
     out = {"value": round(v, 4), "unit": "samples/s", "cores": threads, "physical_cores": phys, "cpu_model": model, "kind": "port",
-           "sample": f"{'LONG 4x1500' if long_seq else 'CMU 4-modality'} {'MMA' if variant == 'mma' else 'MCA'} fp32 full step (fwd+bwd+clip+AdamW) "
+           "sample": f"{'LONG 4x1500' if long_seq else 'CMU 4-modality'} {variant.upper()} fp32 full step (fwd+bwd+clip+AdamW) "
                      f"at batch {b}, uniform lengths, {timed} timed steps after {warm} warm-up ({spent:.0f} s of CPU work on {threads} threads)"}
     if protocol == "full" and not long_seq:
         v8, spent8 = run(min(8, phys), 3, 5)
@@ -124,7 +128,7 @@ def main():
     ap.add_argument("--workload", default="cmu", choices=["cmu", "long"],
                     help="cmu: BASELINE configs[1-3] (N = 2538); long: configs[4] (4 x 1500 tokens, N = 6088, batch 128 per GPU)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 32 for cmu, 128 for long; the DP = 8 configs use 8)")
-    ap.add_argument("--variant", default="mca", choices=["mca", "mma"])
+    ap.add_argument("--variant", default="mca", choices=["mca", "mma", "eao"], help="eao = the paper's EAO baseline (configs/CMU_config1_EAO.yaml); default batch 8")
     ap.add_argument("--lengths", default="full", choices=["full", "uniform"])
     ap.add_argument("--p-drop", type=float, default=0.0)
     ap.add_argument("--attn", default="bf16", choices=["bf16", "fp8"], help="attention operand type (fp8: block-scaled MFMA, BASELINE configs[4])")
@@ -158,10 +162,15 @@ def main():
     optim = importlib.import_module("mca-paper_amd.optim")
     dpmod = importlib.import_module("mca-paper_amd.dp")
     long_seq = args.workload == "long"
-    b = args.batch or (128 if long_seq else 32)
-    cfg = P.config.cmu_model_config(batch_size=b, zorro=args.variant == "mma", long_seq=long_seq)
+    b = args.batch or (128 if long_seq else (8 if args.variant == "eao" else 32))
+    if args.variant == "eao":
+        if long_seq:
+            raise SystemExit("--variant eao is defined on the CMU workload")
+        cfg = P.config.cmu_eao_model_config(batch_size=b)
+    else:
+        cfg = P.config.cmu_model_config(batch_size=b, zorro=args.variant == "mma", long_seq=long_seq)
     torch.manual_seed(43)
-    model = P.MCA(**cfg).to(dev)
+    model = P.build_model(cfg).to(dev)
     eng = model.engine
     eng.check_finite = "deferred"              # as train_accel_gpu.py: finite checks ON, device flag, no host sync in the step
     if args.attn == "fp8":
@@ -242,7 +251,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.attn == "bf16" else "bf16 (attention QK^T / PV operands fp8 e4m3)",
             "data": "synthetic",
-            "config": {"workload": f"synthetic {'LONG 4 x 1500 tokens' if long_seq else 'CMU 4-modality'} ({'MCA fcl' if args.variant == 'mca' else 'MMA/zorro'}), "
+            "config": {"workload": f"synthetic {'LONG 4 x 1500 tokens' if long_seq else 'CMU 4-modality'} ({ {'mca': 'MCA fcl', 'mma': 'MMA/zorro', 'eao': 'EAO baseline, 10 passes as one block-diagonal sequence'}[args.variant]}), "
                                    f"N={N} D=512 L=5 H=8 F=88, lengths={args.lengths}, p_drop={args.p_drop}",
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
                        "inputs": "device-resident, same batch every step", "finite_checks": "on (device flag, polled)",
