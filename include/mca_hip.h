@@ -173,6 +173,13 @@ int mca_nonfinite_flag(const mca_finite_args* args, int32_t* flag, int bit, mca_
 int mca_build_keyinfo(const uint8_t* padding, const uint8_t* kgroup, uint8_t* keyinfo,
                       uint8_t* ktile_flags, int batch, int nk, int nk_pad, mca_stream_t stream);
 
+/* khot[b, nk_pad, 16] (bf16) = one-hot of min(keyinfo, 15): the B^T operand of the MASK PRODUCT.  A structure with at most
+ * 15 key groups lets the attention kernels add -32768 * (query may not see the key's group | key padded) to the scores on
+ * the matrix pipe (one 32x32x16 MFMA per 32-key block: S += Khot . Qblk^T, Qblk[i][g] = bit g of qmask[i] ? 0 : -32768,
+ * Qblk[i][15] = -32768) instead of ~4 vector instructions per score; exp2 of such a score is exactly 0, a row whose every
+ * key is blocked ends with a running maximum below -16384 and takes the uniform-row path.                               */
+int mca_build_keyhot(const uint8_t* keyinfo, uint16_t* khot, int batch, int nk_pad, mca_stream_t stream);
+
 /* vmean[b, h*64+d] = mean over ALL nk keys of V  (value of a fully-masked softmax row); fixed summation order:
  * bitwise reproducible                                                                            */
 int mca_attn_vmean(const uint16_t* V, int64_t kv_bstride, int64_t kv_ld, float* vmean,
@@ -191,6 +198,7 @@ typedef struct {
   int batch, heads, nq, nk, nk_pad, n_qtiles, n_ktiles;
   float scale;                      /* dim_head ** -0.5                                            */
   int flags;                        /* MCA_ATTN_* bits                                             */
+  const uint16_t* khot;             /* optional (mca_build_keyhot): one-hot key groups, the mask as a matrix product */
 } mca_attn_fwd_args;
 /* q already carries scale * log2(e) (folded into the bf16 copy of to_q.weight by mca_cast_pad_bf16_multi's per-tensor
  * scale): the kernels then take q.k as the log2-domain logit and never multiply a score.  lse, o, dq, dk, dv keep their
@@ -273,6 +281,9 @@ typedef struct {
   int batch, heads, nq, nk, nk_pad;
   float scale;
   int flags;
+  /* optional, both or neither: the mask as a matrix product (see mca_build_keyhot).  qblk[nq, 16] bf16 is the static query
+   * side: qblk[i][g] = bit g of qmask[i] ? 0 : -32768 for g < 15, qblk[i][15] = -32768                                  */
+  const uint16_t* khot; const uint16_t* qblk;
 } mca_attn_bwd2_args;
 int mca_attn_bwd_dq(const mca_attn_bwd2_args* args, mca_stream_t stream);
 int mca_attn_bwd_dkv(const mca_attn_bwd2_args* args, mca_stream_t stream);

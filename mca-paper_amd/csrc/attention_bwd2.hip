@@ -33,10 +33,11 @@ __device__ __forceinline__ int row_off(int r, int c) { return r * 64 + ((c ^ ((r
 // =====================================================================================================
 // dQ pass
 // =====================================================================================================
-template <bool PRESCALED, bool OUT_F32>
+template <bool PRESCALED, bool OUT_F32, bool HOT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(mca_attn_bwd2_args a, int dbg) {
   __shared__ __attribute__((aligned(16))) u16 lds[2 * 2 * AK * DH];   // K,V double-buffered: 32 KiB
   __shared__ __attribute__((aligned(16))) uint8_t kinfo[2][AK];
+  __shared__ __attribute__((aligned(16))) u16 hot_s[2][AK * 16];   // one-hot key groups of the tile (mask product operand)
   __shared__ uint8_t flags_s[MAX_KTILES];
   __shared__ uint32_t live_s[MAX_KTILES + 2];
   __shared__ int n_live_s;
@@ -63,6 +64,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(mca_attn_bwd2_args 
     for (int s = 0; s < 4; s++) { qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s); dof[s] = *reinterpret_cast<const bf16x8*>(op + 16 * s); }
   }
   const uint32_t qm = a.qmask[qrow];
+  // the mask as a matrix product (mca_hip.h, mca_build_keyhot): this lane's query-side operand, groups 8 lh .. 8 lh + 7
+  // (rebuilt from qm in every masked tile: four registers held for the whole kernel cost nine spills)
+  constexpr bool use_hot = HOT;          // (a compile-time choice: with both mask paths in one kernel the register file spills)
+  const uint32_t qm8 = ((qm >> (8 * lh)) & 0xffu) & (lh ? 0x7fu : 0xffu);          // visible-bits of this lane's eight groups; slot 15 never
   const float c2 = a.scale * 1.4426950408889634f;
   // row constants as accumulator start values: S - lse (log2 domain; lse = +inf marks a uniform row: P = 0) and dP - delta
   f32x16 neglse, negdel;
@@ -86,6 +91,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(mca_attn_bwd2_args 
   const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
   const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
   const uint8_t* kinfo_g = a.keyinfo + (int64_t)b * a.nk_pad;
+  const u16* khot_g = use_hot ? a.khot + (int64_t)b * a.nk_pad * 16 : nullptr;
   {
     const uint8_t* flags_g = a.ktile_flags + (int64_t)b * a.n_ktiles64;
     for (int i = tid; i < a.n_ktiles64; i += 256) flags_s[i] = flags_g[i];
@@ -101,8 +107,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(mca_attn_bwd2_args 
   }
   const int last_kt = a.n_ktiles64 - 1;
   bf16x8 rk[2], rv[2];
-  uint32_t rinfo = 0;
+  const unsigned hoff = (unsigned)tid * 4u;          // u16 elements into the one-hot image | bytes into the key-group bytes
+  uint2 rhot = make_uint2(0, 0);          // 8 bytes of the tile's one-hot image per thread (element-mask path: .x = four key-group bytes)
   auto gload = [&](int kt) {
+    // (wave-uniform tile base + 32-bit lane offset: a per-lane 64-bit address held across the loop was spilled, and its
+    // reload waited vmcnt(0) in front of the prefetch)
+    if (use_hot) { const u16* hb = khot_g + (int64_t)kt * (AK * 16); rhot = *reinterpret_cast<const uint2*>(hb + hoff); }
+    else if (tid < 16) { const uint8_t* ib = kinfo_g + kt * AK; rhot.x = *reinterpret_cast<const uint32_t*>(ib + hoff); }
     const u16* kb = kbase + (int64_t)kt * AK * a.kv_ld;
     const u16* vb = vbase + (int64_t)kt * AK * a.kv_ld;
     if (kt != last_kt) {
@@ -119,7 +130,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(mca_attn_bwd2_args 
         rv[i] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * a.kv_ld + sc[i] * 8);
       }
     }
-    if (tid < 16) rinfo = *reinterpret_cast<const uint32_t*>(kinfo_g + kt * AK + tid * 4);
   };
   auto swrite = [&](int buf) {
 #pragma unroll
@@ -127,7 +137,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(mca_attn_bwd2_args 
       *reinterpret_cast<bf16x8*>(Ks + buf * AK * DH + rt_off(srow[i], sc[i])) = rk[i];          // rows for S, columns for dQ
       *reinterpret_cast<bf16x8*>(Vs + buf * AK * DH + row_off(srow[i], sc[i])) = rv[i];
     }
-    if (tid < 16) *reinterpret_cast<uint32_t*>(&kinfo[buf][tid * 4]) = rinfo;
+    if (use_hot) *reinterpret_cast<uint2*>(&hot_s[buf][tid * 4]) = rhot;
+    else if (tid < 16) *reinterpret_cast<uint32_t*>(&kinfo[buf][tid * 4]) = rhot.x;
   };
 
   if (wave == 0) {
@@ -213,13 +224,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(mca_attn_bwd2_args 
 #undef DQ_READ
 #undef DQ_DSREAD128
     }
+    if (need_mask && use_hot) {          // blocked (query, key) pairs: -32768 on top of the score, exp2 is exactly 0
+      u32x4v qb;
+#pragma unroll
+      for (int w = 0; w < 4; w++)
+        qb[w] = (((qm8 >> (2 * w)) & 1u) ? 0u : 0xC700u) | (((qm8 >> (2 * w + 1)) & 1u) ? 0u : 0xC7000000u);
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        const bf16x8 hf = *reinterpret_cast<const bf16x8*>(&hot_s[buf][(kb * 32 + l31) * 16 + 8 * lh]);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf, *reinterpret_cast<const bf16x8*>(&qb), s[kb], 0, 0, 0);
+      }
+    }
     if (!PRESCALED) {
 #pragma unroll
       for (int kb = 0; kb < 2; kb++)
 #pragma unroll
         for (int r = 0; r < 16; r++) s[kb][r] = fmaf(s[kb][r], c2, neglse[r]);
     }
-    if (need_mask) {
+    if (need_mask && !use_hot) {
 #pragma unroll
       for (int kb = 0; kb < 2; kb++)
 #pragma unroll
@@ -314,10 +336,14 @@ extern "C" int mca_attn_bwd_dq(const mca_attn_bwd2_args* a, mca_stream_t stream)
   const dim3 grid(a->n_qtiles128, a->heads, a->batch);
   const bool pre = (a->flags & MCA_ATTN_Q_PRESCALED) != 0;
   const int dbg = mca_knobs[9];
-  if (pre && !a->dq_f32) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), grid, dim3(256), 0, as_stream(stream), *a, dbg);
-  else if (pre) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), grid, dim3(256), 0, as_stream(stream), *a, dbg);
-  else if (!a->dq_f32) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), grid, dim3(256), 0, as_stream(stream), *a, dbg);
-  else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), grid, dim3(256), 0, as_stream(stream), *a, dbg);
+  const bool hot = a->khot != nullptr;
+  if ((uintptr_t)a->khot % 16) return MCA_E_ALIGN;
+#define DQ_LAUNCH(P, F, H) hipLaunchKernelGGL((attn_bwd_dq_kernel<P, F, H>), grid, dim3(256), 0, as_stream(stream), *a, dbg)
+  if (pre && !a->dq_f32) { if (hot) DQ_LAUNCH(true, false, true); else DQ_LAUNCH(true, false, false); }
+  else if (pre) { if (hot) DQ_LAUNCH(true, true, true); else DQ_LAUNCH(true, true, false); }
+  else if (!a->dq_f32) { if (hot) DQ_LAUNCH(false, false, true); else DQ_LAUNCH(false, false, false); }
+  else { if (hot) DQ_LAUNCH(false, true, true); else DQ_LAUNCH(false, true, false); }
+#undef DQ_LAUNCH
   return launch_status();
 }
 
@@ -334,6 +360,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
   float* rowc = reinterpret_cast<float*>(Os + 2 * BQ * DH);       // [2][3][64]: -lse, -delta, qmask(bits)
   uint32_t* qlist = reinterpret_cast<uint32_t*>(rowc + 2 * 192);  // [MAX_QTILES]
   float* dvm_s = reinterpret_cast<float*>(qlist + MAX_QTILES);    // [64]
+  u16* qblk_s = reinterpret_cast<u16*>(dvm_s + DH);               // [2][64][16]: query side of the mask product
 
   const int lin0 = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
   const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y * gridDim.z));
@@ -358,6 +385,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
     vf[s] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)keyc * a.kv_ld + 16 * s + 8 * lh);
   }
   const uint32_t kinfo = a.keyinfo[(int64_t)b * a.nk_pad + mykey];     // nk_pad covers every key block
+  // the mask as a matrix product (mca_hip.h, mca_build_keyhot): this lane's key-side operand (groups 8 lh .. 8 lh + 7 of its key)
+  const bool use_hot = a.khot != nullptr && a.qblk != nullptr;
+  bf16x8 khf;
+#pragma unroll
+  for (int j = 0; j < 8; j++) khf[j] = 0;
+  if (use_hot) khf = *reinterpret_cast<const bf16x8*>(a.khot + ((int64_t)b * a.nk_pad + mykey) * 16 + 8 * lh);
   const bool key_ok = kinfo != 31u;
   const uint32_t keybit = key_ok ? (1u << kinfo) : 0u;
   const bool wave_keys_ok = __all(key_ok);
@@ -375,6 +408,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
 
   const int srow = tid >> 3, sc = tid & 7;
   bf16x8 stage_q, stage_o;
+  uint4 stage_b = make_uint4(0, 0, 0, 0);
   float stage_c = 0.f;
   bool stage_oob = false;
   const int cwhich = tid >> 6 < 2 ? tid >> 6 : 2, crow = tid & 63;
@@ -387,6 +421,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
     stage_oob = qq >= a.nq;
     if (qq > a.nq - 1) qq = a.nq - 1;
     stage_c = cbase[qq];
+    if (use_hot && tid < 128) {
+      int qb = qt * BQ + (tid >> 1); if (qb > a.nq - 1) qb = a.nq - 1;
+      stage_b = *reinterpret_cast<const uint4*>(a.qblk + (int64_t)qb * 16 + (tid & 1) * 8);
+    }
   };
   auto swrite = [&](int buf) {
     *reinterpret_cast<bf16x8*>(Qs + buf * BQ * DH + rt_off(srow, sc)) = stage_q;
@@ -396,6 +434,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
       if (cwhich == 0) v = -v * inv_c2; else if (cwhich == 1) v = -v;
       rowc[buf * 192 + tid] = v;
     }
+    if (use_hot && tid < 128) *reinterpret_cast<uint4*>(qblk_s + buf * (BQ * 16) + (tid >> 1) * 16 + (tid & 1) * 8) = stage_b;
   };
 
   if (n_it > 0) gload(first_qt);
@@ -461,7 +500,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
 #undef KV_P
       }
       bf16x8 pb[2], sb[2];
-      if (full && wave_keys_ok) {
+      const bool clean = full && wave_keys_ok;
+      if (!clean && use_hot) {          // blocked (query, key) pairs: -32768 on top of the score, exp2 is exactly 0
+        const bf16x8 qbf = *reinterpret_cast<const bf16x8*>(qblk_s + buf * (BQ * 16) + (sub * 32 + l31) * 16 + 8 * lh);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qbf, khf, s, 0, 0, 0);
+      }
+      if (clean || use_hot) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const float p0 = __builtin_amdgcn_exp2f(PRESCALED ? s[r] : s[r] * c2), p1 = __builtin_amdgcn_exp2f(PRESCALED ? s[r + 1] : s[r + 1] * c2);
@@ -529,7 +573,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
       }
   }
 }
-#define DKV_LDS_BYTES (2 * BQ * DH * 2 * 2 + 2 * 192 * 4 + MAX_QTILES * 4 + DH * 4)
+#define DKV_LDS_BYTES (2 * BQ * DH * 2 * 2 + 2 * 192 * 4 + MAX_QTILES * 4 + DH * 4 + 2 * BQ * 16 * 2)
 
 extern "C" int mca_attn_bwd_dkv(const mca_attn_bwd2_args* a, mca_stream_t stream) {
   const int rc = check_bwd2(a);
@@ -539,6 +583,8 @@ extern "C" int mca_attn_bwd_dkv(const mca_attn_bwd2_args* a, mca_stream_t stream
   if (a->nk_pad < a->n_kblocks256 * BKEYS) return MCA_E_BADARG;
   if (a->dkv_ld % 4 || a->dkv_bstride % 4 || (uintptr_t)a->dk % 8 || (uintptr_t)a->dv % 8 || (uintptr_t)a->k_wg % 16) return MCA_E_ALIGN;
   if (a->n_qtiles64 > MAX_QTILES) return MCA_E_UNSUPPORTED;
+  if ((a->khot != nullptr) != (a->qblk != nullptr)) return MCA_E_BADARG;
+  if ((uintptr_t)a->khot % 16 || (uintptr_t)a->qblk % 16) return MCA_E_ALIGN;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES) != hipSuccess ||

@@ -40,6 +40,7 @@ template <bool PRESCALED>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int dbg) {
   __shared__ __attribute__((aligned(16))) u16 lds[2 * 2 * AK * DH];   // K,V double-buffered: 32 KiB
   __shared__ __attribute__((aligned(16))) uint8_t kinfo[2][AK];
+  __shared__ __attribute__((aligned(16))) u16 hot_s[2][AK * 16];   // one-hot key groups of the tile (mask product operand)
   __shared__ uint8_t flags_s[MAX_KTILES];       // this sample's key-tile flags
   // This query tile's list entries whose key tile has at least one valid key in this sample, compacted once: reading the
   // CSR entry and the flag of the NEXT live tile at the top of every iteration was a chain of a scalar global load and an
@@ -70,6 +71,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
     for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
   }
   const uint32_t qm = a.qmask[qrow];
+  // the mask as a matrix product (mca_build_keyhot): Qblk[q][g] = group g visible ? 0 : -32768 (bf16 0xC700), slot 15 (padded
+  // keys) always -32768; this lane holds groups 8 lh .. 8 lh + 7 of its query
+  const bool use_hot = a.khot != nullptr;
+  bf16x8 qblk;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int g = 8 * lh + j;
+    qblk[j] = (g < 15 && ((qm >> g) & 1u)) ? (short)0 : (short)0xC700;
+  }
   // scores -> log2 domain; q pre-scaled by scale * log2(e) (MCA_ATTN_Q_PRESCALED): they already are
   const float c2 = PRESCALED ? 1.f : a.scale * 1.4426950408889634f;
 
@@ -83,6 +93,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
   const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
   const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
   const uint8_t* kinfo_g = a.keyinfo + (int64_t)b * a.nk_pad;
+  const u16* khot_g = use_hot ? a.khot + (int64_t)b * a.nk_pad * 16 : nullptr;
   {
     const uint8_t* flags_g = a.ktile_flags + (int64_t)b * a.n_ktiles;
     for (int i = tid; i < a.n_ktiles; i += 256) flags_s[i] = flags_g[i];
@@ -103,7 +114,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
   const int last_kt = a.n_ktiles - 1;
   bf16x8 rk[2], rv[2];
   uint32_t rinfo = 0;
+  uint4 rhot = make_uint4(0, 0, 0, 0);
   auto gload = [&](int kt) {
+    if (use_hot) { if (tid < 128) rhot = *reinterpret_cast<const uint4*>(khot_g + ((int64_t)kt * AK + (tid >> 1)) * 16 + (tid & 1) * 8); }
+    else if (tid < 16) rinfo = *reinterpret_cast<const uint32_t*>(kinfo_g + kt * AK + tid * 4);
     const u16* kb = kbase + (int64_t)kt * AK * a.kv_ld;
     const u16* vb = vbase + (int64_t)kt * AK * a.kv_ld;
     if (kt != last_kt) {
@@ -120,7 +134,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
         rv[i] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * a.kv_ld + sc[i] * 8);
       }
     }
-    if (tid < 16) rinfo = *reinterpret_cast<const uint32_t*>(kinfo_g + kt * AK + tid * 4);
   };
   auto swrite = [&](int buf) {
 #pragma unroll
@@ -128,7 +141,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
       *reinterpret_cast<bf16x8*>(Ks + buf * AK * DH + k_off(srow[i], sc[i])) = rk[i];
       *reinterpret_cast<bf16x8*>(Vs + buf * AK * DH + v_off(srow[i], sc[i])) = rv[i];
     }
-    if (tid < 16) *reinterpret_cast<uint32_t*>(&kinfo[buf][tid * 4]) = rinfo;
+    if (use_hot) { if (tid < 128) *reinterpret_cast<uint4*>(&hot_s[buf][(tid >> 1) * 16 + (tid & 1) * 8]) = rhot; }
+    else if (tid < 16) *reinterpret_cast<uint32_t*>(&kinfo[buf][tid * 4]) = rinfo;
   };
 
   // the tile list of this query tile, minus tiles whose keys are all padded in this sample (wavefront 0 compacts it)
@@ -182,9 +196,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[kb], 0, 0, 0);
       }
     }
+    // ---- masking (structure boundary / padded keys / keys past nk) as one more product into the same accumulators
+    if (need_mask && use_hot) {
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        const bf16x8 hf = *reinterpret_cast<const bf16x8*>(&hot_s[buf][(kb * 32 + l31) * 16 + 8 * lh]);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf, qblk, s[kb], 0, 0, 0);
+      }
+    }
     FW_STAMP();
-    // ---- masking (structure boundary / padded keys / keys past nk)
-    if (need_mask) {
+    // ---- the same, element by element (no one-hot operand: more than 15 key groups)
+    if (need_mask && !use_hot) {
 #pragma unroll
       for (int kb = 0; kb < 2; kb++)
 #pragma unroll
@@ -262,8 +284,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
     mca_trace_attn_fwd[1020] = __builtin_amdgcn_s_memrealtime() - rt0; mca_trace_attn_fwd[1021] = __builtin_readcyclecounter() - cy0;
   }
 #endif
-  // ---- epilogue
-  const bool uniform = !(l_run > 0.f);
+  // ---- epilogue (a row that met blocked keys only: no tile at all, or every score carried the -32768 of the mask product)
+  const bool uniform = !(l_run > 0.f) || m_run < -16384.f * c2;
   const float inv = uniform ? 0.f : 1.f / l_run;
   if (qvalid) {
     if (lh == 0) a.lse[((int64_t)b * a.heads + h) * a.nq + qrow] = uniform ? INFINITY : m_run + log2f(l_run);
@@ -655,6 +677,26 @@ extern "C" int mca_build_keyinfo(const uint8_t* padding, const uint8_t* kgroup, 
   const int ntile_pad = (nk_pad + AK - 1) / AK;
   hipLaunchKernelGGL(build_keyinfo_kernel, dim3(ntile_pad, batch), dim3(64), 0, as_stream(stream), padding, kgroup,
                      keyinfo, ktile_flags, nk, nk_pad, n_ktiles);
+  return launch_status();
+}
+
+// khot[b, j, 0..15] = one-hot (bf16 1.0) of min(keyinfo[b, j], 15): padded keys and keys past nk (31) land in slot 15
+__global__ __launch_bounds__(256) void build_keyhot_kernel(const uint8_t* __restrict__ keyinfo, u16* __restrict__ khot, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int g = keyinfo[i] >= 15 ? 15 : keyinfo[i];
+  uint32_t w[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) w[k] = (g >> 1) == k ? (0x3F80u << (16 * (g & 1))) : 0u;
+  uint4* dst = reinterpret_cast<uint4*>(khot + i * 16);
+  dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+extern "C" int mca_build_keyhot(const uint8_t* keyinfo, uint16_t* khot, int batch, int nk_pad, mca_stream_t stream) {
+  if (!keyinfo || !khot || batch <= 0 || nk_pad <= 0) return MCA_E_BADARG;
+  if ((uintptr_t)khot % 16) return MCA_E_ALIGN;
+  const int64_t n = (int64_t)batch * nk_pad;
+  hipLaunchKernelGGL(build_keyhot_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), keyinfo, khot, n);
   return launch_status();
 }
 

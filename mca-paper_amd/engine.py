@@ -110,6 +110,9 @@ class FusionEngine:
         # attention backward in two passes without atomics (mca_attn_bwd_dq + mca_attn_bwd_dkv): dQ written once as bf16 straight
         # into the dqkv operand of the data- / weight-gradient GEMMs; MCA_ATTN_BWD_ONE_PASS=1 keeps the atomic one-pass kernel
         self.attn_bwd_two_pass = os.environ.get("MCA_ATTN_BWD_ONE_PASS", "0") != "1"
+        # the attention mask as a matrix product (mca_build_keyhot): needs every key group id <= 14; MCA_MASK_MFMA=0 keeps the
+        # element-wise mask (A/B)
+        self.mask_mfma = int(self.st.kgroup.max()) <= 14 and os.environ.get("MCA_MASK_MFMA", "1") != "0"
         # micro-batch interleave (opt-in, MCA_MICRO_BATCHES=2): batches of at least micro_batch_min samples run as two
         # halves on two streams.  Measured on CMU b=32: 26.3 vs 26.7 ms/step when the host runs ahead, no gain when it
         # does not (tools/ab_step.py 102 1 2, tools/diag_switch.py) - kept off by default.
@@ -173,6 +176,12 @@ class FusionEngine:
         self.kgroup = _dev(st.kgroup.astype(np.uint8), dev)
         self.qmask_attn = _dev(st.qmask_attn.astype(np.uint32).view(np.int32), dev)
         self.qmask_pool = _dev(st.qmask_pool.astype(np.uint32).view(np.int32), dev)
+        # query side of the mask product (mca_hip.h, mca_build_keyhot): qblk[i][g] = group g visible ? 0 : -32768, slot 15 blocked
+        def qblk_of(qm):
+            bits = (qm.astype(np.uint32)[:, None] >> np.arange(16, dtype=np.uint32)[None, :]) & 1
+            bits[:, 15] = 0
+            return torch.from_numpy(np.where(bits == 1, 0.0, -32768.0).astype(np.float32)).to(torch.bfloat16).to(dev).contiguous()
+        self.qblk_attn, self.qblk_pool = qblk_of(st.qmask_attn), qblk_of(st.qmask_pool)
         self.sched_attn_f = _Sched(st.attn_schedule(FWD_BQ, FWD_BK), dev)
         self.sched_attn_b = _Sched(st.attn_schedule(BWD_BQ, BWD_BK), dev)
         if self.eao:
@@ -324,6 +333,7 @@ class FusionEngine:
             ws["seg_counts"] = torch.zeros(b, R, dtype=torch.int32, device=dev)
         ws["vmean"], ws["dvmean"], ws["delta"], ws["delta_p"] = f32(b, D), f32(b, D), f32(b, H, N), f32(b, H, R)
         ws["keyinfo"], ws["kflags"] = u8(b, self.nk_pad), u8(b, (N + 63) // 64)
+        ws["khot"] = bf(b, self.nk_pad, 16) if self.mask_mfma else None
         ws["padding"] = u8(b, N)
         ws["present"] = torch.zeros(b, dtype=torch.int32, device=dev)
         ws["present_native"] = torch.zeros(b, dtype=torch.int32, device=dev)
@@ -430,6 +440,7 @@ class FusionEngine:
         a.vmean = ws["vmean"].data_ptr()
         a.batch, a.heads, a.nq, a.nk, a.nk_pad = b, self.H, nq, N, self.nk_pad
         a.n_qtiles, a.n_ktiles, a.scale, a.flags = sched.s.n_q, sched.s.n_k, self.scale, self.attn_flags
+        a.khot = ws["khot"].data_ptr() if ws.get("khot") is not None else None
         call("mca_attn_vmean", a.v, a.kv_bstride, a.kv_ld, ws["vmean"].data_ptr(), b, N, self.H, stream_ptr())
         hip.set_tag("pool" if nq != N else "layer")
         if self.attn_dtype == "fp8" and nq == N:
@@ -460,6 +471,8 @@ class FusionEngine:
         a.n_qtiles128, a.n_ktiles64 = sched_f.s.n_q, sched_f.s.n_k
         a.k_wg, a.k_qt, a.n_qtiles64, a.n_kblocks256 = sched_b.k_wg.data_ptr(), sched_b.k_qt.data_ptr(), sched_b.s.n_q, sched_b.s.n_k
         a.batch, a.heads, a.nq, a.nk, a.nk_pad, a.scale, a.flags = b, self.H, nq, N, self.nk_pad, self.scale, self.attn_flags
+        if ws.get("khot") is not None:
+            a.khot, a.qblk = ws["khot"].data_ptr(), (self.qblk_attn if qmask is self.qmask_attn else self.qblk_pool).data_ptr()
         pairs = sched_b.s.allowed_pairs
         hip.set_tag("pool" if nq != N else "layer")
         # algorithmic flops of the whole backward (2 x forward) split 3 : 5 over the passes by their share of the five
@@ -614,6 +627,8 @@ class FusionEngine:
         m, D, N, H, Ip, R, b, T = self.model, self.D, self.N, self.H, self.Ip, self.R, ws["b"], ws["T"]
         call("mca_build_keyinfo", ptr(ws["padding"]), ptr(self.kgroup), ptr(ws["keyinfo"]), ptr(ws["kflags"]), b, N,
              self.nk_pad, stream_ptr())
+        if ws["khot"] is not None:
+            call("mca_build_keyhot", ptr(ws["keyinfo"]), ptr(ws["khot"]), b, self.nk_pad, stream_ptr())
         # T >= 2048: the residual LayerNorm(x) is recomputed inside the out-proj / FF2 GEMM epilogues from x and the saved row
         # statistics (mca_gemm_nt_lnres): the LayerNorm kernels then write the bf16 GEMM operand only
         ln_in_gemm = self.fuse_ln_residual and T >= 2048 and D % 128 == 0 and D >= 512 and Ip >= 512

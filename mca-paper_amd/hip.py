@@ -63,6 +63,7 @@ class AttnFwdArgs(C.Structure):
         ("vmean", C.c_void_p),
         ("batch", C.c_int), ("heads", C.c_int), ("nq", C.c_int), ("nk", C.c_int), ("nk_pad", C.c_int),
         ("n_qtiles", C.c_int), ("n_ktiles", C.c_int), ("scale", C.c_float), ("flags", C.c_int),
+        ("khot", C.c_void_p),
     ]
 
 
@@ -103,6 +104,7 @@ class AttnBwd2Args(C.Structure):
         ("k_wg", C.c_void_p), ("k_qt", C.c_void_p), ("n_qtiles64", C.c_int), ("n_kblocks256", C.c_int),
         ("batch", C.c_int), ("heads", C.c_int), ("nq", C.c_int), ("nk", C.c_int), ("nk_pad", C.c_int),
         ("scale", C.c_float), ("flags", C.c_int),
+        ("khot", C.c_void_p), ("qblk", C.c_void_p),
     ]
 
 
@@ -111,6 +113,7 @@ _P, _I64, _I, _F = C.c_void_p, C.c_int64, C.c_int, C.c_float
 # name -> (restype, argtypes).  Must list EVERY symbol include/mca_hip.h declares (tests check this).
 SIGNATURES = {
     "mca_version": (C.c_char_p, []),
+    "mca_build_keyhot": (_I, [_P, _P, _I, _I, _P]),
     "mca_rows_copy_add": (_I, [_P, _I64, _P, _I64, _I64, _I, _I, _I, _P]),
     "mca_segment_mean_fwd": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "mca_segment_mean_bwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),

@@ -413,6 +413,22 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first, prescaled=True, spi
     assert torch.equal(torch.isinf(lse[:, 0]), uni_ref)
     if drop_first and not pool:
         assert uni_ref.any()
+    # ---- the mask as a matrix product (mca_build_keyhot; structures with at most 15 key groups): same output, same flags
+    if int(st.kgroup.max()) <= 14:
+        khot = torch.empty(b, nk_pad, 16, dtype=torch.bfloat16, device=dev)
+        H.call("mca_build_keyhot", keyinfo.data_ptr(), khot.data_ptr(), b, nk_pad, H.stream_ptr())
+        want_hot = torch.nn.functional.one_hot(keyinfo.long().clamp_max(15), 16).to(torch.bfloat16)
+        assert torch.equal(khot, want_hot)
+        o2 = torch.zeros_like(o); lse2 = torch.empty_like(lse)
+        a.o, a.lse, a.khot = o2.data_ptr(), lse2.data_ptr(), khot.data_ptr()
+        H.call("mca_attn_fwd", C.byref(a), H.stream_ptr())
+        torch.cuda.synchronize()
+        assert rel(o2.float().view(b, nq, D), ref_o) < 6e-3
+        assert torch.equal(torch.isinf(lse2[:, 0]), uni_ref)
+        fin = ~torch.isinf(lse)
+        assert (lse2[fin] - lse[fin]).abs().max() < 1e-4          # adding an exact 0 / an exp2 that underflows to exactly 0
+        assert rel(o2.float(), o.float()) < 2e-3
+        a.o, a.lse = o.data_ptr(), lse.data_ptr()
 
     # ---- backward
     d_o = bf(torch.randn(b, nq, D, device=dev, generator=g))
@@ -472,6 +488,19 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first, prescaled=True, spi
         H.call("mca_attn_bwd_dkv", C.byref(a2), H.stream_ptr())
         torch.cuda.synchronize()
         assert torch.equal(dq2, dq3) and torch.equal(dkv2, dkv3)
+        # the mask as a matrix product (khot + qblk): allowed scores get an exact +0, blocked ones an exp2 that is exactly 0:
+        # the same bits as the element-wise mask
+        if int(st.kgroup.max()) <= 14:
+            bits = (torch.from_numpy(qmask_np.astype(np.int64)).to(dev)[:, None] >> torch.arange(16, device=dev)[None, :]) & 1
+            bits[:, 15] = 0
+            qblk = torch.where(bits == 1, 0.0, -32768.0).to(torch.bfloat16).contiguous()
+            dq4 = torch.empty_like(dq2); dkv4 = torch.zeros_like(dkv2)
+            a2.dq, a2.dk, a2.dv = dq4.data_ptr(), dkv4.data_ptr() + D * 2, dkv4.data_ptr() + 2 * D * 2
+            a2.khot, a2.qblk = khot.data_ptr(), qblk.data_ptr()
+            H.call("mca_attn_bwd_dq", C.byref(a2), H.stream_ptr())
+            H.call("mca_attn_bwd_dkv", C.byref(a2), H.stream_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(dq2, dq4) and torch.equal(dkv2, dkv4)
 
 
 @pytest.mark.parametrize("variant,pool,drop", [("mca", False, False), ("mca", False, True), ("zorro", False, True),

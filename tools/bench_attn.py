@@ -18,6 +18,8 @@ if os.environ.get("MCA_BENCH_ATTN_PAD"):          # the bench's padding (uniform
         ln[torch.rand(b, device="cuda", generator=g) < 0.2] = 0
         ws["padding"][:, eng.offsets[mi]:eng.offsets[mi] + n] = (torch.arange(n, device="cuda")[None] >= ln[:, None]).to(ws["padding"].dtype)
 H.call("mca_build_keyinfo", ws["padding"].data_ptr(), eng.kgroup.data_ptr(), ws["keyinfo"].data_ptr(), ws["kflags"].data_ptr(), b, N, eng.nk_pad, H.stream_ptr())
+if ws.get("khot") is not None:
+    H.call("mca_build_keyhot", ws["keyinfo"].data_ptr(), ws["khot"].data_ptr(), b, eng.nk_pad, H.stream_ptr())
 a = ws["layers"][0]
 a["qkv"].copy_(torch.randn_like(a["qkv"].float()).bfloat16())
 a["qkv"][:, :D] *= 0.18          # q as the engine stores it (scale * log2 e folded in)
