@@ -23,11 +23,14 @@ from . import optim as _optim
 
 
 class GraphedStep:
-    def __init__(self, model, optimizer, batch, clip: float = 2.0, dp=None, warmup: int = 3):
+    def __init__(self, model, optimizer, batch, clip: float = 2.0, dp=None, warmup: int = 3, overlap_wgrad: bool = False):
         if dp is not None:
             raise NotImplementedError("GraphedStep captures a single-GPU step; run the eager step under DataParallelMCA")
         self.model, self.opt, self.clip = model, optimizer, float(clip)
         eng = model.engine
+        # weight-gradient GEMMs on the side stream: inside a graph the fork / join edges cost more than the overlap gains
+        # (b = 32 CMU, one box, alternating processes: 21.9 ms with, 21.5 ms without)
+        eng.overlap_wgrad = bool(overlap_wgrad) and eng.overlap_wgrad
         if eng.check_finite not in (False, "deferred"):
             eng.check_finite = "deferred"          # the synchronous form reads the flag on the host inside the forward
         self.static = {k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in batch.items()}
@@ -53,9 +56,10 @@ class GraphedStep:
         self.opt.step()
         return out
 
-    def step(self, batch=None):
+    def step(self, batch=None, eager: bool = False):
         """One optimizer step; ``batch`` (same shapes) is copied into the static input buffers first.  Returns the loss tensor
-        of the captured step (its value is that of THIS replay once the stream has run it)."""
+        of the captured step (its value is that of THIS replay once the stream has run it).  eager=True runs the same body
+        kernel by kernel instead of replaying it (bench.py times its kernels with HIP events on such a step)."""
         if batch is not None:
             for k, v in batch.items():
                 for kk, vv in v.items():
@@ -66,6 +70,9 @@ class GraphedStep:
             eng.poll_finite()                      # the flag copy of an EARLIER replay that has already landed (no sync)
         self.opt.step_count += 1
         self.opt.set_hyper(self.opt.step_count)
+        if eager:
+            loss = self._body()["loss"]            # records its own flag event (engine._model_forward)
+            return loss
         self.graph.replay()
         if eng.check_finite:                       # the captured step ends with the flag's copy to pinned host memory
             eng._flag_event = torch.cuda.Event()
