@@ -34,6 +34,9 @@ class GraphedStep:
         if eng.check_finite not in (False, "deferred"):
             eng.check_finite = "deferred"          # the synchronous form reads the flag on the host inside the forward
         self.static = {k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in batch.items()}
+        # the warm-up steps are real optimizer steps: weights, moments and the step count are put back afterwards, so that
+        # constructing a GraphedStep does not train (the capture itself executes nothing)
+        saved = (eng.flat.clone(), optimizer.exp_avg.clone(), optimizer.exp_avg_sq.clone(), optimizer.step_count)
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream(device=eng.device)
         side.wait_stream(cur)
@@ -47,6 +50,10 @@ class GraphedStep:
         with torch.cuda.graph(self.graph):
             self.out = self._body()
         self.loss = self.out["loss"]
+        eng.flat.copy_(saved[0]); optimizer.exp_avg.copy_(saved[1]); optimizer.exp_avg_sq.copy_(saved[2])
+        optimizer.step_count = saved[3]
+        eng.invalidate_weights()
+        eng.finite_flag.zero_(); eng._flag_host.zero_(); eng._flag_event = None
 
     def _body(self):
         out = self.model(self.static)

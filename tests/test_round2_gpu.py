@@ -317,6 +317,46 @@ def test_long_config_at_batch_128(P):
         assert torch.equal(ps[i], pb[i])
 
 
+# ------------------------------------------------------------------------------------------------ the training script
+@pytest.mark.parametrize("variant,graph", [("mca", False), ("mca", True), ("eao", False)])
+def test_train_script_end_to_end(P, tmp_path, variant, graph):
+    """train_accel_gpu.py <yaml> --synthetic N (the reference's entry point, train_accel_gpu.py:1-185) as a subprocess: YAML ->
+    model (MCA or EAO) -> N optimizer steps -> log + Accelerate-layout state directory.  The replayed loop (--graph) logs the
+    same first-step loss as the eager one (same seed, same synthetic batches) and every logged number is finite."""
+    import json, subprocess, yaml
+    cfg = small_config(variant)
+    mod_cfg = {name: {"type": "embedded_sequence", "pad_len": enc["max_tokens"], "embedding_size": enc["input_size"], "data_col_name": "data", "dropout": 0.2}
+               for name, enc in cfg["encoder_configs"].items()}
+
+    def run(tag, extra):
+        out = tmp_path / tag
+        y = dict(encoder_configs=cfg["encoder_configs"], modality_config=mod_cfg, hidden_size=cfg["dim"], layers=cfg["depth"], heads=cfg["heads"],
+                 dim_head=cfg["dim_head"], num_fusion_tokens=cfg["num_fusion_tokens"], batch_size=4, fcl=cfg["fcl"], fcl_root=cfg["fcl_root"],
+                 bimodal_contrastive=cfg["bimodal_contrastive"], non_fusion_fcl=cfg["non_fusion_fcl"], fusion_combos=cfg["fusion_combos"],
+                 zorro=cfg["zorro"], eao=cfg["eao"], no_fusion=cfg["no_fusion"], mean_pool=cfg["mean_pool"], predrop=True, epochs=1, lr=1e-3,
+                 lr_scheduler_type="cosine", num_warmup_steps=2, clip=2.0, seed=7, output_dir=str(out), dataset="unused", run_eval_loop=False)
+        ypath = tmp_path / f"{tag}.yaml"
+        ypath.write_text(yaml.safe_dump(y, sort_keys=False))
+        r = subprocess.run([sys.executable, os.path.join(REPO, "train_accel_gpu.py"), str(ypath), "--synthetic", "12"] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        recs = [json.loads(l) for l in open(out / "log.jsonl")]
+        assert len(recs) >= 2 and recs[-1]["step"] == 12
+        for rec in recs:
+            assert all(v == v and abs(v) < 1e9 for k, v in rec.items() if isinstance(v, float)), rec
+        assert os.path.exists(out / "0" / "model.safetensors") and os.path.exists(out / "0" / "optimizer.bin")
+        return recs
+
+    recs = run("eager", [])
+    assert recs[0]["lr"] < recs[1]["lr"] or recs[0]["step"] > 2          # warm-up: the learning rate comes from the schedule
+    if graph:
+        recs_g = run("graph", ["--graph"])
+        assert abs(recs_g[0]["total_loss"] - recs[0]["total_loss"]) <= 1e-4 * abs(recs[0]["total_loss"])
+        assert abs(recs_g[-1]["total_loss"] - recs[-1]["total_loss"]) <= 5e-2 * abs(recs[-1]["total_loss"])
+    if variant == "eao":
+        assert any(k.startswith("audio_") or k.endswith("_audio") for k in recs[0])          # the pairwise terms of the EAO loss
+
+
 # ------------------------------------------------------------------------------------------------ data parallel
 def _dp_worker(rank, world, port, out, p_drop):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -402,11 +442,10 @@ def test_graphed_step_matches_eager(P):
         opt = optim.FusedAdamW(m, lr=lrs[0], weight_decay=0.0)
         losses, snaps = [], []
         if graphed:
-            # the capture's warm-up steps move the weights and the moments: put them back before the comparison starts
-            w0, m0, v0 = m.engine.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()
+            # the constructor's warm-up steps are undone by the constructor itself: weights, moments, step count as before
+            w0 = m.engine.flat.clone()
             g = graph.GraphedStep(m, opt, batches[0], clip=2.0, warmup=2)
-            m.engine.flat.copy_(w0); opt.exp_avg.copy_(m0); opt.exp_avg_sq.copy_(v0); opt.step_count = 0
-            m.engine.invalidate_weights()
+            assert torch.equal(m.engine.flat, w0) and opt.step_count == 0 and float(opt.exp_avg.abs().max()) == 0.0
         for i, bt in enumerate(batches):
             opt.param_groups[0]["lr"] = lrs[i]
             if graphed:

@@ -119,6 +119,9 @@ def main():
     step = config.start_epoch * steps_per_epoch
     if config.restart and "scheduler_last_epoch" in meta:          # the restored scheduler position, as load_state gives the reference
         step = meta["scheduler_last_epoch"] // sched_stride
+    # --graph (single GPU): the whole step replayed as one hipGraph (graph.GraphedStep; batches have static shapes: the
+    # collators pad every modality to its pad_len)
+    use_graph, graphed = "--graph" in sys.argv and world == 1, None
     model.train()
     for epoch in range(config.start_epoch, config.epochs):
         t_epoch = time.time()
@@ -127,16 +130,24 @@ def main():
             for g in opt.param_groups:
                 g["lr"] = config.lr * lr_factor(config.lr_scheduler_type, step * sched_stride, config.num_warmup_steps,
                                                 total_steps * sched_stride)
-            outputs = model(batch)
-            opt.zero_grad()
-            loss = outputs["loss"]
-            loss.backward()
-            if dp is not None:
-                dp.finish_backward()
-            gnorm = optim.clip_grad_norm_(model, config.clip) if config.clip else None
-            opt.step()
-            step += 1
-            model.engine.poll_finite()          # raises for a completed step that saw non-finite values (no host sync)
+            if use_graph:
+                if graphed is None:
+                    graphed = importlib.import_module("mca-paper_amd.graph").GraphedStep(model, opt, batch, clip=config.clip or 0.0)
+                loss = graphed.step(batch)
+                outputs, gnorm = graphed.out, graphed.gnorm
+                step += 1
+                model.engine.poll_finite()
+            else:
+                outputs = model(batch)
+                opt.zero_grad()
+                loss = outputs["loss"]
+                loss.backward()
+                if dp is not None:
+                    dp.finish_backward()
+                gnorm = optim.clip_grad_norm_(model, config.clip) if config.clip else None
+                opt.step()
+                step += 1
+                model.engine.poll_finite()          # raises for a completed step that saw non-finite values (no host sync)
             if rank == 0 and (idb % 10 == 0 or idb == steps_per_epoch - 1):
                 rec = {"epoch": epoch, "step": step, "total_loss": float(loss), "lr": opt.param_groups[0]["lr"],
                        "grad_norm": float(gnorm) if gnorm is not None else None,
@@ -153,8 +164,9 @@ def main():
             # eval loop of the reference (train_accel_gpu.py:137-181): losses + Wang-Isola alignment / uniformity
             model.eval()
             names = list(model_config["encoder_configs"].keys())
-            uni = {k: P.metrics.Uniformity() for k in names + ["fusion"]}
-            ali = {k: P.metrics.Alignment() for k in names}
+            has_fusion = not model_config["eao"]          # the EAO baseline has no fusion token (train_accel_gpu.py:47,155,175)
+            uni = {k: P.metrics.Uniformity() for k in names + (["fusion"] if has_fusion else [])}
+            ali = {k: P.metrics.Alignment() for k in (names if has_fusion else [])}
             with torch.no_grad():
                 tot, n = 0.0, 0
                 for batch in eval_batches:
@@ -162,8 +174,11 @@ def main():
                     tot += float(out["loss"]); n += 1
                     for k in names:
                         sm = out["modality_sample_mask"][k]
-                        uni[k].update(out[k][sm]); ali[k].update(out[k][sm], out["fusion"][sm])
-                    uni["fusion"].update(out["fusion"])
+                        uni[k].update(out[k][sm])
+                        if has_fusion:
+                            ali[k].update(out[k][sm], out["fusion"][sm])
+                    if has_fusion:
+                        uni["fusion"].update(out["fusion"])
             if rank == 0:
                 rec = {"epoch": epoch, "val_epoch_total_loss": tot / max(1, n)}
                 rec.update({f"val_epoch_uniformity_{k}": float(v.compute()) for k, v in uni.items()})
