@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void attn_fwd8_kernel(mca_attn_fwd_args a, mca
   __shared__ __attribute__((aligned(16))) uint8_t lds[2 * 2 * AK * DH];   // K8, V8T double-buffered: 16 KiB
   __shared__ __attribute__((aligned(16))) uint8_t sc_s[2][2][AK * 2];     // [buffer][K | V][row][half] scale bytes
   __shared__ __attribute__((aligned(16))) uint8_t kinfo[2][AK];
+  __shared__ __attribute__((aligned(16))) u16 hot_s[2][AK * 16];          // one-hot key groups (mask product, attention_fwd.hip)
   __shared__ uint8_t flags_s[MAX_KTILES];
   __shared__ uint32_t live_s[MAX_KTILES];
   __shared__ int n_live_s;
@@ -160,6 +161,15 @@ __global__ __launch_bounds__(256) void attn_fwd8_kernel(mca_attn_fwd_args a, mca
     qscale = f.qs[rowi * 2 + lh];
   }
   const uint32_t qm = a.qmask[qrow];
+  // the mask as a matrix product (mca_build_keyhot; a bf16 32x32x16 product into the same fp32 accumulators)
+  const bool use_hot = a.khot != nullptr;
+  bf16x8 qblk;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int g = 8 * lh + j;
+    qblk[j] = (g < 15 && ((qm >> g) & 1u)) ? (short)0 : (short)0xC700;
+  }
+  const u16* khot_g = use_hot ? a.khot + (int64_t)b * a.nk_pad * 16 : nullptr;
 
   f32x16 o[2];
 #pragma unroll
@@ -184,17 +194,20 @@ __global__ __launch_bounds__(256) void attn_fwd8_kernel(mca_attn_fwd_args a, mca
   const int srow = tid >> 2, scol = tid & 3;
   uint4 rk, rv;
   uint32_t rsk = 0, rsv = 0, rinfo = 0;
+  uint2 rhot = make_uint2(0, 0);
   auto gload = [&](int kt) {
+    if (use_hot) rhot = *reinterpret_cast<const uint2*>(khot_g + (int64_t)kt * (AK * 16) + tid * 4);
     rk = *reinterpret_cast<const uint4*>(k8b + ((int64_t)kt * AK + srow) * DH + 16 * scol);
     rv = *reinterpret_cast<const uint4*>(v8b + ((int64_t)kt * DH + srow) * AK + 16 * scol);
     if (tid < 32) { rsk = *reinterpret_cast<const uint32_t*>(ksb + (int64_t)kt * AK * 2 + tid * 4); rsv = *reinterpret_cast<const uint32_t*>(vsb + (int64_t)kt * DH * 2 + tid * 4); }
-    if (tid < 16) rinfo = *reinterpret_cast<const uint32_t*>(kinfo_g + kt * AK + tid * 4);
+    if (!use_hot && tid < 16) rinfo = *reinterpret_cast<const uint32_t*>(kinfo_g + kt * AK + tid * 4);
   };
   auto swrite = [&](int buf) {
     *reinterpret_cast<uint4*>(Ks + buf * AK * DH + t8_off(srow, scol)) = rk;
     *reinterpret_cast<uint4*>(Vs + buf * AK * DH + t8_off(srow, scol)) = rv;
     if (tid < 32) { *reinterpret_cast<uint32_t*>(&sc_s[buf][0][tid * 4]) = rsk; *reinterpret_cast<uint32_t*>(&sc_s[buf][1][tid * 4]) = rsv; }
-    if (tid < 16) *reinterpret_cast<uint32_t*>(&kinfo[buf][tid * 4]) = rinfo;
+    if (use_hot) *reinterpret_cast<uint2*>(&hot_s[buf][tid * 4]) = rhot;
+    else if (tid < 16) *reinterpret_cast<uint32_t*>(&kinfo[buf][tid * 4]) = rinfo;
   };
 
   if (wave == 0) {
@@ -238,7 +251,14 @@ __global__ __launch_bounds__(256) void attn_fwd8_kernel(mca_attn_fwd_args a, mca
       for (int r = 0; r < 16; r++) s[kb][r] = 0.f;
       s[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, s[kb], 0, 0, 0, kscale, 0, qscale);
     }
-    if (need_mask) {
+    if (need_mask && use_hot) {
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        const bf16x8 hf = *reinterpret_cast<const bf16x8*>(&hot_s[buf][(kb * 32 + l31) * 16 + 8 * lh]);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf, qblk, s[kb], 0, 0, 0);
+      }
+    }
+    if (need_mask && !use_hot) {
 #pragma unroll
       for (int kb = 0; kb < 2; kb++)
 #pragma unroll
@@ -300,7 +320,7 @@ __global__ __launch_bounds__(256) void attn_fwd8_kernel(mca_attn_fwd_args a, mca
     it = nit;
   }
 
-  const bool uniform = !(l_run > 0.f);
+  const bool uniform = !(l_run > 0.f) || m_run < -16384.f;          // (every score carried the -32768 of the mask product)
   const float inv = uniform ? 0.f : 1.f / l_run;
   if (qvalid) {
     if (lh == 0) a.lse[bh * a.nq + qrow] = uniform ? INFINITY : m_run + log2f(l_run) - 7.f;
@@ -330,7 +350,7 @@ extern "C" int mca_attn_fwd_fp8(const mca_attn_fwd_args* a, const mca_attn_fp8_o
   if (a->n_qtiles != (a->nq + AQ - 1) / AQ || a->n_ktiles != (a->nk + AK - 1) / AK || f->n_ktiles != a->n_ktiles) return MCA_E_BADARG;
   if (a->nk_pad < a->n_ktiles * AK || a->nk_pad % 4 || (uintptr_t)a->keyinfo % 4) return MCA_E_BADARG;
   if (a->o_ld % 4 || a->o_bstride % 4 || (uintptr_t)a->o % 8 || (uintptr_t)f->q8 % 16 || (uintptr_t)f->k8 % 16 || (uintptr_t)f->v8t % 16 ||
-      (uintptr_t)f->ks % 4 || (uintptr_t)f->vs % 4)
+      (uintptr_t)f->ks % 4 || (uintptr_t)f->vs % 4 || (uintptr_t)a->khot % 16)
     return MCA_E_ALIGN;
   if (a->heads > 65535 || a->batch > 65535 || a->n_ktiles > MAX_KTILES) return MCA_E_UNSUPPORTED;
   hipLaunchKernelGGL(attn_fwd8_kernel, dim3(a->n_qtiles, a->heads, a->batch), dim3(256), 0, as_stream(stream), *a, *f, mca_knobs[9]);

@@ -624,6 +624,14 @@ def test_attention_fp8_forward(H, shape):
     a.flags = H.ATTN_Q_PRESCALED
     H.call("mca_attn_fwd_fp8", C.byref(a), C.byref(f), H.stream_ptr())
     torch.cuda.synchronize()
+    # the mask as a matrix product (mca_build_keyhot): the same bits
+    khot = torch.empty(b, nk_pad, 16, dtype=torch.bfloat16, device=dev)
+    H.call("mca_build_keyhot", keyinfo.data_ptr(), khot.data_ptr(), b, nk_pad, H.stream_ptr())
+    o_h = torch.zeros_like(o); lse_h = torch.empty_like(lse)
+    a.o, a.lse, a.khot = o_h.data_ptr(), lse_h.data_ptr(), khot.data_ptr()
+    H.call("mca_attn_fwd_fp8", C.byref(a), C.byref(f), H.stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(o_h, o) and torch.equal(lse_h, lse)
     got = o.float().view(b, N, heads, 64).permute(0, 2, 1, 3)
     blocked = (~allowed)[None, None] | pad[:, None, None, :]
     emu = O.fp8_attention_core(q4, k4, v4, blocked)
