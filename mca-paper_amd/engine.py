@@ -104,7 +104,11 @@ class FusionEngine:
         self._mod_shifts = torch.arange(len(model.modality_types), dtype=torch.int32, device=self.device)
         self.fuse_ln_residual = True                # residual LayerNorm recomputed in the GEMM epilogue (large batches)
         # weight-gradient GEMMs on a side stream, concurrent with the backward chain
-        self.overlap_wgrad = os.environ.get("MCA_OVERLAP_WGRAD", "1") != "0"
+        # OFF by default since round 2: with the atomic-free attention backward the main stream keeps every CU busy, and the
+        # persistent weight-gradient GEMMs of a second stream only take CUs away from it (one box, alternating processes:
+        # 23.7 / 25.6 ms per b = 32 step with the side stream, 22.17 / 22.16 without; in round 1 it gained 0.7 ms).
+        # MCA_OVERLAP_WGRAD=1 turns it back on.
+        self.overlap_wgrad = os.environ.get("MCA_OVERLAP_WGRAD", "0") == "1"
         self.group_wgrad = os.environ.get("MCA_GROUP_WGRAD", "1") != "0"      # one weight-gradient launch per layer
         self.zero_dq_once = True                    # (one-pass backward) all dQ accumulators zeroed by one side-stream memset per step
         # attention backward in two passes without atomics (mca_attn_bwd_dq + mca_attn_bwd_dkv): dQ written once as bf16 straight
