@@ -365,8 +365,17 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
   const int lin0 = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
   const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y * gridDim.z));
   const int4 w = reinterpret_cast<const int4*>(a.k_wg)[lin % (int)gridDim.x];
-  const int kbi = w.x, it_begin = w.y, n_it = w.z, first_qt = w.w;
+  const int kbi = w.x, it_begin = w.y, first_qt = w.w;
   const int h = (lin / (int)gridDim.x) % (int)gridDim.y, b = lin / (int)(gridDim.x * gridDim.y);
+  // a key block whose four 64-key tiles hold no valid key in this sample (ktile_flags == 0: a dropped modality) sweeps nothing:
+  // dK = 0, dV = dvmean straight from the epilogue
+  int n_it = w.z;
+  {
+    const uint8_t* fl = a.ktile_flags + (int64_t)b * a.n_ktiles64;
+    int live = 0;
+    for (int t = 0; t < BKEYS / AK; t++) { const int kt = kbi * (BKEYS / AK) + t; if (kt < a.n_ktiles64) live |= fl[kt]; }
+    if (!live) n_it = 0;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int key0 = kbi * BKEYS;
@@ -394,6 +403,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
   const bool key_ok = kinfo != 31u;
   const uint32_t keybit = key_ok ? (1u << kinfo) : 0u;
   const bool wave_keys_ok = __all(key_ok);
+  // a wavefront whose 32 keys are all padded (a dropped modality, the tail of a short sequence) has P = 0 everywhere: it
+  // keeps staging and meeting the barriers, but skips its products and arithmetic; dK stays 0, dV becomes dvmean
+  const bool wave_dead = !__any(key_ok);
 
   f32x16 dk[2], dv[2];
 #pragma unroll
@@ -463,6 +475,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
     const uint32_t ent = __builtin_amdgcn_readfirstlane(qlist[it]);          // wave-uniform: scalar branch on `full`
     const bool full = (ent >> 31) != 0;
     if (it + 1 < n_it) gload((int)(__builtin_amdgcn_readfirstlane(qlist[it + 1]) & 0x7fffffffu));
+    if (!wave_dead)
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
       const u16* qs = Qs + buf * BQ * DH + sub * 32 * DH;
