@@ -107,8 +107,10 @@ class FusionEngine:
         # OFF by default since round 2: with the atomic-free attention backward the main stream keeps every CU busy, and the
         # persistent weight-gradient GEMMs of a second stream only take CUs away from it (one box, alternating processes:
         # 23.7 / 25.6 ms per b = 32 step with the side stream, 22.17 / 22.16 without; in round 1 it gained 0.7 ms).
-        # MCA_OVERLAP_WGRAD=1 turns it back on.
-        self.overlap_wgrad = os.environ.get("MCA_OVERLAP_WGRAD", "0") == "1"
+        # At small batches (b = 8: the N = 512 GEMMs fill 160 of 256 CUs) the side stream still pays: 8.7-8.8 against 9.5-10.2 ms
+        # eager.  None = by size (on below OVERLAP_ROWS_MAX token rows); MCA_OVERLAP_WGRAD=0 / 1 forces it.
+        env = os.environ.get("MCA_OVERLAP_WGRAD")
+        self.overlap_wgrad = None if env is None else env == "1"
         self.group_wgrad = os.environ.get("MCA_GROUP_WGRAD", "1") != "0"      # one weight-gradient launch per layer
         self.zero_dq_once = True                    # (one-pass backward) all dQ accumulators zeroed by one side-stream memset per step
         # attention backward in two passes without atomics (mca_attn_bwd_dq + mca_attn_bwd_dkv): dQ written once as bf16 straight
@@ -698,7 +700,7 @@ class FusionEngine:
     # ------------------------------------------------------------------------------------------------
     def _on_side(self, fn, slot: int, ws: dict):
         """Run fn() on the workspace's side stream, ordered after everything enqueued so far on the current stream."""
-        if not self.overlap_wgrad:
+        if not self.overlap_on(ws):
             fn()
             return
         side, events = ws["side"], ws["side_events"]
@@ -709,6 +711,14 @@ class FusionEngine:
         with torch.cuda.stream(side), hip.use_stream(side.cuda_stream):
             side.wait_event(ev)
             fn()
+
+    OVERLAP_ROWS_MAX = 40960
+
+    def overlap_on(self, ws) -> bool:
+        """weight-gradient GEMMs of this workspace on its side stream?"""
+        if self.overlap_wgrad is None:
+            return ws["T"] < self.OVERLAP_ROWS_MAX
+        return bool(self.overlap_wgrad)
 
     def _bucket_ready(self, idx):
         if self.grad_bucket_hook is not None:
@@ -725,7 +735,7 @@ class FusionEngine:
         main = torch.cuda.current_stream()
         if "parts" not in ws:
             self._backward_part(ws, d_pooled, self._bucket_ready)
-            if self.overlap_wgrad:
+            if self.overlap_on(ws):
                 main.wait_stream(ws["side"])                  # every weight gradient is in before clip / AdamW
             return
         # two half batches on two streams; every gradient accumulation is atomic, so both halves add into the same

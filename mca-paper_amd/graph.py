@@ -28,9 +28,9 @@ class GraphedStep:
             raise NotImplementedError("GraphedStep captures a single-GPU step; run the eager step under DataParallelMCA")
         self.model, self.opt, self.clip = model, optimizer, float(clip)
         eng = model.engine
-        # weight-gradient GEMMs on the side stream: inside a graph the fork / join edges cost more than the overlap gains
-        # (b = 32 CMU, one box, alternating processes: 21.9 ms with, 21.5 ms without)
-        eng.overlap_wgrad = bool(overlap_wgrad) and eng.overlap_wgrad
+        # weight-gradient GEMMs on the side stream: inside a graph the fork / join edges cost more than the overlap gains at
+        # every size tried (one box, alternating processes: b = 32 21.9 ms with, 21.5 without; b = 8 7.90-8.02 with, 7.80 without)
+        eng.overlap_wgrad = bool(overlap_wgrad)
         if eng.check_finite not in (False, "deferred"):
             eng.check_finite = "deferred"          # the synchronous form reads the flag on the host inside the forward
         self.static = {k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in batch.items()}
