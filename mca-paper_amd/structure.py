@@ -281,6 +281,15 @@ class EAOStructure:
     def attn_schedule(self, bq: int = 128, bk: int = 64) -> TileSchedule:
         return build_schedule(self.qmask_attn, self.kgroup, bq, bk)
 
+    def dense_attn_mask(self) -> np.ndarray:
+        """True = blocked (the block-diagonal complement), as FusionStructure.dense_attn_mask"""
+        return ~(((self.qmask_attn[:, None] >> self.kgroup[None, :].astype(np.uint32)) & 1).astype(bool))
+
+    @property
+    def block_dims(self) -> List[int]:
+        """lengths of the modality blocks of the super-sequence, in order (segment by segment)"""
+        return [self.token_dims[m] for mods in self.segments for m in mods]
+
 
 # --------------------------------------------------------------------------------------------------
 # loss schedule: which pooled slots are contrasted and which samples count   (model.py:132-233)

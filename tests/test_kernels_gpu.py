@@ -539,6 +539,31 @@ def test_attention_cmu_shape(H, variant, pool):
     _attention_case(H, st, b=2, heads=2, pool=pool, seed=12, drop_first=True)
 
 
+@pytest.mark.parametrize("mods,powers,n_groups", [([40, 30, 20, 10], (4, 3, 2), 15), ([40, 30, 20, 10, 24], (5, 4, 3), 21)])
+def test_attention_group_count_boundary(H, mods, powers, n_groups):
+    """15 key groups is the most the mask product holds (slot 15 = padded keys): the 4-modality structure uses every slot and
+    runs both mask paths (bitwise-equal gradients asserted in _attention_case); with 5 modalities and 16 combinations (21
+    groups) only the element-wise mask applies and the engine must not offer the one-hot operand."""
+    S = importlib.import_module("mca-paper_amd.structure")
+    st = S.FusionStructure(mods, 32 if n_groups > 15 else 33, powers, fcl=True)
+    assert int(st.kgroup.max()) + 1 == n_groups
+    _attention_case(H, st, b=2, heads=2, pool=False, seed=19, drop_first=True)
+    _attention_case(H, st, b=2, heads=2, pool=True, seed=20, drop_first=True)
+
+
+def test_attention_eao_block_diagonal(H):
+    """The EAO super-sequence (structure.EAOStructure): 3 + 3 segments, attention block-diagonal over them; a dropped
+    modality empties its own segment (uniform rows) and the part of the combination segments it occupies."""
+    S = importlib.import_module("mca-paper_amd.structure")
+    import types
+    e = S.EAOStructure([70, 45, 30], (2,), fcl=True, zorro=False)
+    # the harness pads per entry of token_dims: give it every block of the super-sequence (first block dropped in sample 0)
+    st = types.SimpleNamespace(n_tokens=e.n_tokens, qmask_attn=e.qmask_attn, qmask_pool=e.qmask_pool, kgroup=e.kgroup,
+                               token_dims=e.block_dims, attn_schedule=e.attn_schedule, dense_attn_mask=e.dense_attn_mask)
+    assert sum(st.token_dims) == st.n_tokens == 435
+    _attention_case(H, st, b=3, heads=2, pool=False, seed=23, drop_first=True)
+
+
 def test_attention_long_sequence_shape(H):
     """BASELINE config 5 shape: every modality padded to 1500 tokens (N = 6088, 96 key tiles)."""
     S = importlib.import_module("mca-paper_amd.structure")
