@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--variant", default="mca", choices=["mca", "mma", "eao"], help="eao = the paper's EAO baseline (configs/CMU_config1_EAO.yaml); default batch 8")
     ap.add_argument("--lengths", default="full", choices=["full", "uniform"])
     ap.add_argument("--p-drop", type=float, default=0.0)
+    ap.add_argument("--inputs", default="device", choices=["device", "host"],
+                    help="host: every step first copies its batch from pinned host memory (the PCIe-inclusive rate; NOT the headline value)")
     ap.add_argument("--attn", default="bf16", choices=["bf16", "fp8"], help="attention operand type (fp8: block-scaled MFMA, BASELINE configs[4])")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (small per-GPU batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -180,7 +182,18 @@ def main():
     dp = dpmod.DataParallelMCA(model) if world > 1 else None
     batch = P.data.synthetic_batch(cfg, b, seed=1234 + rank, p_drop=args.p_drop, lengths=args.lengths, device=dev)
 
+    host_batch = None
+    if args.inputs == "host":          # what the training loop's move_to(batch, device) costs per step
+        host_batch = {k: {kk: vv.cpu().pin_memory() for kk, vv in v.items()} for k, v in batch.items()}
+
+    def h2d():
+        for k, v in host_batch.items():
+            for kk, vv in v.items():
+                batch[k][kk].copy_(vv, non_blocking=True)
+
     def eager_step():
+        if host_batch is not None:
+            h2d()
         out = model(batch)
         opt.zero_grad()
         out["loss"].backward()
@@ -237,7 +250,12 @@ def main():
             # event pair brackets ONE kernel's own duration; the other steps run the overlapped production schedule
             saved = (eng.overlap_wgrad, eng.micro_batches)
             eng.overlap_wgrad, eng.micro_batches = False, 1
-        loss = graphed.step(eager=True) if (rec and graphed is not None) else step()          # (a sampled step of the replayed loop runs its body eagerly)
+        if graphed is not None:
+            if host_batch is not None:
+                h2d()
+            loss = graphed.step(batch if host_batch is not None else None, eager=rec)          # (a sampled step of the replayed loop runs its body eagerly)
+        else:
+            loss = step()
         if rec:
             hip.profile_collect()             # its timing events are resolved and released right away
             eng.overlap_wgrad, eng.micro_batches = saved
@@ -269,7 +287,7 @@ def main():
             "config": {"workload": f"synthetic {'LONG 4 x 1500 tokens' if long_seq else 'CMU 4-modality'} ({ {'mca': 'MCA fcl', 'mma': 'MMA/zorro', 'eao': 'EAO baseline, 10 passes as one block-diagonal sequence'}[args.variant]}), "
                                    f"N={N} D=512 L=5 H=8 F=88, lengths={args.lengths}, p_drop={args.p_drop}",
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
-                       "inputs": "device-resident, same batch every step", "finite_checks": "on (device flag, polled)",
+                       "inputs": "device-resident, same batch every step" if host_batch is None else "pinned host memory, copied to the device every step (PCIe-inclusive)", "finite_checks": "on (device flag, polled)",
                        "attention_operands": args.attn, "launch": ("hipGraph replay (one launch per step" + (f"; {sampled} of {args.steps} steps eager for the kernel timing)" if sampled else ")")) if use_graph else "eager",
                        "collectives": (f"{dist.get_backend()} over {dist.get_world_size()} ranks" if world > 1 else "none")},
         }
