@@ -184,6 +184,11 @@ int mca_build_keyhot(const uint8_t* keyinfo, uint16_t* khot, int batch, int nk_p
  * bitwise reproducible                                                                            */
 int mca_attn_vmean(const uint16_t* V, int64_t kv_bstride, int64_t kv_ld, float* vmean,
                    int batch, int nk, int heads, mca_stream_t stream);
+/* the same, skipping the samples whose presence bits (mca_pack_masks: bit m = modality m has a valid token) equal full_bits:
+ * with every modality present no query row of the fusion / EAO structures is fully masked, vmean[b] is never read and is
+ * left as it was                                                                                                        */
+int mca_attn_vmean_if_needed(const uint16_t* V, int64_t kv_bstride, int64_t kv_ld, float* vmean, int batch, int nk,
+                             int heads, const int32_t* present, int32_t full_bits, mca_stream_t stream);
 
 typedef struct {
   const uint16_t* q; int64_t q_bstride; int64_t q_ld;     /* q[b*q_bstride + i*q_ld + h*64 + d]   */

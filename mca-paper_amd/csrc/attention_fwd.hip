@@ -705,9 +705,11 @@ extern "C" int mca_build_keyhot(const uint8_t* keyinfo, uint16_t* khot, int batc
 // is bitwise reproducible (it is the output of every query row without a valid key: an atomic here made the whole step's
 // gradients differ from run to run at the 1e-3 level).
 __global__ __launch_bounds__(512) void vmean_kernel(const u16* __restrict__ V, int64_t bstride, int64_t ld,
-                                                     float* __restrict__ vmean, int nk, int cols) {
+                                                     float* __restrict__ vmean, int nk, int cols,
+                                                     const int32_t* __restrict__ present, int32_t full_bits) {
   __shared__ float red[64][65];
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
+  if (present && present[b] == full_bits) return;          // every modality present: no row of this sample is fully masked
   const int cl = threadIdx.x & 7, rg = threadIdx.x >> 3;
   const u16* base = V + (int64_t)b * bstride + c0 + cl * 8;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -731,6 +733,17 @@ extern "C" int mca_attn_vmean(const uint16_t* V, int64_t kv_bstride, int64_t kv_
   const int cols = heads * DH;
   if (kv_ld % 8 || kv_bstride % 8 || (uintptr_t)V % 16) return MCA_E_ALIGN;
   if (batch > 65535) return MCA_E_UNSUPPORTED;
-  hipLaunchKernelGGL(vmean_kernel, dim3(heads, batch), dim3(512), 0, as_stream(stream), V, kv_bstride, kv_ld, vmean, nk, cols);
+  hipLaunchKernelGGL(vmean_kernel, dim3(heads, batch), dim3(512), 0, as_stream(stream), V, kv_bstride, kv_ld, vmean, nk, cols,
+                     (const int32_t*)nullptr, 0);
+  return launch_status();
+}
+extern "C" int mca_attn_vmean_if_needed(const uint16_t* V, int64_t kv_bstride, int64_t kv_ld, float* vmean, int batch, int nk,
+                                        int heads, const int32_t* present, int32_t full_bits, mca_stream_t stream) {
+  if (!V || !vmean || !present || batch <= 0 || nk <= 0 || heads <= 0) return MCA_E_BADARG;
+  const int cols = heads * DH;
+  if (kv_ld % 8 || kv_bstride % 8 || (uintptr_t)V % 16) return MCA_E_ALIGN;
+  if (batch > 65535) return MCA_E_UNSUPPORTED;
+  hipLaunchKernelGGL(vmean_kernel, dim3(heads, batch), dim3(512), 0, as_stream(stream), V, kv_bstride, kv_ld, vmean, nk, cols,
+                     present, full_bits);
   return launch_status();
 }

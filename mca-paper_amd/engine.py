@@ -337,7 +337,7 @@ class FusionEngine:
         ws["pooled"] = f32(b * R, D)
         if self.eao:
             ws["seg_counts"] = torch.zeros(b, R, dtype=torch.int32, device=dev)
-        ws["vmean"], ws["dvmean"], ws["delta"], ws["delta_p"] = f32(b, D), f32(b, D), f32(b, H, N), f32(b, H, R)
+        ws["vmean"], ws["dvmean"], ws["delta"], ws["delta_p"] = torch.zeros(b, D, dtype=torch.float32, device=dev), f32(b, D), f32(b, H, N), f32(b, H, R)
         ws["keyinfo"], ws["kflags"] = u8(b, self.nk_pad), u8(b, (N + 63) // 64)
         ws["khot"] = bf(b, self.nk_pad, 16) if self.mask_mfma else None
         ws["padding"] = u8(b, N)
@@ -447,7 +447,12 @@ class FusionEngine:
         a.batch, a.heads, a.nq, a.nk, a.nk_pad = b, self.H, nq, N, self.nk_pad
         a.n_qtiles, a.n_ktiles, a.scale, a.flags = sched.s.n_q, sched.s.n_k, self.scale, self.attn_flags
         a.khot = ws["khot"].data_ptr() if ws.get("khot") is not None else None
-        call("mca_attn_vmean", a.v, a.kv_bstride, a.kv_ld, ws["vmean"].data_ptr(), b, N, self.H, stream_ptr())
+        # mean(V) is the output of fully masked rows only: samples with every modality present have none and are skipped
+        if ws.get("present_cur") is not None:
+            call("mca_attn_vmean_if_needed", a.v, a.kv_bstride, a.kv_ld, ws["vmean"].data_ptr(), b, N, self.H, ptr(ws["present_cur"]),
+                 (1 << self.M) - 1, stream_ptr())
+        else:
+            call("mca_attn_vmean", a.v, a.kv_bstride, a.kv_ld, ws["vmean"].data_ptr(), b, N, self.H, stream_ptr())
         hip.set_tag("pool" if nq != N else "layer")
         if self.attn_dtype == "fp8" and nq == N:
             f = self._fp8_operands(ws, b)

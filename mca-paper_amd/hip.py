@@ -138,6 +138,7 @@ SIGNATURES = {
     "mca_pack_masks": (_I, [_P, _P, _P, _P]),
     "mca_build_keyinfo": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "mca_attn_vmean": (_I, [_P, _I64, _I64, _P, _I, _I, _I, _P]),
+    "mca_attn_vmean_if_needed": (_I, [_P, _I64, _I64, _P, _I, _I, _I, _P, _I, _P]),
     "mca_attn_fwd": (_I, [C.POINTER(AttnFwdArgs), _P]),
     "mca_attn_quant_mxfp8": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, C.POINTER(AttnFp8Operands), _I, _I, _I, _P]),
     "mca_attn_fwd_fp8": (_I, [C.POINTER(AttnFwdArgs), C.POINTER(AttnFp8Operands), _P]),
