@@ -272,6 +272,10 @@ def main():
         dt = float(t)
     eng.assert_finite()                        # the device flag of the last step (blocking read, outside the timed region)
     assert bool(torch.isfinite(loss)), "non-finite loss in the timed region"
+    # a step whose gradients blew up is not a measurement (a mis-ordered memset node in the captured graph once left the loss
+    # plausible and every gradient at 1e28: DESIGN.md section 5)
+    gmax = float(eng.gflat.abs().max())
+    assert gmax == gmax and gmax < 1e6, f"gradients of the last timed step are not sane (max |g| = {gmax})"
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3

@@ -166,6 +166,9 @@ int mca_pack_masks(const mca_pack_masks_args* args, uint8_t* padding, int32_t* p
  * flag word, reads it once per step and passes it to mca_adamw_step as skip_flag.                                       */
 typedef struct { const float* p[MCA_MAX_MODALITIES]; int64_t n[MCA_MAX_MODALITIES]; int32_t count, pad_; } mca_finite_args;
 int mca_nonfinite_flag(const mca_finite_args* args, int32_t* flag, int bit, mca_stream_t stream);
+/* *host_pinned = *flag, by a kernel (host_pinned: pinned, device-visible host memory): the host polls it after an event,
+ * no copy node in a captured step                                                                                        */
+int mca_flag_to_host(const int32_t* flag, int32_t* host_pinned, mca_stream_t stream);
 
 /* keyinfo[b, nk_pad] = padded ? 31 : kgroup[j]; entries >= nk are 31.
  * ktile_flags[b, n_ktiles] = 0 no valid key in the 64-key tile, 1 mixed, 2 all valid.

@@ -452,12 +452,19 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restric
     __syncthreads();
   }
 }
+// (a kernel, not hipMemsetAsync: as a memset NODE of a captured step the zeroing was not ordered against the kernels around it
+// when the captured graph was a single chain - the whole backward then started from a dvmean full of stale sums)
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
 extern "C" int mca_attn_bwd_prep(const uint16_t* o, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld,
                                  const float* lse, float* delta, float* dvmean, int batch, int heads, int nq, int nk,
                                  mca_stream_t stream) {
   if (!o || !d_o || !lse || !delta || !dvmean || batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0) return MCA_E_BADARG;
   if (o_ld % 8 || o_bstride % 8 || (uintptr_t)o % 16 || (uintptr_t)d_o % 16) return MCA_E_ALIGN;
-  if (hipMemsetAsync(dvmean, 0, (size_t)batch * heads * DH * sizeof(float), as_stream(stream)) != hipSuccess) return MCA_E_LAUNCH;
+  const int64_t nz = (int64_t)batch * heads * DH;
+  hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, as_stream(stream), dvmean, nz);
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((nq + PREP_ROWS - 1) / PREP_ROWS, batch), dim3(256), 0, as_stream(stream), o, d_o,
                      o_bstride, o_ld, lse, delta, dvmean, heads, nq, 1.f / (float)nk);
   return launch_status();

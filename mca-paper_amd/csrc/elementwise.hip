@@ -722,6 +722,16 @@ __global__ __launch_bounds__(256) void nonfinite_flag_kernel(mca_finite_args a, 
     bad |= (__float_as_uint(p[i]) & 0x7f800000u) == 0x7f800000u;
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, bit);
 }
+// the flag word, written by a kernel straight into PINNED host memory (device-visible): a copy NODE of a captured step is not
+// ordered reliably against the kernels around it (see mca_attn_bwd_prep), a kernel is
+__global__ void flag_to_host_kernel(const int32_t* __restrict__ flag, volatile int32_t* __restrict__ host_word) {
+  if (threadIdx.x == 0) { *host_word = *flag; __threadfence_system(); }
+}
+extern "C" int mca_flag_to_host(const int32_t* flag, int32_t* host_pinned, mca_stream_t stream) {
+  if (!flag || !host_pinned) return MCA_E_BADARG;
+  hipLaunchKernelGGL(flag_to_host_kernel, dim3(1), dim3(64), 0, as_stream(stream), flag, host_pinned);
+  return launch_status();
+}
 extern "C" int mca_nonfinite_flag(const mca_finite_args* args, int32_t* flag, int bit, mca_stream_t stream) {
   if (!args || !flag || args->count <= 0 || args->count > MCA_MAX_MODALITIES || bit == 0) return MCA_E_BADARG;
   int64_t nmax = 0;

@@ -984,7 +984,7 @@ class FusionEngine:
         slots = m.output_slots()
         if self.check_finite:
             self._flag_tensors([pooled], 2)
-            self._flag_host.copy_(self.finite_flag, non_blocking=True)
+            call("mca_flag_to_host", ptr(self.finite_flag), self._flag_host.data_ptr(), stream_ptr())          # (a kernel, not a copy node)
             if not torch.cuda.is_current_stream_capturing():          # (a captured step: graph.GraphedStep records it after the replay)
                 self._flag_event = torch.cuda.Event()
                 self._flag_event.record()
@@ -1070,7 +1070,10 @@ def _loss_forward(engine, pooled, present):
     else:
         pooled_all, present_all, row0 = pooled, present, 0
     res = engine.loss_fwd_bwd(pooled_all.contiguous(), present_all.contiguous(), b, row0)
-    return pooled.clone(), res["term_loss"], res["loss"], res
+    pooled_out = torch.empty_like(pooled)          # the embeddings handed to the caller: copied by a kernel (no copy node in a captured step)
+    flat_in, flat_out = pooled.reshape(-1, pooled.shape[-1]), pooled_out.view(-1, pooled.shape[-1])
+    call("mca_rows_copy_add", ptr(flat_in), 0, ptr(flat_out), 0, flat_in.shape[0], flat_in.shape[1], 1, 0, stream_ptr())
+    return pooled_out, res["term_loss"], res["loss"], res
 
 
 class _MCAStep(torch.autograd.Function):

@@ -113,6 +113,7 @@ _P, _I64, _I, _F = C.c_void_p, C.c_int64, C.c_int, C.c_float
 # name -> (restype, argtypes).  Must list EVERY symbol include/mca_hip.h declares (tests check this).
 SIGNATURES = {
     "mca_version": (C.c_char_p, []),
+    "mca_flag_to_host": (_I, [_P, _P, _P]),
     "mca_build_keyhot": (_I, [_P, _P, _I, _I, _P]),
     "mca_rows_copy_add": (_I, [_P, _I64, _P, _I64, _I64, _I, _I, _I, _P]),
     "mca_segment_mean_fwd": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),

@@ -317,6 +317,39 @@ def test_long_config_at_batch_128(P):
         assert torch.equal(ps[i], pb[i])
 
 
+def test_graphed_step_at_cmu_size_matches_eager(P):
+    """The replayed step at the CMU shape (D = 512: fused LayerNorm-residual GEMMs, grouped weight gradients, mask product; the
+    captured graph is ONE chain, no side stream) against the eager loop, four optimizer steps: loss and global gradient norm
+    of every step.  This is the test that caught a `hipMemsetAsync` inside the captured region (the zeroing of dvmean in
+    mca_attn_bwd_prep): as a memset node of a single-chain graph it was not ordered against the kernels around it, and from
+    the second replay on the whole backward started from garbage while the loss still looked plausible."""
+    optim = importlib.import_module("mca-paper_amd.optim")
+    graph = importlib.import_module("mca-paper_amd.graph")
+    cfg = P.config.cmu_model_config(batch_size=2)
+    batch = P.data.synthetic_batch(cfg, 2, seed=1234, lengths="uniform", p_drop=0.3, device="cuda")
+    hist = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(43)
+        m = P.MCA(**cfg).cuda(); m.engine.check_finite = "deferred"
+        opt = optim.FusedAdamW(m, lr=1e-5)
+        g = graph.GraphedStep(m, opt, batch, clip=2.0) if mode == "graph" else None
+        rows = []
+        for _ in range(4):
+            if g is None:
+                out = m(batch); opt.zero_grad(); out["loss"].backward(); gn = optim.clip_grad_norm_(m, 2.0); opt.step()
+                rows.append((float(out["loss"].detach()), float(gn)))
+            else:
+                loss = g.step(batch)
+                rows.append((float(loss), float(g.gnorm)))
+            emb = (g.out if g is not None else out)[m.modality_types[0]]
+            assert bool(torch.isfinite(emb).all())
+        torch.cuda.synchronize(); m.engine.assert_finite()
+        assert bool(torch.isfinite(m.engine.gflat).all()) and float(m.engine.gflat.abs().max()) < 1e4
+        hist[mode] = rows
+    for (le, ge), (lg, gg) in zip(hist["eager"], hist["graph"]):
+        assert abs(le - lg) <= 5e-3 * abs(le) and abs(ge - gg) <= 2e-2 * ge, hist
+
+
 # ------------------------------------------------------------------------------------------------ the training script
 @pytest.mark.parametrize("variant,graph", [("mca", False), ("mca", True), ("eao", False)])
 def test_train_script_end_to_end(P, tmp_path, variant, graph):
