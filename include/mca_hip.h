@@ -292,6 +292,9 @@ typedef struct {
   /* optional, both or neither: the mask as a matrix product (see mca_build_keyhot).  qblk[nq, 16] bf16 is the static query
    * side: qblk[i][g] = bit g of qmask[i] ? 0 : -32768 for g < 15, qblk[i][15] = -32768                                  */
   const uint16_t* khot; const uint16_t* qblk;
+  /* keys per workgroup of the dkv pass: 0 / 256 (8 wavefronts) or 128 (4 wavefronts, two workgroups per CU: a few % faster
+   * for short sequences, slower for long ones); k_wg / k_qt / n_kblocks256 describe key blocks of THIS size              */
+  int kblock_keys;
 } mca_attn_bwd2_args;
 int mca_attn_bwd_dq(const mca_attn_bwd2_args* args, mca_stream_t stream);
 int mca_attn_bwd_dkv(const mca_attn_bwd2_args* args, mca_stream_t stream);

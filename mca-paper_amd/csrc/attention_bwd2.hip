@@ -20,7 +20,9 @@
 #define AQ 128      // dq pass: query rows per workgroup
 #define AK 64       // dq pass: keys per tile
 #define MAX_KTILES 512
-#define BKEYS 256   // dkv pass: keys per workgroup
+// dkv pass: W wavefronts per workgroup, 32 keys each: W = 8 (256 keys, one workgroup per CU) or W = 4 (128 keys, two
+// independent workgroups per CU, free to drift apart: 3 % faster at N = 2538, equal at N = 6088); chosen by the caller through
+// mca_attn_bwd2_args.kblock_keys
 #define BQ 64       // dkv pass: query rows per step
 #define MAX_QTILES 2048
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
@@ -355,8 +357,9 @@ extern "C" int mca_attn_bwd_dq(const mca_attn_bwd2_args* a, mca_stream_t stream)
 // 64-query steps the structure allows for the block; the key sits on the MFMA lane, so P and dS are directly the B operands
 // of the dV^T / dK^T products (guide, Appendix B "Attention backward").  Q / dO tiles in one LDS image for row AND column reads.
 // =====================================================================================================
-template <bool PRESCALED>
-__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a, int dbg) {
+template <bool PRESCALED, int W>
+__global__ __launch_bounds__(64 * W) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a, int dbg) {
+  constexpr int BKEYS = 32 * W, DKV_NT = 64 * W, DKV_SU = 512 / DKV_NT;
   extern __shared__ __attribute__((aligned(16))) u16 lds[];
   u16* Qs = lds;                               // 2 x 64 x 64
   u16* Os = Qs + 2 * BQ * DH;                  // 2 x 64 x 64   (dO)
@@ -421,17 +424,20 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
   const float* lse_g = a.lse + ((int64_t)b * a.heads + h) * a.nq;
   const float* delta_g = a.delta + ((int64_t)b * a.heads + h) * a.nq;
 
-  const int srow = tid >> 3, sc = tid & 7;
-  bf16x8 stage_q, stage_o;
+  const int srow = tid >> 3, sc = tid & 7;          // (+ 64 * DKV_NT / 512 rows per further piece)
+  bf16x8 stage_q[DKV_SU], stage_o[DKV_SU];
   uint4 stage_b = make_uint4(0, 0, 0, 0);
   float stage_c = 0.f;
   bool stage_oob = false;
   const int cwhich = tid >> 6 < 2 ? tid >> 6 : 2, crow = tid & 63;
   const float* cbase = cwhich == 0 ? lse_g : (cwhich == 1 ? delta_g : reinterpret_cast<const float*>(a.qmask));
   auto gload = [&](int qt) {
-    int q = qt * BQ + srow; if (q > a.nq - 1) q = a.nq - 1;
-    stage_q = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)q * a.q_ld + sc * 8);
-    stage_o = *reinterpret_cast<const bf16x8*>(obase + (int64_t)q * a.o_ld + sc * 8);
+#pragma unroll
+    for (int u = 0; u < DKV_SU; u++) {
+      int q = qt * BQ + srow + u * (DKV_NT / 8); if (q > a.nq - 1) q = a.nq - 1;
+      stage_q[u] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)q * a.q_ld + sc * 8);
+      stage_o[u] = *reinterpret_cast<const bf16x8*>(obase + (int64_t)q * a.o_ld + sc * 8);
+    }
     int qq = qt * BQ + crow;
     stage_oob = qq >= a.nq;
     if (qq > a.nq - 1) qq = a.nq - 1;
@@ -442,8 +448,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
     }
   };
   auto swrite = [&](int buf) {
-    *reinterpret_cast<bf16x8*>(Qs + buf * BQ * DH + rt_off(srow, sc)) = stage_q;
-    *reinterpret_cast<bf16x8*>(Os + buf * BQ * DH + rt_off(srow, sc)) = stage_o;
+#pragma unroll
+    for (int u = 0; u < DKV_SU; u++) {
+      *reinterpret_cast<bf16x8*>(Qs + buf * BQ * DH + rt_off(srow + u * (DKV_NT / 8), sc)) = stage_q[u];
+      *reinterpret_cast<bf16x8*>(Os + buf * BQ * DH + rt_off(srow + u * (DKV_NT / 8), sc)) = stage_o[u];
+    }
     if (tid < 192) {          // rows past nq contribute nothing: lse = +inf (P = 0), delta = 0, qmask = 0
       float v = stage_oob ? (cwhich == 0 ? INFINITY : 0.f) : stage_c;
       if (cwhich == 0) v = -v * inv_c2; else if (cwhich == 1) v = -v;
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(mca_attn_bwd2_args a,
   // every step wait for the next tile's loads it has just issued
 #pragma unroll
   for (int s4 = 0; s4 < 4; s4++) asm volatile("" :: "v"(kf[s4]), "v"(vf[s4]));
-  for (int i = tid; i < n_it; i += 512) qlist[i] = a.k_qt[it_begin + i];
+  for (int i = tid; i < n_it; i += DKV_NT) qlist[i] = a.k_qt[it_begin + i];
   if (tid < DH) dvm_s[tid] = a.dvmean[(int64_t)b * a.heads * DH + h * DH + tid];
   int buf = 0;
   if (n_it > 0) swrite(0);
@@ -607,6 +616,8 @@ extern "C" int mca_attn_bwd_dkv(const mca_attn_bwd2_args* a, mca_stream_t stream
   const int rc = check_bwd2(a);
   if (rc != MCA_OK) return rc;
   if (!a->dk || !a->dv || !a->dvmean || !a->k_wg || !a->k_qt) return MCA_E_BADARG;
+  const int BKEYS = a->kblock_keys ? a->kblock_keys : 256;
+  if (BKEYS != 256 && BKEYS != 128) return MCA_E_UNSUPPORTED;
   if (a->n_qtiles64 != (a->nq + BQ - 1) / BQ || a->n_kblocks256 != (a->nk + BKEYS - 1) / BKEYS) return MCA_E_BADARG;
   if (a->nk_pad < a->n_kblocks256 * BKEYS) return MCA_E_BADARG;
   if (a->dkv_ld % 4 || a->dkv_bstride % 4 || (uintptr_t)a->dk % 8 || (uintptr_t)a->dv % 8 || (uintptr_t)a->k_wg % 16) return MCA_E_ALIGN;
@@ -615,13 +626,18 @@ extern "C" int mca_attn_bwd_dkv(const mca_attn_bwd2_args* a, mca_stream_t stream
   if ((uintptr_t)a->khot % 16 || (uintptr_t)a->qblk % 16) return MCA_E_ALIGN;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES) != hipSuccess)
       return MCA_E_LAUNCH;
     attr_set = true;
   }
   const dim3 grid(a->n_kblocks256, a->heads, a->batch);
-  if (a->flags & MCA_ATTN_Q_PRESCALED) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(512), DKV_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
-  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(512), DKV_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
+  const bool pre = (a->flags & MCA_ATTN_Q_PRESCALED) != 0;
+#define DKV_LAUNCH(P, W) hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, W>), grid, dim3(64 * W), DKV_LDS_BYTES, as_stream(stream), *a, mca_knobs[9])
+  if (BKEYS == 256) { if (pre) DKV_LAUNCH(true, 8); else DKV_LAUNCH(false, 8); }
+  else { if (pre) DKV_LAUNCH(true, 4); else DKV_LAUNCH(false, 4); }
+#undef DKV_LAUNCH
   return launch_status();
 }

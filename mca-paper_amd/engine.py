@@ -190,11 +190,17 @@ class FusionEngine:
         self.qblk_attn, self.qblk_pool = qblk_of(st.qmask_attn), qblk_of(st.qmask_pool)
         self.sched_attn_f = _Sched(st.attn_schedule(FWD_BQ, FWD_BK), dev)
         self.sched_attn_b = _Sched(st.attn_schedule(BWD_BQ, BWD_BK), dev)
+        # key-block size of the dkv pass: 128 (4 wavefronts, two independent workgroups per CU) is 3 % faster than 256 (8 wavefronts,
+        # one workgroup per CU) at N = 2538 and equal at N = 6088; MCA_DKV_KEYS=256 for A/B
+        dkv_keys = int(os.environ.get("MCA_DKV_KEYS", "128"))
+        self.dkv_keys = dkv_keys
+        self.sched_attn_b2 = self.sched_attn_b if dkv_keys == BWD_BK else _Sched(st.attn_schedule(BWD_BQ, dkv_keys), dev)
         if self.eao:
             self.seg_start = _dev(st.seg_start, dev)
         else:
             self.sched_pool_f = _Sched(st.pool_schedule(FWD_BQ, FWD_BK), dev)
             self.sched_pool_b = _Sched(st.pool_schedule(BWD_BQ, BWD_BK), dev)
+            self.sched_pool_b2 = self.sched_pool_b if dkv_keys == BWD_BK else _Sched(st.pool_schedule(BWD_BQ, dkv_keys), dev)
         terms = self.model.loss_terms
         arr = (LossTerm * len(terms))()
         for i, t in enumerate(terms):
@@ -484,6 +490,7 @@ class FusionEngine:
         a.batch, a.heads, a.nq, a.nk, a.nk_pad, a.scale, a.flags = b, self.H, nq, N, self.nk_pad, self.scale, self.attn_flags
         if ws.get("khot") is not None:
             a.khot, a.qblk = ws["khot"].data_ptr(), (self.qblk_attn if qmask is self.qmask_attn else self.qblk_pool).data_ptr()
+        a.kblock_keys = sched_b.s.bk
         pairs = sched_b.s.allowed_pairs
         hip.set_tag("pool" if nq != N else "layer")
         # algorithmic flops of the whole backward (2 x forward) split 3 : 5 over the passes by their share of the five
@@ -787,7 +794,7 @@ class FusionEngine:
         if self.attn_bwd_two_pass:
             self._attn_bwd2(ws["qp"].data_ptr(), 0, D, ws["kvp"], 0, D, 2 * D, ws["op"], ws["dop"], ws["lse_p"], ws["delta_p"],
                             ws["dqp32"].data_ptr(), R * D, D, True, ws["dkvp"], 0, D, 2 * D, self.qmask_pool, self.sched_pool_f,
-                            self.sched_pool_b, ws, b, R)
+                            self.sched_pool_b2, ws, b, R)
         else:
             ws["dqp32"].zero_()
             self._attn_bwd(ws["qp"].data_ptr(), 0, D, ws["kvp"], 0, D, 2 * D, ws["op"], ws["dop"], ws["lse_p"], ws["delta_p"],
@@ -853,7 +860,7 @@ class FusionEngine:
                 # dq | dk | dv land in dqkv as bf16, each element written once
                 self._attn_bwd2(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], ws["do"], a["lse"],
                                 ws["delta"], dqkv.data_ptr(), N * 3 * D, 3 * D, False, dqkv, D, 2 * D, 3 * D, self.qmask_attn,
-                                self.sched_attn_f, self.sched_attn_b, ws, b, N)
+                                self.sched_attn_f, self.sched_attn_b2, ws, b, N)
             else:
                 dq32 = ws["dq32_all"][i]
                 if not self.zero_dq_once:

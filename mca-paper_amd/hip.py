@@ -104,7 +104,7 @@ class AttnBwd2Args(C.Structure):
         ("k_wg", C.c_void_p), ("k_qt", C.c_void_p), ("n_qtiles64", C.c_int), ("n_kblocks256", C.c_int),
         ("batch", C.c_int), ("heads", C.c_int), ("nq", C.c_int), ("nk", C.c_int), ("nk_pad", C.c_int),
         ("scale", C.c_float), ("flags", C.c_int),
-        ("khot", C.c_void_p), ("qblk", C.c_void_p),
+        ("khot", C.c_void_p), ("qblk", C.c_void_p), ("kblock_keys", C.c_int),
     ]
 
 

@@ -348,6 +348,7 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first, prescaled=True, spi
     nq = len(qmask_np)
     sf = eng._Sched(st.pool_schedule(128, 64) if pool else st.attn_schedule(128, 64), dev)
     sb = eng._Sched(st.pool_schedule(64, 256) if pool else st.attn_schedule(64, 256), dev)
+    sb128 = eng._Sched(st.pool_schedule(64, 128) if pool else st.attn_schedule(64, 128), dev)          # the dkv pass's 4-wavefront form
     qmask = torch.from_numpy(qmask_np.astype(np.uint32).view(np.int32)).to(dev)
     kgroup = torch.from_numpy(st.kgroup).to(dev)
     allowed = torch.from_numpy(~(st.dense_pool_mask() if pool else st.dense_attn_mask())).to(dev)
@@ -488,6 +489,14 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first, prescaled=True, spi
         H.call("mca_attn_bwd_dkv", C.byref(a2), H.stream_ptr())
         torch.cuda.synchronize()
         assert torch.equal(dq2, dq3) and torch.equal(dkv2, dkv3)
+        # 128-key blocks (4 wavefronts per workgroup): every key sees the same query steps in the same order: the same bits
+        dkv5 = torch.zeros_like(dkv2)
+        a2.dk, a2.dv = dkv5.data_ptr() + D * 2, dkv5.data_ptr() + 2 * D * 2
+        a2.k_wg, a2.k_qt, a2.n_kblocks256, a2.kblock_keys = sb128.k_wg.data_ptr(), sb128.k_qt.data_ptr(), sb128.s.n_k, 128
+        H.call("mca_attn_bwd_dkv", C.byref(a2), H.stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(dkv2, dkv5)
+        a2.k_wg, a2.k_qt, a2.n_kblocks256, a2.kblock_keys = sb.k_wg.data_ptr(), sb.k_qt.data_ptr(), sb.s.n_k, 0
         # the mask as a matrix product (khot + qblk): allowed scores get an exact +0, blocked ones an exp2 that is exactly 0:
         # the same bits as the element-wise mask
         if int(st.kgroup.max()) <= 14:

@@ -394,7 +394,7 @@ def test_attention_backward_bitwise_deterministic_at_cmu_size(P, variant):
         a["dqkv"].fill_(7.0)
         eng._attn_bwd2(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], ws["do"], a["lse"], ws["delta"],
                        a["dqkv"].data_ptr(), N * 3 * D, 3 * D, False, a["dqkv"], D, 2 * D, 3 * D, eng.qmask_attn, eng.sched_attn_f,
-                       eng.sched_attn_b, ws, b, N)
+                       eng.sched_attn_b2, ws, b, N)
         torch.cuda.synchronize()
         snaps.append(a["dqkv"].clone())
     assert torch.isfinite(snaps[0].float()).all()

@@ -28,7 +28,7 @@ def fwd(): eng._attn_fwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D,
 def bwd():
     if eng.attn_bwd_two_pass:
         eng._attn_bwd2(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], ws["do"], a["lse"], ws["delta"], a["dqkv"].data_ptr(), N*3*D, 3*D, False,
-                       a["dqkv"], D, 2*D, 3*D, eng.qmask_attn, eng.sched_attn_f, eng.sched_attn_b, ws, b, N)
+                       a["dqkv"], D, 2*D, 3*D, eng.qmask_attn, eng.sched_attn_f, eng.sched_attn_b2, ws, b, N)
     else:
         ws["dq32"].zero_()
         eng._attn_bwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], ws["do"], a["lse"], ws["delta"], ws["dq32"], N*D, a["dqkv"], D, 2*D, 3*D, eng.qmask_attn, eng.sched_attn_b, ws, b, N)
