@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(mca_attn_bwd2_args 
         }
     }
     // dS^T = P^T o (dP^T - delta), packed as the B operand of the dQ^T product
-    bf16x8 dsb[2][2];
+    u32x4v dsw[2][2];          // (one packed conversion per operand dword, no re-packing)
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
@@ -270,8 +270,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(mca_attn_bwd2_args 
         for (int j = 0; j < 8; j += 2) {
           const float d0 = __builtin_amdgcn_exp2f(s[kb][8 * sp + j]) * dp[kb][8 * sp + j];
           const float d1 = __builtin_amdgcn_exp2f(s[kb][8 * sp + j + 1]) * dp[kb][8 * sp + j + 1];
-          const uint32_t pk = pack2bf(d0, d1);
-          dsb[kb][sp][j] = (short)(pk & 0xffffu); dsb[kb][sp][j + 1] = (short)(pk >> 16);
+          dsw[kb][sp][j >> 1] = pack2bf_pk(d0, d1);
         }
     // dQ^T[d][q] += K^T[d][key] dS^T[key][q]: A = K^T by transposed reads of the K image (element j of k-step sp carries
     // key 16sp + 8(j>>2) + 4lh + (j&3) of the 32-key block, the accumulator-as-operand order)
@@ -290,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(mca_attn_bwd2_args 
 #pragma unroll
             for (int e = 0; e < 4; e++) ktf[4 * t + e] = k4[e];
           }
-          dq[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsb[kb][sp], dq[n], 0, 0, 0);
+          dq[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, *reinterpret_cast<const bf16x8*>(&dsw[kb][sp]), dq[n], 0, 0, 0);
         }
 
     if (nit < it_end) swrite(buf ^ 1);
@@ -524,7 +523,9 @@ __global__ __launch_bounds__(64 * W) void attn_bwd_dkv_kernel(mca_attn_bwd2_args
 #undef KV_S
 #undef KV_P
       }
-      bf16x8 pb[2], sb[2];
+      // P and dS as the B operands of the products: the packed conversion's dword IS two adjacent operand elements (splitting
+      // it into shorts and re-packing cost a v_perm per dword)
+      u32x4v pbw[2], sbw[2];
       const bool clean = full && wave_keys_ok;
       if (!clean && use_hot) {          // blocked (query, key) pairs: -32768 on top of the score, exp2 is exactly 0
         const bf16x8 qbf = *reinterpret_cast<const bf16x8*>(qblk_s + buf * (BQ * 16) + (sub * 32 + l31) * 16 + 8 * lh);
@@ -538,9 +539,9 @@ __global__ __launch_bounds__(64 * W) void attn_bwd_dkv_kernel(mca_attn_bwd2_args
 #else
           const float p0 = __builtin_amdgcn_exp2f(PRESCALED ? s[r] : s[r] * c2), p1 = __builtin_amdgcn_exp2f(PRESCALED ? s[r + 1] : s[r + 1] * c2);
 #endif
-          const uint32_t pp = pack2bf(p0, p1), ss = pack2bf(p0 * dp[r], p1 * dp[r + 1]);
-          pb[r >> 3][r & 7] = (short)(pp & 0xffffu); pb[r >> 3][(r & 7) + 1] = (short)(pp >> 16);
-          sb[r >> 3][r & 7] = (short)(ss & 0xffffu); sb[r >> 3][(r & 7) + 1] = (short)(ss >> 16);
+          const uint32_t pp = pack2bf_pk(p0, p1), ss = pack2bf_pk(p0 * dp[r], p1 * dp[r + 1]);
+          pbw[r >> 3][(r & 7) >> 1] = pp;
+          sbw[r >> 3][(r & 7) >> 1] = ss;
         }
       } else {
 #pragma unroll
@@ -552,15 +553,15 @@ __global__ __launch_bounds__(64 * W) void attn_bwd_dkv_kernel(mca_attn_bwd2_args
             const uint32_t q0 = full ? 0xffffffffu : __float_as_uint(qm4[e]), q1 = full ? 0xffffffffu : __float_as_uint(qm4[e + 1]);
             float p0 = __builtin_amdgcn_exp2f(PRESCALED ? s[r] : s[r] * c2), p1 = __builtin_amdgcn_exp2f(PRESCALED ? s[r + 1] : s[r + 1] * c2);
             p0 = (q0 & keybit) ? p0 : 0.f; p1 = (q1 & keybit) ? p1 : 0.f;
-            const uint32_t pp = pack2bf(p0, p1), ss = pack2bf(p0 * dp[r], p1 * dp[r + 1]);
-            pb[r >> 3][r & 7] = (short)(pp & 0xffffu); pb[r >> 3][(r & 7) + 1] = (short)(pp >> 16);
-            sb[r >> 3][r & 7] = (short)(ss & 0xffffu); sb[r >> 3][(r & 7) + 1] = (short)(ss >> 16);
+            const uint32_t pp = pack2bf_pk(p0, p1), ss = pack2bf_pk(p0 * dp[r], p1 * dp[r + 1]);
+            pbw[r >> 3][(r & 7) >> 1] = pp;
+            sbw[r >> 3][(r & 7) >> 1] = ss;
           }
         }
       }
       // dV^T += dO^T P ; dK^T += Q^T dS   (element j of k-step sp carries q = 16sp + 8(j>>2) + 4lh + (j&3))
 #if DKV_ABL & 2
-      asm volatile("" :: "v"(pb[0]), "v"(pb[1]), "v"(sb[0]), "v"(sb[1]));
+      asm volatile("" :: "v"(pbw[0]), "v"(pbw[1]), "v"(sbw[0]), "v"(sbw[1]));
       if (false)
 #endif
 #pragma unroll
@@ -581,8 +582,8 @@ __global__ __launch_bounds__(64 * W) void attn_bwd_dkv_kernel(mca_attn_bwd2_args
 #pragma unroll
             for (int e = 0; e < 4; e++) { ot[4 * t + e] = o4[e]; qtf[4 * t + e] = q4[e]; }
           }
-          dv[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot, pb[sp], dv[n], 0, 0, 0);
-          dk[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, sb[sp], dk[n], 0, 0, 0);
+          dv[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot, *reinterpret_cast<const bf16x8*>(&pbw[sp]), dv[n], 0, 0, 0);
+          dk[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, *reinterpret_cast<const bf16x8*>(&sbw[sp]), dk[n], 0, 0, 0);
         }
     }
     if (it + 1 < n_it) swrite(buf ^ 1);

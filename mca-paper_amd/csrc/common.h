@@ -21,6 +21,14 @@ __device__ __forceinline__ u16 f2bf(float f) {
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
+// the same value as ONE v_cvt_pk_bf16_f32 whatever the use of the result (pack2bf relies on the compiler re-fusing two scalar
+// conversions, which it does not do when the dword is used as a dword)
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2bf_pk(float lo, float hi) {
+  const bf16x2v h = __builtin_convertvector(f32x2v{lo, hi}, bf16x2v);
+  return *reinterpret_cast<const uint32_t*>(&h);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
