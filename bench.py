@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-protocol", default="short", choices=["short", "full"])
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"], help="auto: hipGraph replay on one GPU, eager under data parallelism")
+    ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"], help="auto: hipGraph replay (one graph on one GPU; graph segments cut at the eager collectives under data parallelism); falls back to the eager loop if the capture fails")
     ap.add_argument("--sample-every", type=int, default=20, help="record per-kernel HIP events on every n-th timed step (a sampled step runs its kernels one at a time and costs ~1.3 steps)")
     args = ap.parse_args()
 
@@ -186,15 +186,24 @@ def main():
     if args.inputs == "host":          # what the training loop's move_to(batch, device) costs per step
         host_batch = {k: {kk: vv.cpu().pin_memory() for kk, vv in v.items()} for k, v in batch.items()}
 
+    # --inputs host: the training loop's input pipeline (data.DevicePrefetcher: the pinned batch is copied to the device one step
+    # ahead on a copy stream, double-buffered); MCA_PREFETCH=0 = the reference's synchronous move_to in the compute stream
+    feed = None
+    if host_batch is not None and os.environ.get("MCA_PREFETCH", "1") != "0":
+        import itertools
+        feed = P.data.DevicePrefetcher(itertools.repeat(host_batch), dev)
+
     def h2d():
+        if feed is not None:
+            return next(feed)
         for k, v in host_batch.items():
             for kk, vv in v.items():
                 batch[k][kk].copy_(vv, non_blocking=True)
+        return batch
 
     def eager_step():
-        if host_batch is not None:
-            h2d()
-        out = model(batch)
+        cur = h2d() if host_batch is not None else batch
+        out = model(cur)
         opt.zero_grad()
         out["loss"].backward()
         if dp is not None:
@@ -207,19 +216,25 @@ def main():
     step = eager_step
     # launch mode: "auto" = one hipGraph replay per step on a single GPU (the eager step issues ~330 launches from Python: on a
     # loaded host that is longer than the GPU needs for them: 23.8-25.0 ms eager against 21.5-21.9 ms replayed on the same box),
-    # eager under data parallelism (the RCCL collectives are not captured)
-    use_graph = args.graph or (args.launch == "graph") or (args.launch == "auto" and world == 1)
-    if use_graph and world > 1:
-        raise SystemExit("--launch graph needs --gpus 1 (data-parallel collectives are not captured)")
+    # also under data parallelism (segments cut at the collectives, which stay eager RCCL calls)
+    # under data parallelism the replayed step is a chain of graph segments cut at the collectives (graph.GraphedStep)
+    use_graph = args.graph or (args.launch == "graph") or args.launch == "auto"
     graphed = None
     if use_graph:
+        err = None
         try:
             graphed = importlib.import_module("mca-paper_amd.graph").GraphedStep(model, opt, batch, clip=2.0, dp=dp)
-            step = graphed.step
         except Exception as e:          # auto mode only: a failed capture must not cost the measurement
             if args.launch != "auto" or args.graph:
                 raise
-            print(f"bench: hipGraph capture failed ({type(e).__name__}: {e}); running the eager loop", file=sys.stderr, flush=True)
+            err = e
+        ok = torch.tensor([0 if err is not None else 1], device=dev, dtype=torch.int32)
+        if world > 1:                   # every rank takes the same path
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok):
+            step = graphed.step
+        else:
+            print(f"bench: hipGraph capture failed on rank {rank} ({type(err).__name__ if err else 'another rank'}: {err}); running the eager loop", file=sys.stderr, flush=True)
             use_graph, graphed = False, None
             opt.hyper_external = False
 
@@ -251,9 +266,7 @@ def main():
             saved = (eng.overlap_wgrad, eng.micro_batches)
             eng.overlap_wgrad, eng.micro_batches = False, 1
         if graphed is not None:
-            if host_batch is not None:
-                h2d()
-            loss = graphed.step(batch if host_batch is not None else None, eager=rec)          # (a sampled step of the replayed loop runs its body eagerly)
+            loss = graphed.step(h2d() if host_batch is not None else None, eager=rec)          # (a sampled step of the replayed loop runs its body eagerly)
         else:
             loss = step()
         if rec:
@@ -291,8 +304,8 @@ def main():
             "config": {"workload": f"synthetic {'LONG 4 x 1500 tokens' if long_seq else 'CMU 4-modality'} ({ {'mca': 'MCA fcl', 'mma': 'MMA/zorro', 'eao': 'EAO baseline, 10 passes as one block-diagonal sequence'}[args.variant]}), "
                                    f"N={N} D=512 L=5 H=8 F=88, lengths={args.lengths}, p_drop={args.p_drop}",
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
-                       "inputs": "device-resident, same batch every step" if host_batch is None else "pinned host memory, copied to the device every step (PCIe-inclusive)", "finite_checks": "on (device flag, polled)",
-                       "attention_operands": args.attn, "launch": ("hipGraph replay (one launch per step" + (f"; {sampled} of {args.steps} steps eager for the kernel timing)" if sampled else ")")) if use_graph else "eager",
+                       "inputs": "device-resident, same batch every step" if host_batch is None else ("pinned host memory, copied to the device every step (PCIe-inclusive" + (", one step ahead on a copy stream)" if feed is not None else ", in the compute stream)")), "finite_checks": "on (device flag, polled)",
+                       "attention_operands": args.attn, "launch": ("hipGraph replay (" + ("one launch per step" if world == 1 else f"{sum(1 for it in graphed.program if isinstance(it, torch.cuda.CUDAGraph))} graph segments cut at {sum(1 for it in graphed.program if not isinstance(it, torch.cuda.CUDAGraph))} eager collectives per step") + (f"; {sampled} of {args.steps} steps eager for the kernel timing)" if sampled else ")")) if use_graph else "eager",
                        "collectives": (f"{dist.get_backend()} over {dist.get_world_size()} ranks" if world > 1 else "none")},
         }
         if gf:

@@ -1,8 +1,14 @@
 """Drop-in module with the reference's name: ``from encoders import encoders_dict, collators, MultimodalCollator``
-(reference: encoders.py:277-283,367-403).  Implementation: mca-paper_amd/encoders.py."""
+(reference: encoders.py:277-283,367-403; train_accel_gpu.py:13).  Implementation: mca-paper_amd/encoders.py.
+``TokenEncoder`` / ``ContinuousValueEncoder`` are the parameter holders of the tabular encoder under the reference's names
+(encoders.py:17-72)."""
 import importlib as _il
 
 _e = _il.import_module("mca-paper_amd.encoders")
 encoders_dict, collators, MultimodalCollator = _e.encoders_dict, _e.collators, _e.MultimodalCollator
 EmbeddedSequenceEncoder, TabularEncoder, PositionalEncoder = _e.EmbeddedSequenceEncoder, _e.TabularEncoder, _e.PositionalEncoder
+TokenEncoder, ContinuousValueEncoder = _e._TokenTable, _e._ValueMLP
 SequenceCollator, EmbeddedSequenceCollator, MatrixCollator = _e.SequenceCollator, _e.EmbeddedSequenceCollator, _e.MatrixCollator
+
+__all__ = ["encoders_dict", "collators", "MultimodalCollator", "EmbeddedSequenceEncoder", "TabularEncoder", "PositionalEncoder",
+           "TokenEncoder", "ContinuousValueEncoder", "SequenceCollator", "EmbeddedSequenceCollator", "MatrixCollator"]

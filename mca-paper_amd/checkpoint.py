@@ -66,7 +66,7 @@ def load_model(model, path: str, strict: bool = True):
     return missing, unexpected
 
 
-def _optimizer_bin(model, optimizer, step: int) -> dict:
+def _optimizer_bin(model, optimizer, step: int, lr: Optional[float] = None) -> dict:
     """``torch.optim.AdamW.state_dict()`` as Accelerate pickles it into optimizer.bin: state index i = i-th entry of
     ``model.parameters()`` (the module tree, hence that order, is the reference's)."""
     eng = model.engine
@@ -79,7 +79,7 @@ def _optimizer_bin(model, optimizer, step: int) -> dict:
                     "exp_avg": optimizer.exp_avg[o:o + n].view(p.shape).detach().cpu().clone(),
                     "exp_avg_sq": optimizer.exp_avg_sq[o:o + n].view(p.shape).detach().cpu().clone()}
     g = optimizer.param_groups[0]
-    group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": g["weight_decay"], "amsgrad": False,
+    group = {"lr": g["lr"] if lr is None else lr, "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": g["weight_decay"], "amsgrad": False,
              "foreach": None, "maximize": False, "capturable": False, "differentiable": False, "fused": None,
              "params": list(range(len(params)))}
     if "initial_lr" in g:
@@ -115,14 +115,18 @@ def _load_optimizer_bin(model, optimizer, sd: dict):
             optimizer.param_groups[0][k] = tuple(g[k]) if k == "betas" else g[k]
 
 
-def save_state(output_dir: str, model, optimizer=None, step: int = 0, extra: Optional[dict] = None, sched_stride: int = 1):
+def save_state(output_dir: str, model, optimizer=None, step: int = 0, extra: Optional[dict] = None, sched_stride: int = 1,
+               next_lr: Optional[float] = None):
     """``accelerator.save_state(output_dir)`` layout (train_accel_gpu.py:122-123,133-134): model.safetensors +
     optimizer.bin (torch AdamW state_dict) + scheduler.bin (LambdaLR state: ``last_epoch`` = scheduler steps taken) +
-    meta.json (ours: optimizer step count).  RNG blobs are not written: nothing in the native step draws random numbers."""
+    meta.json (ours: optimizer step count).  RNG blobs are not written: nothing in the native step draws random numbers.
+    ``next_lr``: torch's schedulers leave the learning rate of the NEXT step in ``param_groups[*]['lr']`` / ``_last_lr``
+    (``base * lambda(last_epoch)``), and that is what Accelerate pickles; the native loop sets the rate right before each step,
+    so the caller passes the next step's rate (train_accel_gpu.py does); None keeps the rate of the step just taken."""
     save_model(model, output_dir)
     if optimizer is not None:
-        torch.save(_optimizer_bin(model, optimizer, step), os.path.join(output_dir, "optimizer.bin"))
-        lr = optimizer.param_groups[0]["lr"]
+        lr = optimizer.param_groups[0]["lr"] if next_lr is None else float(next_lr)
+        torch.save(_optimizer_bin(model, optimizer, step, lr), os.path.join(output_dir, "optimizer.bin"))
         torch.save({"base_lrs": [optimizer.defaults["lr"]], "last_epoch": int(step) * sched_stride, "verbose": False,
                     "_step_count": int(step) * sched_stride + 1, "_get_lr_called_within_step": False, "_last_lr": [lr],
                     "lr_lambdas": [None]}, os.path.join(output_dir, "scheduler.bin"))
@@ -145,15 +149,15 @@ def load_state(input_dir: str, model, optimizer=None) -> dict:
     if optimizer is not None:
         pb, pt = os.path.join(input_dir, "optimizer.bin"), os.path.join(input_dir, "optimizer.pt")
         if os.path.exists(pb):
-            _load_optimizer_bin(model, optimizer, torch.load(pb, map_location="cpu", weights_only=False))
+            _load_optimizer_bin(model, optimizer, torch.load(pb, map_location="cpu", weights_only=True))
             meta.setdefault("step", optimizer.step_count)
         elif os.path.exists(pt):                    # round-1 layout of this repo
-            optimizer.load_state_dict(torch.load(pt, map_location=next(model.parameters()).device))
+            optimizer.load_state_dict(torch.load(pt, map_location=next(model.parameters()).device, weights_only=True))
         else:
             warnings.append(f"load_state: no optimizer state in {input_dir}: Adam moments start from zero")
     sb = os.path.join(input_dir, "scheduler.bin")
     if os.path.exists(sb):
-        meta["scheduler_last_epoch"] = int(torch.load(sb, map_location="cpu", weights_only=False).get("last_epoch", 0))
+        meta["scheduler_last_epoch"] = int(torch.load(sb, map_location="cpu", weights_only=True).get("last_epoch", 0))
     others = [f for f in os.listdir(input_dir) if f.startswith("random_states") or f.endswith(".pkl")] if os.path.isdir(input_dir) else []
     if others:
         warnings.append(f"load_state: ignored {others} (the native step draws no random numbers; data order is reseeded per epoch)")

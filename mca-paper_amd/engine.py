@@ -942,6 +942,23 @@ class FusionEngine:
         with hip.cached_stream():
             return self._model_forward(batch, no_loss)
 
+    def forward_backward(self, batch):
+        """forward + loss + backward WITHOUT autograd: the same kernels as ``model(batch)`` followed by ``loss.backward()``, issued
+        from the calling thread (autograd runs a CUDA backward on its device thread; a stream capture that is cut into segments
+        at the data-parallel collectives must begin and end its captures on one thread: graph.GraphedStep).  Every ``p.grad`` is
+        the view of the flat gradient buffer.  Returns the output dict of the forward."""
+        m = self.model
+        if not all(isinstance(m.encoders[n], (EmbeddedSequenceEncoder, TabularEncoder)) for n in m.modality_types):
+            raise NotImplementedError("forward_backward needs native encoders (a torch encoder's backward runs under autograd)")
+        with hip.cached_stream(), torch.no_grad():
+            self._last_direct = None
+            out = self._model_forward(batch, no_loss=False)
+            ws, res = self._last_direct
+            self.backward(ws, res["d_pooled"], res["d_logit"], accumulate=False)
+        for p in self.param_order:
+            p.grad = self.grad_of(p)
+        return out
+
     def _forward_split(self, batch, b, need_grad):
         """Micro-batch interleave: the two halves of the batch run encoders + trunk on two streams; they only meet in the
         loss.  Per-sample results are identical to the unsplit pass (no kernel mixes samples before the loss)."""
@@ -1008,7 +1025,8 @@ class FusionEngine:
         if need_grad:
             pooled_out, terms, loss = _MCAStep.apply(self, ws, pooled, present, *self.param_order)
         else:
-            pooled_out, terms, loss, _ = _loss_forward(self, pooled, present)
+            pooled_out, terms, loss, res = _loss_forward(self, pooled, present)
+            self._last_direct = (ws, res)          # forward_backward(): the backward chain without an autograd node
         out = {k: pooled_out[:, s] for k, s in slots.items()}
         names = [t.name for t in m.loss_terms]
         out["losses"] = {n: terms[i] for i, n in enumerate(names)}

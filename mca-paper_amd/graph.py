@@ -10,8 +10,16 @@ learning rate and Adam bias corrections, ``mca_adamw_hyper``), optional copies i
 What makes the step capturable: every kernel takes its stream as an argument and nothing in the library allocates or
 synchronises (include/mca_hip.h); the finite checks are a device flag (no ``.item()``); the optimizer reads lr / bias
 corrections from device memory; all workspaces are allocated by the warm-up steps and the loss outputs come from the graph's
-private pool.  Not captured: data-parallel collectives (``dp`` runs eagerly around the graph is NOT supported: use the eager
-step under DP).
+private pool.
+
+Data parallelism (``dp=DataParallelMCA``): the step is captured as a CHAIN of graph segments cut at the collectives, which stay
+ordinary eager torch.distributed calls between two replays — forward | all-gather of the pooled block | loss + pooling backward |
+all-reduce(bucket 0, async) | layer L-1 backward | all-reduce(bucket 1) | ... | encoder backward | all-reduce(last) | wait + finite-
+flag MAX | clip + AdamW.  Per step the host issues ~9 ``hipGraphLaunch`` and ~9 collective calls instead of ~330 kernel launches;
+the bucket all-reduces run on the process group's stream beside the following backward segments exactly as in the eager loop.
+No RCCL call is ever inside a captured region, so nothing depends on RCCL's own capture support.  The segmented body runs the
+backward through ``engine.forward_backward`` (no autograd node): a capture has to end on the thread that began it, and autograd
+runs a CUDA backward on its own device thread.
 
 Reference loop being replaced: train_accel_gpu.py:108-119 (model(batch); zero_grad; backward; clip_grad_norm_; optimizer.step).
 """
@@ -24,9 +32,7 @@ from . import optim as _optim
 
 class GraphedStep:
     def __init__(self, model, optimizer, batch, clip: float = 2.0, dp=None, warmup: int = 3, overlap_wgrad: bool = False):
-        if dp is not None:
-            raise NotImplementedError("GraphedStep captures a single-GPU step; run the eager step under DataParallelMCA")
-        self.model, self.opt, self.clip = model, optimizer, float(clip)
+        self.model, self.opt, self.clip, self.dp = model, optimizer, float(clip), dp
         eng = model.engine
         # weight-gradient GEMMs on the side stream: inside a graph the fork / join edges cost more than the overlap gains at
         # every size tried (one box, alternating processes: b = 32 21.9 ms with, 21.5 without; b = 8 7.90-8.02 with, 7.80 without)
@@ -46,16 +52,70 @@ class GraphedStep:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         self.opt.hyper_external = True             # from here on the driver sets lr / bias corrections and counts the steps
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = self._body()
+        self.program = None
+        if dp is None:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._body()
+        else:
+            self._capture_segments()
         self.loss = self.out["loss"]
         eng.flat.copy_(saved[0]); optimizer.exp_avg.copy_(saved[1]); optimizer.exp_avg_sq.copy_(saved[2])
         optimizer.step_count = saved[3]
         eng.invalidate_weights()
         eng.finite_flag.zero_(); eng._flag_host.zero_(); eng._flag_event = None
 
+    def _capture_segments(self):
+        """The data-parallel step as [graph, collective, graph, collective, ...] (module docstring).  The collectives also run
+        while capturing (on whatever the buffers hold: captured kernels do not execute), so every rank goes through the same
+        sequence of collective calls as in a replay."""
+        import gc
+        torch.cuda.synchronize(); gc.collect(); torch.cuda.empty_cache()          # as torch.cuda.graph() does before a capture
+        pool = torch.cuda.graph_pool_handle()
+        self.program = []
+        stream = torch.cuda.Stream(device=self.model.engine.device)
+        stream.wait_stream(torch.cuda.current_stream())
+        state = {"g": None}
+
+        def begin():
+            state["g"] = torch.cuda.CUDAGraph()
+            state["g"].capture_begin(pool=pool, capture_error_mode="relaxed")          # (the process group's watchdog thread polls events)
+
+        def end():
+            state["g"].capture_end()
+            self.program.append(state["g"])
+
+        def cut(fn):
+            end()
+            fn()
+            self.program.append(fn)
+            begin()
+
+        self.dp.set_cut(cut)
+        try:
+            with torch.cuda.stream(stream):
+                begin()
+                try:
+                    self.out = self._body()
+                except BaseException:
+                    try:
+                        state["g"].capture_end()          # leave no stream in capture mode behind a failed body
+                    except Exception:
+                        pass
+                    raise
+                end()
+        finally:
+            self.dp.set_cut(None)
+        torch.cuda.current_stream().wait_stream(stream)
+        torch.cuda.synchronize()
+
     def _body(self):
+        if self.dp is not None:          # no autograd node (see _capture_segments); the same kernel chain
+            out = self.model.engine.forward_backward(self.static)
+            self.dp.finish_backward()
+            self.gnorm = _optim.clip_grad_norm_(self.model, self.clip) if self.clip else None
+            self.opt.step()
+            return out
         out = self.model(self.static)
         self.opt.zero_grad()
         out["loss"].backward()
@@ -80,7 +140,14 @@ class GraphedStep:
         if eager:
             loss = self._body()["loss"]            # records its own flag event (engine._model_forward)
             return loss
-        self.graph.replay()
+        if self.program is not None:
+            for item in self.program:
+                item.replay() if isinstance(item, torch.cuda.CUDAGraph) else item()
+        else:
+            self.graph.replay()
+        # the replay's AdamW moved the fp32 weights behind torch's version counters, and its bf16 cast ran BEFORE that update: an
+        # eval / no_grad forward after this step must rebuild the bf16 GEMM-weight copies (the next replay casts for itself)
+        eng.invalidate_weights()
         if eng.check_finite:                       # the captured step ends with the flag's copy to pinned host memory
             eng._flag_event = torch.cuda.Event()
             eng._flag_event.record()

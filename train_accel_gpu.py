@@ -59,6 +59,45 @@ def move_to(obj, device):
     raise TypeError("Invalid type for move_to")
 
 
+def run_eval(model, eval_batches, model_config, device):
+    """The reference's evaluation loop (train_accel_gpu.py:137-181) on the native model: mean of the total loss and of every loss
+    term without '|' over the eval batches, Wang-Isola uniformity per modality (+ 'fusion' unless EAO) and alignment of every
+    modality with the fusion embedding (samples that have the modality), raw and normalised, with the reference's log keys
+    (its 'unformity_avg' spelling included).  Returns {key: float}."""
+    was_training = model.training
+    model.eval()
+    names = list(model_config["encoder_configs"].keys())
+    has_fusion = not model_config["eao"]          # the EAO baseline has no fusion token (train_accel_gpu.py:47,155,175)
+    uni = {k: P.metrics.Uniformity() for k in names + (["fusion"] if has_fusion else [])}
+    ali = {k: P.metrics.Alignment() for k in (names if has_fusion else [])}
+    sums, n = {}, 0
+    with torch.no_grad():
+        for batch in eval_batches:
+            out = model(move_to(batch, device))
+            n += 1
+            sums["total_loss"] = sums.get("total_loss", 0.0) + float(out["loss"])
+            for k, v in out["losses"].items():
+                sums[k] = sums.get(k, 0.0) + float(v)
+            for k in names:
+                sm = out["modality_sample_mask"][k]
+                uni[k].update(out[k][sm])
+                if has_fusion:
+                    ali[k].update(out[k][sm], out["fusion"][sm])
+            if has_fusion:
+                uni["fusion"].update(out["fusion"])
+    rec = {f"val_epoch_{k}": v / max(1, n) for k, v in sums.items() if "|" not in k}
+    mean = lambda d: sum(d.values()) / max(1, len(d))
+    for tag, norm in (("", False), ("norm_", True)):
+        u = {f"val_epoch_{tag}uniformity_{k}": float(v.compute(norm=norm)) for k, v in uni.items()}
+        rec.update(u); rec[f"val_epoch_{tag}unformity_avg"] = mean(u)
+        if has_fusion:
+            a = {f"val_epoch_{tag}alignment_{k}": float(v.compute(norm=norm)) for k, v in ali.items()}
+            rec.update(a); rec[f"val_epoch_{tag}alignment_avg"] = mean(a)
+    if was_training:
+        model.train()
+    return rec
+
+
 def main():
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
@@ -91,8 +130,9 @@ def main():
         collate = P.MultimodalCollator(modality_config)
         sampler = DistributedSampler(ds["train"], world, rank, shuffle=True, drop_last=True) if world > 1 else None
         train_dl = DataLoader(ds["train"], collate_fn=collate, batch_size=config.batch_size, shuffle=sampler is None, sampler=sampler,
-                              num_workers=8, prefetch_factor=4, drop_last=True)
-        eval_dl = DataLoader(ds["test"], collate_fn=collate, batch_size=config.batch_size, drop_last=True)
+                              num_workers=8, prefetch_factor=4, drop_last=True, pin_memory=True)
+        # the reference's eval loader keeps the last partial batch (train_accel_gpu.py:71); under DP equal local batches are needed
+        eval_dl = DataLoader(ds["test"], collate_fn=collate, batch_size=config.batch_size, drop_last=world > 1)
         steps_per_epoch = len(train_dl)
 
         def batches(epoch):
@@ -122,14 +162,19 @@ def main():
     # --graph (single GPU): the whole step replayed as one hipGraph (graph.GraphedStep; batches have static shapes: the
     # collators pad every modality to its pad_len)
     use_graph, graphed = "--graph" in sys.argv and world == 1, None
+    lr_at = lambda st: config.lr * lr_factor(config.lr_scheduler_type, st * sched_stride, config.num_warmup_steps, total_steps * sched_stride)
     model.train()
     for epoch in range(config.start_epoch, config.epochs):
         t_epoch = time.time()
-        for idb, batch in enumerate(batches(epoch)):
-            batch = move_to(batch, device)
+        # host -> device copies one batch ahead on a copy stream (data.DevicePrefetcher); MCA_PREFETCH=0: the reference's
+        # synchronous move_to in the compute stream (train_accel_gpu.py:111)
+        feed = batches(epoch)
+        if os.environ.get("MCA_PREFETCH", "1") != "0":
+            feed = P.data.DevicePrefetcher(feed, device)
+        for idb, batch in enumerate(feed):
+            batch = move_to(batch, device)          # (no-op for batches the prefetcher already placed)
             for g in opt.param_groups:
-                g["lr"] = config.lr * lr_factor(config.lr_scheduler_type, step * sched_stride, config.num_warmup_steps,
-                                                total_steps * sched_stride)
+                g["lr"] = lr_at(step)
             if use_graph:
                 if graphed is None:
                     graphed = importlib.import_module("mca-paper_amd.graph").GraphedStep(model, opt, batch, clip=config.clip or 0.0)
@@ -155,38 +200,17 @@ def main():
                 print(json.dumps(rec), flush=True)
                 log.write(json.dumps(rec) + "\n"); log.flush()
             if config.n_step_checkpoint and idb % config.n_step_checkpoint == 0 and rank == 0:
-                P.checkpoint.save_state(config.output_dir, model, opt, step, sched_stride=sched_stride)
+                P.checkpoint.save_state(config.output_dir, model, opt, step, sched_stride=sched_stride, next_lr=lr_at(step))
         model.engine.assert_finite()
         if rank == 0:
-            P.checkpoint.save_state(os.path.join(config.output_dir, str(epoch)), model, opt, step, sched_stride=sched_stride)
+            P.checkpoint.save_state(os.path.join(config.output_dir, str(epoch)), model, opt, step, sched_stride=sched_stride, next_lr=lr_at(step))
             print(f"epoch {epoch} done in {time.time() - t_epoch:.1f}s", flush=True)
         if config.run_eval_loop and eval_batches is not None:
-            # eval loop of the reference (train_accel_gpu.py:137-181): losses + Wang-Isola alignment / uniformity
-            model.eval()
-            names = list(model_config["encoder_configs"].keys())
-            has_fusion = not model_config["eao"]          # the EAO baseline has no fusion token (train_accel_gpu.py:47,155,175)
-            uni = {k: P.metrics.Uniformity() for k in names + (["fusion"] if has_fusion else [])}
-            ali = {k: P.metrics.Alignment() for k in (names if has_fusion else [])}
-            with torch.no_grad():
-                tot, n = 0.0, 0
-                for batch in eval_batches:
-                    out = model(move_to(batch, device))
-                    tot += float(out["loss"]); n += 1
-                    for k in names:
-                        sm = out["modality_sample_mask"][k]
-                        uni[k].update(out[k][sm])
-                        if has_fusion:
-                            ali[k].update(out[k][sm], out["fusion"][sm])
-                    if has_fusion:
-                        uni["fusion"].update(out["fusion"])
+            rec = run_eval(model, eval_batches, model_config, device)
             if rank == 0:
-                rec = {"epoch": epoch, "val_epoch_total_loss": tot / max(1, n)}
-                rec.update({f"val_epoch_uniformity_{k}": float(v.compute()) for k, v in uni.items()})
-                rec.update({f"val_epoch_alignment_{k}": float(v.compute()) for k, v in ali.items()})
-                rec.update({f"val_epoch_norm_uniformity_{k}": float(v.compute(norm=True)) for k, v in uni.items()})
-                rec.update({f"val_epoch_norm_alignment_{k}": float(v.compute(norm=True)) for k, v in ali.items()})
+                rec = {"epoch": epoch, **rec}
                 print(json.dumps(rec), flush=True)
-            model.train()
+                log.write(json.dumps(rec) + "\n"); log.flush()
     if rank == 0:
         P.checkpoint.save_model(model, config.output_dir, safe_serialization=True)   # train_accel_gpu.py:187
     if world > 1:
