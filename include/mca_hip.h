@@ -245,6 +245,18 @@ int mca_attn_quant_mxfp8(const uint16_t* q, int64_t q_bstride, int64_t q_ld, con
  * the q / k / v pointers of args are not read).  o (bf16) and lse as mca_attn_fwd; the backward stays in bf16.            */
 int mca_attn_fwd_fp8(const mca_attn_fwd_args* args, const mca_attn_fp8_operands* f, mca_stream_t stream);
 
+/* Backward of the fusion attention with the two score recomputes (S = Q K^T, dP = dO V^T: 4 of the 7 matrix products of
+ * the two-pass backward) on the block-scaled fp8 matrix instruction (BASELINE configs[4]; autograd of model.py:87-99).
+ * Operands: e4m3 copies of q, k, v, dO, all [batch][heads][npad][64] with [batch][heads][npad][2] E8M0 scale bytes (blocks of
+ * 32 ALONG d, the contraction of both products), npad = n_ktiles * 64, rows >= n zero.  q8 / k8 are the arrays of
+ * mca_attn_quant_mxfp8, so S is bit for bit the S of mca_attn_fwd_fp8 and P = 2^(S - lse) is consistent with its lse.   */
+typedef struct { uint8_t* q8; uint8_t* qs; uint8_t* k8; uint8_t* ks; uint8_t* v8; uint8_t* vs; uint8_t* do8; uint8_t* dos; int n_ktiles; } mca_attn_fp8_bwd_operands;
+int mca_attn_quant_bwd_mxfp8(const uint16_t* q, int64_t q_bstride, int64_t q_ld, const uint16_t* k, const uint16_t* v,
+                             int64_t kv_bstride, int64_t kv_ld, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld,
+                             const mca_attn_fp8_bwd_operands* f, int batch, int heads, int n, mca_stream_t stream);
+/* mca_attn_bwd_dq / mca_attn_bwd_dkv (arguments as documented below) with those operands; self-attention,
+ * MCA_ATTN_Q_PRESCALED and the mask product (khot / qblk) required, kblock_keys = 128 for the dkv pass; the q / v pointers
+ * of args are read only by the dkv pass (bf16 Q tile of the dK product); dQ, dK, dV products stay bf16 / fp32.            */
 /* delta[b,h,i] = sum_d dO*O ; dvmean[b,h*64+d] = (1/nk) * sum over uniform rows i of dO          */
 int mca_attn_bwd_prep(const uint16_t* o, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld,
                       const float* lse, float* delta, float* dvmean,
@@ -298,6 +310,8 @@ typedef struct {
 } mca_attn_bwd2_args;
 int mca_attn_bwd_dq(const mca_attn_bwd2_args* args, mca_stream_t stream);
 int mca_attn_bwd_dkv(const mca_attn_bwd2_args* args, mca_stream_t stream);
+int mca_attn_bwd_dq_fp8(const mca_attn_bwd2_args* args, const mca_attn_fp8_bwd_operands* f, mca_stream_t stream);
+int mca_attn_bwd_dkv_fp8(const mca_attn_bwd2_args* args, const mca_attn_fp8_bwd_operands* f, mca_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * All-pairs contrastive loss with temperature

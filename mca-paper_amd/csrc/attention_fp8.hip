@@ -356,3 +356,542 @@ extern "C" int mca_attn_fwd_fp8(const mca_attn_fwd_args* a, const mca_attn_fp8_o
   hipLaunchKernelGGL(attn_fwd8_kernel, dim3(a->n_qtiles, a->heads, a->batch), dim3(256), 0, as_stream(stream), *a, *f, mca_knobs[9]);
   return launch_status();
 }
+
+// =========================================================================================================
+// Backward with MX-fp8 score recomputes (BASELINE configs[4]).  The two-pass backward of attention_bwd2.hip recomputes
+// S = Q K^T and dP = dO V^T in both passes: here those two products (4 of the 7 per tile) run on the block-scaled fp8 matrix
+// instruction, from e4m3 copies of q, k, v and dO with one E8M0 scale per 32 elements ALONG d (the contraction of both
+// products); the three products that build gradients (dQ = dS K, dK = dS^T Q, dV = P^T dO) keep bf16 operands and fp32
+// accumulation.  S is then bit for bit the S of mca_attn_fwd_fp8 (same q8 / k8), so P = 2^(S - lse) is consistent with the
+// log-sum-exp that forward wrote (the bf16 recompute was not).  delta stays rowsum(dO o O) of mca_attn_bwd_prep.
+//   mca_attn_quant_bwd_mxfp8   q | k | v | dO (bf16) -> four [b][h][npad][64] e4m3 arrays + [b][h][npad][2] scale bytes
+//   mca_attn_bwd_dq_fp8        attn_bwd_dq_kernel's structure (128-query workgroups, 64-key tiles, query on the lane)
+//   mca_attn_bwd_dkv_fp8       attn_bwd_dkv_kernel's structure, 4 wavefronts x 32 keys, key on the lane
+// Self-attention, MCA_ATTN_Q_PRESCALED and the mask product (khot / qblk) only.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void attn_quant_rows4_kernel(const u16* __restrict__ q, int64_t q_bstride, int64_t q_ld,
+                                                                const u16* __restrict__ k, const u16* __restrict__ v,
+                                                                int64_t kv_bstride, int64_t kv_ld, const u16* __restrict__ d_o,
+                                                                int64_t o_bstride, int64_t o_ld, mca_attn_fp8_bwd_operands f,
+                                                                int heads, int n, int ntiles) {
+  const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int r = tid >> 2, c = tid & 3;
+  const int tok = kt * AK + r;
+  const bool live = tok < n;
+  const int64_t rowi = ((int64_t)b * heads + h) * ((int64_t)ntiles * AK) + tok;
+  const int64_t t = live ? tok : 0;
+#pragma unroll
+  for (int which = 0; which < 4; which++) {
+    const u16* src = which == 0 ? q + (int64_t)b * q_bstride + t * q_ld
+                   : which == 1 ? k + (int64_t)b * kv_bstride + t * kv_ld
+                   : which == 2 ? v + (int64_t)b * kv_bstride + t * kv_ld
+                                : d_o + (int64_t)b * o_bstride + t * o_ld;
+    src += h * DH + 16 * c;
+    float x[16];
+    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(src), a1 = *reinterpret_cast<const bf16x8*>(src + 8);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { x[i] = live ? bf2f((u16)a0[i]) : 0.f; x[8 + i] = live ? bf2f((u16)a1[i]) : 0.f; }
+    uint4 o;
+    const uint32_t sb = quant_block_half(x, o);
+    uint8_t* d8 = which == 0 ? f.q8 : which == 1 ? f.k8 : which == 2 ? f.v8 : f.do8;
+    uint8_t* ds = which == 0 ? f.qs : which == 1 ? f.ks : which == 2 ? f.vs : f.dos;
+    *reinterpret_cast<uint4*>(d8 + rowi * DH + 16 * c) = o;
+    if ((c & 1) == 0) ds[rowi * 2 + (c >> 1)] = (uint8_t)sb;
+  }
+}
+
+static int check_fp8_bwd_operands(const mca_attn_fp8_bwd_operands* f) {
+  if (!f || !f->q8 || !f->qs || !f->k8 || !f->ks || !f->v8 || !f->vs || !f->do8 || !f->dos) return MCA_E_BADARG;
+  if ((uintptr_t)f->q8 % 16 || (uintptr_t)f->k8 % 16 || (uintptr_t)f->v8 % 16 || (uintptr_t)f->do8 % 16) return MCA_E_ALIGN;
+  if ((uintptr_t)f->qs % 4 || (uintptr_t)f->ks % 4 || (uintptr_t)f->vs % 4 || (uintptr_t)f->dos % 4) return MCA_E_ALIGN;
+  return MCA_OK;
+}
+
+extern "C" int mca_attn_quant_bwd_mxfp8(const uint16_t* q, int64_t q_bstride, int64_t q_ld, const uint16_t* k, const uint16_t* v,
+                                        int64_t kv_bstride, int64_t kv_ld, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld,
+                                        const mca_attn_fp8_bwd_operands* f, int batch, int heads, int n, mca_stream_t stream) {
+  if (!q || !k || !v || !d_o || batch <= 0 || heads <= 0 || n <= 0) return MCA_E_BADARG;
+  const int rc = check_fp8_bwd_operands(f);
+  if (rc != MCA_OK) return rc;
+  if (q_ld % 8 || kv_ld % 8 || o_ld % 8 || q_bstride % 8 || kv_bstride % 8 || o_bstride % 8 || (uintptr_t)q % 16 || (uintptr_t)k % 16 ||
+      (uintptr_t)v % 16 || (uintptr_t)d_o % 16)
+    return MCA_E_ALIGN;
+  const int ntiles = (n + AK - 1) / AK;
+  if (f->n_ktiles != ntiles) return MCA_E_BADARG;
+  if (heads > 65535 || batch > 65535) return MCA_E_UNSUPPORTED;
+  hipLaunchKernelGGL(attn_quant_rows4_kernel, dim3(ntiles, heads, batch), dim3(256), 0, as_stream(stream), q, q_bstride, q_ld, k, v,
+                     kv_bstride, kv_ld, d_o, o_bstride, o_ld, *f, heads, n, ntiles);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dQ pass
+// ---------------------------------------------------------------------------------------------------------
+// bf16 K image for the transposed reads of the dQ product (attention_bwd2.hip rt_off)
+__device__ __forceinline__ int rt8_off(int r, int c) {
+  const int s = ((r >> 1) & 7) ^ (((r >> 1) & 1) << 2);
+  return r * 64 + ((c ^ s) << 3);
+}
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq8_kernel(mca_attn_bwd2_args a, mca_attn_fp8_bwd_operands f, int dbg) {
+  __shared__ __attribute__((aligned(16))) u16 kbf_s[2 * AK * DH];          // bf16 K tile, double-buffered: 16 KiB
+  __shared__ __attribute__((aligned(16))) uint8_t t8_s[2 * 2 * AK * DH];   // K8, V8 double-buffered: 16 KiB
+  __shared__ __attribute__((aligned(16))) uint8_t sc_s[2][2][AK * 2];      // [buffer][K | V][row][block] scale bytes
+  __shared__ __attribute__((aligned(16))) u16 hot_s[2][AK * 16];
+  __shared__ uint8_t flags_s[MAX_KTILES];
+  __shared__ uint32_t live_s[MAX_KTILES];
+  __shared__ int n_live_s;
+  uint8_t* K8s = t8_s;
+  uint8_t* V8s = t8_s + 2 * AK * DH;
+
+  const int lin0 = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+  const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y * gridDim.z));
+  const int qt = a.q_order[lin % (int)gridDim.x];
+  const int h = (lin / (int)gridDim.x) % (int)gridDim.y, b = lin / (int)(gridDim.x * gridDim.y);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int q0 = qt * AQ + wave * 32;
+  int qrow = q0 + l31;
+  const bool qvalid = qrow < a.nq;
+  if (qrow > a.nq - 1) qrow = a.nq - 1;
+  const int ntiles = f.n_ktiles;
+  const int64_t bh = (int64_t)b * a.heads + h;
+
+  // B operands held for the whole kernel: this lane's query row of Q8 and dO8 (bytes 16 lh .. +15 of both 32-element blocks)
+  v8i qf, dof;
+  int qscale, doscale;
+  {
+    const int64_t rowi = bh * ((int64_t)ntiles * AK) + qrow;
+    const uint4 lo = *reinterpret_cast<const uint4*>(f.q8 + rowi * DH + 16 * lh), hi = *reinterpret_cast<const uint4*>(f.q8 + rowi * DH + 32 + 16 * lh);
+    qf[0] = lo.x; qf[1] = lo.y; qf[2] = lo.z; qf[3] = lo.w; qf[4] = hi.x; qf[5] = hi.y; qf[6] = hi.z; qf[7] = hi.w;
+    qscale = f.qs[rowi * 2 + lh];
+    const uint4 l2 = *reinterpret_cast<const uint4*>(f.do8 + rowi * DH + 16 * lh), h2 = *reinterpret_cast<const uint4*>(f.do8 + rowi * DH + 32 + 16 * lh);
+    dof[0] = l2.x; dof[1] = l2.y; dof[2] = l2.z; dof[3] = l2.w; dof[4] = h2.x; dof[5] = h2.y; dof[6] = h2.z; dof[7] = h2.w;
+    doscale = f.dos[rowi * 2 + lh];
+  }
+  const uint32_t qm = a.qmask[qrow];
+  const uint32_t qm8 = ((qm >> (8 * lh)) & 0xffu) & (lh ? 0x7fu : 0xffu);
+  f32x16 neglse, negdel;
+  {
+    const int64_t ri = bh * a.nq + qrow;
+    const float nl = -a.lse[ri], nd = -a.delta[ri];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { neglse[r] = nl; negdel[r] = nd; }
+  }
+  f32x16 dq[2];
+#pragma unroll
+  for (int n = 0; n < 2; n++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) dq[n][r] = 0.f;
+
+  const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
+  const uint8_t* k8b = f.k8 + bh * ((int64_t)ntiles * AK) * DH;
+  const uint8_t* ksb = f.ks + bh * ((int64_t)ntiles * AK) * 2;
+  const uint8_t* v8b = f.v8 + bh * ((int64_t)ntiles * AK) * DH;
+  const uint8_t* vsb = f.vs + bh * ((int64_t)ntiles * AK) * 2;
+  const u16* khot_g = a.khot + (int64_t)b * a.nk_pad * 16;
+  {
+    const uint8_t* flags_g = a.ktile_flags + (int64_t)b * a.n_ktiles64;
+    for (int i = tid; i < a.n_ktiles64; i += 256) flags_s[i] = flags_g[i];
+  }
+  __syncthreads();
+
+  // staging per thread and tile: two 16-byte pieces of the bf16 K tile, one of K8, one of V8, 8 bytes of the one-hot image
+  int srow[2], scc[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) { const int id = tid + 256 * i; srow[i] = id >> 3; scc[i] = id & 7; }
+  const int s8row = tid >> 2, s8col = tid & 3;
+  const int last_kt = a.n_ktiles64 - 1;
+  bf16x8 rk[2];
+  uint4 rk8, rv8;
+  uint32_t rsk = 0, rsv = 0;
+  uint2 rhot = make_uint2(0, 0);
+  auto gload = [&](int kt) {
+    rhot = *reinterpret_cast<const uint2*>(khot_g + (int64_t)kt * (AK * 16) + tid * 4);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      int key = kt * AK + srow[i]; if (kt == last_kt && key > a.nk - 1) key = a.nk - 1;
+      rk[i] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * a.kv_ld + scc[i] * 8);
+    }
+    rk8 = *reinterpret_cast<const uint4*>(k8b + ((int64_t)kt * AK + s8row) * DH + 16 * s8col);
+    rv8 = *reinterpret_cast<const uint4*>(v8b + ((int64_t)kt * AK + s8row) * DH + 16 * s8col);
+    if (tid < 32) { rsk = *reinterpret_cast<const uint32_t*>(ksb + (int64_t)kt * AK * 2 + tid * 4); rsv = *reinterpret_cast<const uint32_t*>(vsb + (int64_t)kt * AK * 2 + tid * 4); }
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) *reinterpret_cast<bf16x8*>(kbf_s + buf * AK * DH + rt8_off(srow[i], scc[i])) = rk[i];
+    *reinterpret_cast<uint4*>(K8s + buf * AK * DH + t8_off(s8row, s8col)) = rk8;
+    *reinterpret_cast<uint4*>(V8s + buf * AK * DH + t8_off(s8row, s8col)) = rv8;
+    if (tid < 32) { *reinterpret_cast<uint32_t*>(&sc_s[buf][0][tid * 4]) = rsk; *reinterpret_cast<uint32_t*>(&sc_s[buf][1][tid * 4]) = rsv; }
+    *reinterpret_cast<uint2*>(&hot_s[buf][tid * 4]) = rhot;
+  };
+
+  if (wave == 0) {
+    const int lb = a.q_ptr[qt], le = a.q_ptr[qt + 1];
+    int n = 0;
+    for (int i0 = lb; i0 < le; i0 += 64) {
+      const int i = i0 + lane;
+      const uint32_t e = i < le ? a.q_kt[i] : 0u;
+      const uint8_t fl = i < le ? flags_s[e & 0x7fffffffu] : (uint8_t)0;
+      const bool keep = fl != 0;
+      const unsigned long long m = __ballot(keep);
+      if (keep) live_s[n + __popcll(m & ((1ull << lane) - 1ull))] = (e & 0x7fffffffu) | ((e >> 31) && fl == 2 ? 0x80000000u : 0u);
+      n += __popcll(m);
+    }
+    if (lane == 0) n_live_s = n;
+  }
+  __syncthreads();
+  const int it_end = n_live_s;
+  int buf = 0;
+  if (it_end > 0) { gload((int)(live_s[0] & 0x7fffffffu)); swrite(0); }
+  __syncthreads();
+
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  for (int it = 0; it < it_end; it++) {
+    const uint32_t ent = live_s[it];
+    const bool need_mask = (ent >> 31) == 0;
+    if (it + 1 < it_end) gload((int)(live_s[it + 1] & 0x7fffffffu));
+    const u16* ks = kbf_s + buf * AK * DH;
+    const uint8_t* k8 = K8s + buf * AK * DH;
+    const uint8_t* v8 = V8s + buf * AK * DH;
+    // S^T - lse and dP^T - delta: ONE block-scaled MFMA each per 32-key block (row constants as the accumulator start values)
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      const int row = kb * 32 + l31;
+      const uint4 klo = *reinterpret_cast<const uint4*>(k8 + t8_off(row, lh)), khi = *reinterpret_cast<const uint4*>(k8 + t8_off(row, 2 + lh));
+      const uint4 vlo = *reinterpret_cast<const uint4*>(v8 + t8_off(row, lh)), vhi = *reinterpret_cast<const uint4*>(v8 + t8_off(row, 2 + lh));
+      v8i kf, vf;
+      kf[0] = klo.x; kf[1] = klo.y; kf[2] = klo.z; kf[3] = klo.w; kf[4] = khi.x; kf[5] = khi.y; kf[6] = khi.z; kf[7] = khi.w;
+      vf[0] = vlo.x; vf[1] = vlo.y; vf[2] = vlo.z; vf[3] = vlo.w; vf[4] = vhi.x; vf[5] = vhi.y; vf[6] = vhi.z; vf[7] = vhi.w;
+      const int kscale = sc_s[buf][0][row * 2 + lh], vscale = sc_s[buf][1][row * 2 + lh];
+      s[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, neglse, 0, 0, 0, kscale, 0, qscale);
+      dp[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, dof, negdel, 0, 0, 0, vscale, 0, doscale);
+    }
+    if (need_mask) {          // blocked (query, key) pairs: -32768 on top of the score, exp2 is exactly 0
+      u32x4v qb;
+#pragma unroll
+      for (int w = 0; w < 4; w++)
+        qb[w] = (((qm8 >> (2 * w)) & 1u) ? 0u : 0xC700u) | (((qm8 >> (2 * w + 1)) & 1u) ? 0u : 0xC7000000u);
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        const bf16x8 hf = *reinterpret_cast<const bf16x8*>(&hot_s[buf][(kb * 32 + l31) * 16 + 8 * lh]);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf, *reinterpret_cast<const bf16x8*>(&qb), s[kb], 0, 0, 0);
+      }
+    }
+    // dS^T = P^T o (dP^T - delta), packed as the B operand of the dQ^T product (bf16)
+    u32x4v dsw[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int sp = 0; sp < 2; sp++)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const float d0 = __builtin_amdgcn_exp2f(s[kb][8 * sp + j]) * dp[kb][8 * sp + j];
+          const float d1 = __builtin_amdgcn_exp2f(s[kb][8 * sp + j + 1]) * dp[kb][8 * sp + j + 1];
+          dsw[kb][sp][j >> 1] = pack2bf_pk(d0, d1);
+        }
+    // dQ^T[d][q] += K^T[d][key] dS^T[key][q]: bf16, A = K^T by transposed reads of the bf16 K image
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int sp = 0; sp < 2; sp++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+          bf16x8 ktf;
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            const int key = kb * 32 + 16 * sp + 8 * t + 4 * lh + tq;
+            const int d = n * 32 + 16 * tg + 4 * tp;
+            const bf16x4 k4 = lds_read_tr16(ks + rt8_off(key, d >> 3) + (d & 7));
+#pragma unroll
+            for (int e = 0; e < 4; e++) ktf[4 * t + e] = k4[e];
+          }
+          dq[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, *reinterpret_cast<const bf16x8*>(&dsw[kb][sp]), dq[n], 0, 0, 0);
+        }
+    if (it + 1 < it_end) swrite(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  if (qvalid) {
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int d = n * 32 + 8 * g + 4 * lh;
+        const float v0 = dq[n][4 * g] * a.scale, v1 = dq[n][4 * g + 1] * a.scale, v2 = dq[n][4 * g + 2] * a.scale, v3 = dq[n][4 * g + 3] * a.scale;
+        if (OUT_F32) {
+          float* p = reinterpret_cast<float*>(a.dq) + (int64_t)b * a.dq_bstride + (int64_t)qrow * a.dq_ld + h * DH + d;
+          *reinterpret_cast<f32x4*>(p) = f32x4{v0, v1, v2, v3};
+        } else {
+          u16* p = reinterpret_cast<u16*>(a.dq) + (int64_t)b * a.dq_bstride + (int64_t)qrow * a.dq_ld + h * DH + d;
+          uint2 pk; pk.x = pack2bf(v0, v1); pk.y = pack2bf(v2, v3);
+          *reinterpret_cast<uint2*>(p) = pk;
+        }
+      }
+  }
+}
+
+static int check_bwd8(const mca_attn_bwd2_args* a, const mca_attn_fp8_bwd_operands* f) {
+  if (!a || !a->k || !a->d_o || !a->lse || !a->delta || !a->qmask || !a->keyinfo || !a->ktile_flags) return MCA_E_BADARG;
+  const int rc = check_fp8_bwd_operands(f);
+  if (rc != MCA_OK) return rc;
+  if (a->batch <= 0 || a->heads <= 0 || a->nq <= 0 || a->nk <= 0) return MCA_E_BADARG;
+  if (a->nq != a->nk) return MCA_E_UNSUPPORTED;                                   // self-attention: one quantised token block
+  if (!(a->flags & MCA_ATTN_Q_PRESCALED) || !a->khot || !a->qblk) return MCA_E_UNSUPPORTED;
+  if (f->n_ktiles != (a->nk + AK - 1) / AK) return MCA_E_BADARG;
+  if (a->q_ld % 8 || a->kv_ld % 8 || a->o_ld % 8 || a->q_bstride % 8 || a->kv_bstride % 8 || a->o_bstride % 8) return MCA_E_ALIGN;
+  if ((uintptr_t)a->q % 16 || (uintptr_t)a->k % 16 || (uintptr_t)a->d_o % 16 || (uintptr_t)a->khot % 16 || (uintptr_t)a->qblk % 16) return MCA_E_ALIGN;
+  if (a->heads > 65535 || a->batch > 65535) return MCA_E_UNSUPPORTED;
+  return MCA_OK;
+}
+
+extern "C" int mca_attn_bwd_dq_fp8(const mca_attn_bwd2_args* a, const mca_attn_fp8_bwd_operands* f, mca_stream_t stream) {
+  const int rc = check_bwd8(a, f);
+  if (rc != MCA_OK) return rc;
+  if (!a->dq || !a->q_ptr || !a->q_kt || !a->q_order) return MCA_E_BADARG;
+  if (a->n_qtiles128 != (a->nq + AQ - 1) / AQ || a->n_ktiles64 != (a->nk + AK - 1) / AK) return MCA_E_BADARG;
+  if (a->nk_pad < a->n_ktiles64 * AK) return MCA_E_BADARG;
+  if (a->dq_ld % 4 || a->dq_bstride % 4 || (uintptr_t)a->dq % (a->dq_f32 ? 16 : 8)) return MCA_E_ALIGN;
+  if (a->n_ktiles64 > MAX_KTILES) return MCA_E_UNSUPPORTED;
+  const dim3 grid(a->n_qtiles128, a->heads, a->batch);
+  if (a->dq_f32) hipLaunchKernelGGL(attn_bwd_dq8_kernel<true>, grid, dim3(256), 0, as_stream(stream), *a, *f, mca_knobs[9]);
+  else hipLaunchKernelGGL(attn_bwd_dq8_kernel<false>, grid, dim3(256), 0, as_stream(stream), *a, *f, mca_knobs[9]);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dK / dV pass (4 wavefronts x 32 keys per workgroup, 64-query steps)
+// ---------------------------------------------------------------------------------------------------------
+#define BQ8 64
+#define MAX_QTILES8 2048
+#define DKV8_LDS_BYTES (2 * BQ8 * DH * 2 * 2 + 2 * BQ8 * DH * 2 + 2 * 2 * BQ8 * 2 + 2 * 192 * 4 + MAX_QTILES8 * 4 + DH * 4 + 2 * BQ8 * 16 * 2)
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv8_kernel(mca_attn_bwd2_args a, mca_attn_fp8_bwd_operands f, int dbg) {
+  constexpr int BKEYS = 128, NT = 256;
+  extern __shared__ __attribute__((aligned(16))) u16 lds[];
+  u16* Qs = lds;                               // bf16 Q tile, 2 x 64 x 64 (transposed reads of the dK product)
+  u16* Os = Qs + 2 * BQ8 * DH;                 // bf16 dO tile
+  uint8_t* Q8s = reinterpret_cast<uint8_t*>(Os + 2 * BQ8 * DH);      // 2 x 64 x 64 bytes
+  uint8_t* O8s = Q8s + 2 * BQ8 * DH;
+  uint8_t* sc8 = O8s + 2 * BQ8 * DH;                                  // [2][Q | dO][64 rows][2]
+  float* rowc = reinterpret_cast<float*>(sc8 + 2 * 2 * BQ8 * 2);      // [2][3][64]: -lse, -delta, (unused)
+  uint32_t* qlist = reinterpret_cast<uint32_t*>(rowc + 2 * 192);
+  float* dvm_s = reinterpret_cast<float*>(qlist + MAX_QTILES8);
+  u16* qblk_s = reinterpret_cast<u16*>(dvm_s + DH);                   // [2][64][16]
+
+  const int lin0 = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+  const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y * gridDim.z));
+  const int4 w = reinterpret_cast<const int4*>(a.k_wg)[lin % (int)gridDim.x];
+  const int kbi = w.x, it_begin = w.y, first_qt = w.w;
+  const int h = (lin / (int)gridDim.x) % (int)gridDim.y, b = lin / (int)(gridDim.x * gridDim.y);
+  int n_it = w.z;
+  {
+    const uint8_t* fl = a.ktile_flags + (int64_t)b * a.n_ktiles64;
+    int live = 0;
+    for (int t = 0; t < BKEYS / AK; t++) { const int kt = kbi * (BKEYS / AK) + t; if (kt < a.n_ktiles64) live |= fl[kt]; }
+    if (!live) n_it = 0;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int key0 = kbi * BKEYS;
+  const int mykey = key0 + wave * 32 + l31;
+  const int ntiles = f.n_ktiles;
+  const int64_t bh = (int64_t)b * a.heads + h;
+  const int64_t row0 = bh * ((int64_t)ntiles * AK);
+
+  // B operands held for the whole kernel: this lane's key row of K8 and V8
+  v8i kf, vf;
+  int kscale, vscale;
+  {
+    // (a key past the quantised block, 128-key blocks against 64-row padding, is a padded key: masked by its khot row)
+    const int64_t rowi = row0 + (mykey < ntiles * AK ? mykey : ntiles * AK - 1);
+    const uint4 lo = *reinterpret_cast<const uint4*>(f.k8 + rowi * DH + 16 * lh), hi = *reinterpret_cast<const uint4*>(f.k8 + rowi * DH + 32 + 16 * lh);
+    kf[0] = lo.x; kf[1] = lo.y; kf[2] = lo.z; kf[3] = lo.w; kf[4] = hi.x; kf[5] = hi.y; kf[6] = hi.z; kf[7] = hi.w;
+    kscale = f.ks[rowi * 2 + lh];
+    const uint4 l2 = *reinterpret_cast<const uint4*>(f.v8 + rowi * DH + 16 * lh), h2 = *reinterpret_cast<const uint4*>(f.v8 + rowi * DH + 32 + 16 * lh);
+    vf[0] = l2.x; vf[1] = l2.y; vf[2] = l2.z; vf[3] = l2.w; vf[4] = h2.x; vf[5] = h2.y; vf[6] = h2.z; vf[7] = h2.w;
+    vscale = f.vs[rowi * 2 + lh];
+  }
+  const uint32_t kinfo = a.keyinfo[(int64_t)b * a.nk_pad + mykey];
+  const bf16x8 khf = *reinterpret_cast<const bf16x8*>(a.khot + ((int64_t)b * a.nk_pad + mykey) * 16 + 8 * lh);
+  const bool key_ok = kinfo != 31u;
+  const bool wave_keys_ok = __all(key_ok);
+  const bool wave_dead = !__any(key_ok);
+  const float dk_scale = 0.6931471805599453f;          // q carries scale * log2 e: dK^T carries that factor
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int n = 0; n < 2; n++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dk[n][r] = 0.f; dv[n][r] = 0.f; }
+
+  const u16* qbase = a.q + (int64_t)b * a.q_bstride + h * DH;
+  const u16* obase = a.d_o + (int64_t)b * a.o_bstride + h * DH;
+  const float* lse_g = a.lse + bh * a.nq;
+  const float* delta_g = a.delta + bh * a.nq;
+
+  const int srow = tid >> 3, sc = tid & 7;          // bf16 tiles: 512 pieces of 16 bytes, two per thread
+  const int s8row = tid >> 2, s8col = tid & 3;      // fp8 tiles: 256 pieces, one per thread
+  bf16x8 stage_q[2], stage_o[2];
+  uint4 stage_q8, stage_o8, stage_b = make_uint4(0, 0, 0, 0);
+  uint32_t stage_s = 0;
+  float stage_c = 0.f;
+  bool stage_oob = false;
+  const int cwhich = tid >> 6 < 2 ? tid >> 6 : 2, crow = tid & 63;
+  const float* cbase = cwhich == 0 ? lse_g : delta_g;
+  auto gload = [&](int qt) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      int q = qt * BQ8 + srow + u * 32; if (q > a.nq - 1) q = a.nq - 1;
+      stage_q[u] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)q * a.q_ld + sc * 8);
+      stage_o[u] = *reinterpret_cast<const bf16x8*>(obase + (int64_t)q * a.o_ld + sc * 8);
+    }
+    const int64_t r8 = row0 + (int64_t)qt * BQ8 + s8row;          // rows past nq are zero rows of the quantised arrays
+    stage_q8 = *reinterpret_cast<const uint4*>(f.q8 + r8 * DH + 16 * s8col);
+    stage_o8 = *reinterpret_cast<const uint4*>(f.do8 + r8 * DH + 16 * s8col);
+    if (tid < 64) {          // scale bytes of the 64 rows: 128 bytes of Q (threads 0..31), 128 of dO (32..63)
+      const uint8_t* sp = (tid < 32 ? f.qs : f.dos) + (row0 + (int64_t)qt * BQ8) * 2 + (tid & 31) * 4;
+      stage_s = *reinterpret_cast<const uint32_t*>(sp);
+    }
+    int qq = qt * BQ8 + crow;
+    stage_oob = qq >= a.nq;
+    if (qq > a.nq - 1) qq = a.nq - 1;
+    if (cwhich < 2) stage_c = cbase[qq];
+    if (tid < 128) {
+      int qb = qt * BQ8 + (tid >> 1); if (qb > a.nq - 1) qb = a.nq - 1;
+      stage_b = *reinterpret_cast<const uint4*>(a.qblk + (int64_t)qb * 16 + (tid & 1) * 8);
+    }
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      *reinterpret_cast<bf16x8*>(Qs + buf * BQ8 * DH + rt8_off(srow + u * 32, sc)) = stage_q[u];
+      *reinterpret_cast<bf16x8*>(Os + buf * BQ8 * DH + rt8_off(srow + u * 32, sc)) = stage_o[u];
+    }
+    *reinterpret_cast<uint4*>(Q8s + buf * BQ8 * DH + t8_off(s8row, s8col)) = stage_q8;
+    *reinterpret_cast<uint4*>(O8s + buf * BQ8 * DH + t8_off(s8row, s8col)) = stage_o8;
+    if (tid < 64) *reinterpret_cast<uint32_t*>(sc8 + buf * (2 * BQ8 * 2) + (tid >> 5) * (BQ8 * 2) + (tid & 31) * 4) = stage_s;
+    if (tid < 128) {          // rows past nq contribute nothing: lse = +inf (P = 0), delta = 0
+      float v = stage_oob ? (cwhich == 0 ? INFINITY : 0.f) : stage_c;
+      rowc[buf * 192 + tid] = -v;
+    }
+    if (tid < 128) *reinterpret_cast<uint4*>(qblk_s + buf * (BQ8 * 16) + (tid >> 1) * 16 + (tid & 1) * 8) = stage_b;
+  };
+
+  if (n_it > 0) gload(first_qt);
+  for (int i = tid; i < n_it; i += NT) qlist[i] = a.k_qt[it_begin + i];
+  if (tid < DH) dvm_s[tid] = a.dvmean[(int64_t)b * a.heads * DH + h * DH + tid];
+  int buf = 0;
+  if (n_it > 0) swrite(0);
+  __syncthreads();
+
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  for (int it = 0; it < n_it; it++) {
+    const uint32_t ent = __builtin_amdgcn_readfirstlane(qlist[it]);
+    const bool full = (ent >> 31) != 0;
+    if (it + 1 < n_it) gload((int)(__builtin_amdgcn_readfirstlane(qlist[it + 1]) & 0x7fffffffu));
+    if (!wave_dead)
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+      const u16* qs = Qs + buf * BQ8 * DH + sub * 32 * DH;
+      const u16* os = Os + buf * BQ8 * DH + sub * 32 * DH;
+      const uint8_t* q8 = Q8s + buf * BQ8 * DH;
+      const uint8_t* o8 = O8s + buf * BQ8 * DH;
+      const float* rc = rowc + buf * 192 + sub * 32;
+      const int row = sub * 32 + l31;
+      // A operands: this lane's QUERY row of the sub-tile (Q8 for S, dO8 for dP); accumulator start values = the row constants
+      // of the rows this lane's registers hold (rows 8 g + 4 lh + e)
+      const uint4 qlo = *reinterpret_cast<const uint4*>(q8 + t8_off(row, lh)), qhi = *reinterpret_cast<const uint4*>(q8 + t8_off(row, 2 + lh));
+      const uint4 olo = *reinterpret_cast<const uint4*>(o8 + t8_off(row, lh)), ohi = *reinterpret_cast<const uint4*>(o8 + t8_off(row, 2 + lh));
+      v8i qa, oa;
+      qa[0] = qlo.x; qa[1] = qlo.y; qa[2] = qlo.z; qa[3] = qlo.w; qa[4] = qhi.x; qa[5] = qhi.y; qa[6] = qhi.z; qa[7] = qhi.w;
+      oa[0] = olo.x; oa[1] = olo.y; oa[2] = olo.z; oa[3] = olo.w; oa[4] = ohi.x; oa[5] = ohi.y; oa[6] = ohi.z; oa[7] = ohi.w;
+      const int qsc = sc8[buf * (2 * BQ8 * 2) + row * 2 + lh], osc = sc8[buf * (2 * BQ8 * 2) + BQ8 * 2 + row * 2 + lh];
+      f32x16 s, dp;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 cl = *reinterpret_cast<const f32x4*>(rc + 8 * g + 4 * lh), cd = *reinterpret_cast<const f32x4*>(rc + 64 + 8 * g + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { s[4 * g + e] = cl[e]; dp[4 * g + e] = cd[e]; }
+      }
+      s = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa, kf, s, 0, 0, 0, qsc, 0, kscale);
+      dp = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(oa, vf, dp, 0, 0, 0, osc, 0, vscale);
+      const bool clean = full && wave_keys_ok;
+      if (!clean) {          // blocked (query, key) pairs: -32768 on top of the score, exp2 is exactly 0
+        const bf16x8 qbf = *reinterpret_cast<const bf16x8*>(qblk_s + buf * (BQ8 * 16) + (sub * 32 + l31) * 16 + 8 * lh);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qbf, khf, s, 0, 0, 0);
+      }
+      u32x4v pbw[2], sbw[2];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
+        pbw[r >> 3][(r & 7) >> 1] = pack2bf_pk(p0, p1);
+        sbw[r >> 3][(r & 7) >> 1] = pack2bf_pk(p0 * dp[r], p1 * dp[r + 1]);
+      }
+      // dV^T += dO^T P ; dK^T += Q^T dS  (bf16 operands, transposed reads of the bf16 tiles)
+#pragma unroll
+      for (int sp = 0; sp < 2; sp++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+          bf16x8 ot, qtf;
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            const int qr = 16 * sp + 8 * t + 4 * lh + tq;
+            const int d = n * 32 + 16 * tg + 4 * tp;
+            const bf16x4 o4 = lds_read_tr16(os + rt8_off(qr, d >> 3) + (d & 7));
+            const bf16x4 q4 = lds_read_tr16(qs + rt8_off(qr, d >> 3) + (d & 7));
+#pragma unroll
+            for (int e = 0; e < 4; e++) { ot[4 * t + e] = o4[e]; qtf[4 * t + e] = q4[e]; }
+          }
+          dv[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot, *reinterpret_cast<const bf16x8*>(&pbw[sp]), dv[n], 0, 0, 0);
+          dk[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, *reinterpret_cast<const bf16x8*>(&sbw[sp]), dk[n], 0, 0, 0);
+        }
+    }
+    if (it + 1 < n_it) swrite(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  if (mykey < a.nk) {
+    u16* dkp = a.dk + (int64_t)b * a.dkv_bstride + (int64_t)mykey * a.dkv_ld + h * DH;
+    u16* dvp = a.dv + (int64_t)b * a.dkv_bstride + (int64_t)mykey * a.dkv_ld + h * DH;
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int d = n * 32 + 8 * g + 4 * lh;
+        uint2 pk;
+        pk.x = pack2bf(dk[n][4 * g] * dk_scale, dk[n][4 * g + 1] * dk_scale);
+        pk.y = pack2bf(dk[n][4 * g + 2] * dk_scale, dk[n][4 * g + 3] * dk_scale);
+        *reinterpret_cast<uint2*>(dkp + d) = pk;
+        const f32x4 dvm = *reinterpret_cast<const f32x4*>(dvm_s + d);
+        pk.x = pack2bf(dv[n][4 * g] + dvm[0], dv[n][4 * g + 1] + dvm[1]);
+        pk.y = pack2bf(dv[n][4 * g + 2] + dvm[2], dv[n][4 * g + 3] + dvm[3]);
+        *reinterpret_cast<uint2*>(dvp + d) = pk;
+      }
+  }
+}
+
+extern "C" int mca_attn_bwd_dkv_fp8(const mca_attn_bwd2_args* a, const mca_attn_fp8_bwd_operands* f, mca_stream_t stream) {
+  const int rc = check_bwd8(a, f);
+  if (rc != MCA_OK) return rc;
+  if (!a->dk || !a->dv || !a->dvmean || !a->k_wg || !a->k_qt) return MCA_E_BADARG;
+  if (a->kblock_keys != 128) return MCA_E_UNSUPPORTED;
+  if (a->n_qtiles64 != (a->nq + BQ8 - 1) / BQ8 || a->n_kblocks256 != (a->nk + 127) / 128) return MCA_E_BADARG;
+  if (a->nk_pad < a->n_kblocks256 * 128) return MCA_E_BADARG;
+  if (a->dkv_ld % 4 || a->dkv_bstride % 4 || (uintptr_t)a->dk % 8 || (uintptr_t)a->dv % 8 || (uintptr_t)a->k_wg % 16) return MCA_E_ALIGN;
+  if (a->n_qtiles64 > MAX_QTILES8) return MCA_E_UNSUPPORTED;
+  int dev = 0;
+  static bool attr_set[64] = {false};          // the attribute is per device
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MCA_E_LAUNCH;
+  if (!attr_set[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DKV8_LDS_BYTES) != hipSuccess)
+      return MCA_E_LAUNCH;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_dkv8_kernel, dim3(a->n_kblocks256, a->heads, a->batch), dim3(256), DKV8_LDS_BYTES, as_stream(stream), *a, *f, mca_knobs[9]);
+  return launch_status();
+}

@@ -27,7 +27,7 @@ import torch
 
 from . import hip
 from .encoders import EmbeddedSequenceEncoder, NativeEncoder, TabularEncoder
-from .hip import AttnBwd2Args, AttnBwdArgs, AttnFp8Operands, AttnFwdArgs, LossTerm, call, ptr, stream_ptr
+from .hip import AttnBwd2Args, AttnBwdArgs, AttnFp8BwdOperands, AttnFp8Operands, AttnFwdArgs, LossTerm, call, ptr, stream_ptr
 
 LN_EPS = 1e-5
 FWD_BQ, FWD_BK = 128, 64
@@ -238,9 +238,11 @@ class FusionEngine:
         self._cast_list.append(hip.CastDesc(ptr(src), ptr(d), src.stride(0), r, c, dst.stride(0), rp, cp, int(transpose), float(scale)))
 
     def set_attention_dtype(self, dtype: str):
-        """'bf16' (default) or 'fp8': the fusion layers' forward attention computes Q K^T and P V on the block-scaled fp8 matrix
-        instruction from MX-fp8 copies of q, k, v (one quantisation pass per layer, mca_attn_quant_mxfp8); pooling attention
-        and the whole backward stay in bf16 (BASELINE configs[4])."""
+        """'bf16' (default) or 'fp8' (BASELINE configs[4]): the fusion layers' forward attention computes Q K^T and P V on the
+        block-scaled fp8 matrix instruction from MX-fp8 copies of q, k, v (one quantisation pass per layer,
+        mca_attn_quant_mxfp8), and their backward recomputes S = Q K^T and dP = dO V^T on it (mca_attn_quant_bwd_mxfp8 +
+        mca_attn_bwd_dq_fp8 / mca_attn_bwd_dkv_fp8; the three gradient products stay bf16; needs the mask product and
+        128-key dkv blocks, else the backward keeps bf16 recomputes).  Pooling attention stays bf16."""
         if dtype not in ("bf16", "fp8"):
             raise ValueError(dtype)
         if dtype == "fp8" and not (self.attn_flags & hip.ATTN_Q_PRESCALED):
@@ -259,6 +261,24 @@ class FusionEngine:
             f.n_ktiles = nt
             ws["fp8"] = (bufs, f)
         return ws["fp8"][1]
+
+    def _fp8_bwd_operands(self, ws, b):
+        """one set of MX-fp8 backward operand buffers per workspace (q, k, v, dO quantised along d; every layer reuses it)"""
+        if "fp8b" not in ws:
+            nt = (self.N + 63) // 64
+            u8 = lambda *s: torch.zeros(*s, dtype=torch.uint8, device=self.device)
+            bufs = {k: u8(b, self.H, nt * 64, 64) for k in ("q8", "k8", "v8", "do8")}
+            bufs.update({k: u8(b, self.H, nt * 64, 2) for k in ("qs", "ks", "vs", "dos")})
+            f = AttnFp8BwdOperands()
+            for k in ("q8", "qs", "k8", "ks", "v8", "vs", "do8", "dos"):
+                setattr(f, k, bufs[k].data_ptr())
+            f.n_ktiles = nt
+            ws["fp8b"] = (bufs, f)
+        return ws["fp8b"][1]
+
+    def fp8_backward_on(self, ws, nq) -> bool:
+        return (self.attn_dtype == "fp8" and nq == self.N and ws.get("khot") is not None and self.dkv_keys == 128
+                and bool(self.attn_flags & hip.ATTN_Q_PRESCALED) and self.attn_bwd_two_pass)
 
     def invalidate_weights(self):
         """Call after writing parameters through an alias autograd's version counters cannot see (``p.data.op_()``, a raw
@@ -495,8 +515,15 @@ class FusionEngine:
         hip.set_tag("pool" if nq != N else "layer")
         # algorithmic flops of the whole backward (2 x forward) split 3 : 5 over the passes by their share of the five
         # products a one-pass backward needs (dq pass: S, dP, dQ minus the recomputed S, dP counted once)
-        call("mca_attn_bwd_dkv", C.byref(a), stream_ptr(), flops=8.0 * 64 * pairs * self.H * b * 0.6)
-        call("mca_attn_bwd_dq", C.byref(a), stream_ptr(), flops=8.0 * 64 * pairs * self.H * b * 0.4)
+        if self.fp8_backward_on(ws, nq):
+            f = self._fp8_bwd_operands(ws, b)
+            call("mca_attn_quant_bwd_mxfp8", a.q, a.q_bstride, a.q_ld, a.k, a.v, a.kv_bstride, a.kv_ld, a.d_o, a.o_bstride, a.o_ld,
+                 C.byref(f), b, self.H, N, stream_ptr())
+            call("mca_attn_bwd_dkv_fp8", C.byref(a), C.byref(f), stream_ptr(), flops=8.0 * 64 * pairs * self.H * b * 0.6)
+            call("mca_attn_bwd_dq_fp8", C.byref(a), C.byref(f), stream_ptr(), flops=8.0 * 64 * pairs * self.H * b * 0.4)
+        else:
+            call("mca_attn_bwd_dkv", C.byref(a), stream_ptr(), flops=8.0 * 64 * pairs * self.H * b * 0.6)
+            call("mca_attn_bwd_dq", C.byref(a), stream_ptr(), flops=8.0 * 64 * pairs * self.H * b * 0.4)
         hip.set_tag("")
 
     def _attn_bwd(self, q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, d_o, lse, delta, dq, dq_bstride, dkv, dk_off,

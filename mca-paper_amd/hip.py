@@ -91,6 +91,11 @@ class AttnFp8Operands(C.Structure):
                 ("n_ktiles", C.c_int)]
 
 
+class AttnFp8BwdOperands(C.Structure):
+    _fields_ = [("q8", C.c_void_p), ("qs", C.c_void_p), ("k8", C.c_void_p), ("ks", C.c_void_p), ("v8", C.c_void_p), ("vs", C.c_void_p),
+                ("do8", C.c_void_p), ("dos", C.c_void_p), ("n_ktiles", C.c_int)]
+
+
 class AttnBwd2Args(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("q_bstride", C.c_int64), ("q_ld", C.c_int64),
@@ -147,6 +152,9 @@ SIGNATURES = {
     "mca_attn_bwd": (_I, [C.POINTER(AttnBwdArgs), _P]),
     "mca_attn_bwd_dq": (_I, [C.POINTER(AttnBwd2Args), _P]),
     "mca_attn_bwd_dkv": (_I, [C.POINTER(AttnBwd2Args), _P]),
+    "mca_attn_quant_bwd_mxfp8": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _P, _I64, _I64, C.POINTER(AttnFp8BwdOperands), _I, _I, _I, _P]),
+    "mca_attn_bwd_dq_fp8": (_I, [C.POINTER(AttnBwd2Args), C.POINTER(AttnFp8BwdOperands), _P]),
+    "mca_attn_bwd_dkv_fp8": (_I, [C.POINTER(AttnBwd2Args), C.POINTER(AttnFp8BwdOperands), _P]),
     "mca_contrastive_workspace_bytes": (_I64, [_I, _I]),
     "mca_contrastive_fwd_bwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "mca_grad_sqnorm": (_I, [_P, _I64, _P, _P]),

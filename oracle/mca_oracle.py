@@ -35,7 +35,8 @@ class Prec:
     def __init__(self, mode: str = "fp32"):
         assert mode in ("fp32", "fp64", "bf16emu", "fp8emu")
         # fp8emu = bf16emu + MX-fp8 (e4m3, power-of-two scale per 32 elements) operands of Q K^T and P V in the SELF-attention
-        # layers, as mca_attn_quant_mxfp8 / mca_attn_fwd_fp8 compute them (BASELINE configs[4]); gradients straight-through
+        # layers, as mca_attn_quant_mxfp8 / mca_attn_fwd_fp8 compute them, and the fp8 score recomputes of their backward
+        # (BASELINE configs[4]; _Fp8AttentionCore restates both directions, nothing is straight-through there)
         self.fp8 = mode == "fp8emu"
         if self.fp8:
             mode = "bf16emu"
@@ -82,24 +83,77 @@ def mx_e4m3(x: torch.Tensor, dim: int = -1) -> torch.Tensor:
     return x + (q - x.detach())
 
 
+def _mx(x: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    """mx_e4m3 without the straight-through identity (plain values)"""
+    return mx_e4m3(x.detach(), dim)
+
+
+def _bf(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _Fp8AttentionCore(torch.autograd.Function):
+    """The MX-fp8 self-attention of BASELINE configs[4] with the arithmetic of BOTH directions of the HIP path
+    (mca-paper_amd/csrc/attention_fp8.hip), not a straight-through estimate:
+
+    forward  (mca_attn_quant_mxfp8 + mca_attn_fwd_fp8): S = MX(q2) . MX(k)^T in the log2 domain (blocks of 32 along d),
+             m = row maximum over the allowed keys, P = 2^(S - m), l = sum of the UNROUNDED P, O = e4m3(128 P) . MX_keys(V) / 128 l
+             (V quantised in blocks of 32 consecutive keys); a row with every key blocked is uniform over all n keys (mean of V);
+             lse = m + log2 l.
+    backward (mca_attn_bwd_prep + mca_attn_quant_bwd_mxfp8 + mca_attn_bwd_dq_fp8 / mca_attn_bwd_dkv_fp8): delta = rowsum(dO o
+             bf16(O)); S recomputed from the SAME MX(q2), MX(k); P = 2^(S - lse) (0 on blocked pairs and on uniform rows);
+             dP = MX(dO) . MX_d(V)^T with BOTH operands quantised along d; dS = P o (dP - delta); P and dS rounded to bf16 feed the
+             three gradient products with bf16 operands: dV = P^T dO (+ mean of dO over the uniform rows / n), dK = ln2 dS^T q2,
+             dq2 = ln2 dS k   (q2 = q . scale . log2 e: the log2-domain query the kernels see)."""
+
+    @staticmethod
+    def forward(ctx, q2, k, v, blocked):
+        b, h, n, d = q2.shape
+        n_pad = (n + 31) // 32 * 32
+        q8, k8 = _mx(q2), _mx(k)
+        v8 = _mx(torch.nn.functional.pad(v.detach(), (0, 0, 0, n_pad - n)), 2)[:, :, :n, :]
+        s2 = torch.einsum("bhid,bhjd->bhij", q8, k8).masked_fill(blocked, float("-inf"))
+        m = s2.max(dim=-1, keepdim=True).values
+        uniform = torch.isinf(m) & (m < 0)
+        e = torch.exp2(s2 - torch.where(uniform, torch.zeros_like(m), m))
+        l = e.sum(-1, keepdim=True)
+        p8 = (128.0 * e).to(torch.float8_e4m3fn).to(e.dtype)
+        out = torch.einsum("bhij,bhjd->bhid", p8, v8) / (128.0 * l.clamp_min(1e-30))
+        out = torch.where(uniform, v.detach().mean(dim=2, keepdim=True).expand_as(out), out)
+        lse = torch.where(uniform, torch.full_like(m, float("inf")), m + torch.log2(l.clamp_min(1e-30)))
+        ctx.save_for_backward(q2.detach(), k.detach(), v.detach(), blocked, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        q2, k, v, blocked, out, lse = ctx.saved_tensors
+        return (*fp8_attention_backward(q2, k, v, blocked, out, lse, d_out), None)
+
+
+def fp8_attention_backward(q2, k, v, blocked, out, lse, d_out):
+    """(dq2, dk, dv) of _Fp8AttentionCore from the saved forward results ``out`` (b,h,n,64) and ``lse`` (b,h,n,1; +inf marks a
+    uniform row): the arithmetic of mca_attn_bwd_prep + mca_attn_quant_bwd_mxfp8 + mca_attn_bwd_dq_fp8 / mca_attn_bwd_dkv_fp8
+    (see the class docstring).  A kernel test may pass the kernel's own forward results to isolate the backward."""
+    n = q2.shape[2]
+    d_o = _bf(d_out)
+    delta = (d_o * _bf(out)).sum(-1, keepdim=True)
+    s2 = torch.einsum("bhid,bhjd->bhij", _mx(q2), _mx(k))
+    p = torch.exp2(s2 - lse).masked_fill(blocked, 0.0)          # lse = +inf on uniform rows: P = 0
+    dp = torch.einsum("bhid,bhjd->bhij", _mx(d_o), _mx(v))
+    ds = p * (dp - delta)
+    pb, dsb = _bf(p), _bf(ds)
+    uniform = torch.isinf(lse)
+    dvmean = (d_o * uniform).sum(dim=2, keepdim=True) / n
+    dv = torch.einsum("bhij,bhid->bhjd", pb, d_o) + dvmean
+    ln2 = 0.6931471805599453
+    dk = ln2 * torch.einsum("bhij,bhid->bhjd", dsb, _bf(q2))
+    dq2 = ln2 * torch.einsum("bhij,bhjd->bhid", dsb, _bf(k))
+    return dq2, dk, dv
+
+
 def fp8_attention_core(q2, k, v, blocked):
-    """q2 (b,h,n,64) already in the log2 domain (scale * log2 e folded in), k, v (b,h,n,64), blocked (b,1|h,n,n) bool.
-    MX-fp8 Q, K (blocks of 32 along d) and V (blocks of 32 consecutive keys), P fed as e4m3(128 * 2^(S - m)), row sum of the
-    unrounded P; a row with every key blocked is uniform over all n keys (reference semantics)."""
-    b, h, n, d = q2.shape
-    n_pad = (n + 31) // 32 * 32
-    q8, k8 = mx_e4m3(q2, -1), mx_e4m3(k, -1)
-    v8 = mx_e4m3(torch.nn.functional.pad(v, (0, 0, 0, n_pad - n)), 2)[:, :, :n, :]
-    s2 = torch.einsum("bhid,bhjd->bhij", q8, k8)
-    s2 = s2.masked_fill(blocked, float("-inf"))
-    m = s2.max(dim=-1, keepdim=True).values
-    uniform = torch.isinf(m) & (m < 0)
-    e = torch.exp2(s2 - torch.where(uniform, torch.zeros_like(m), m))
-    l = e.sum(-1, keepdim=True)
-    e128 = 128.0 * e
-    p8 = e128 + ((e128.detach().to(torch.float8_e4m3fn).to(e.dtype)) - e128.detach())
-    out = torch.einsum("bhij,bhjd->bhid", p8, v8) / (128.0 * l.clamp_min(1e-30))
-    return torch.where(uniform, v.mean(dim=2, keepdim=True).expand_as(out), out)
+    """q2 (b,h,n,64) already in the log2 domain (scale * log2 e folded in), k, v (b,h,n,64), blocked (b,1|h,n,n) bool."""
+    return _Fp8AttentionCore.apply(q2, k, v, blocked)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -692,6 +692,146 @@ def test_attention_fp8_forward(H, shape):
     assert (lse[:, 0][fin] - lse_ref[fin]).abs().max() < 2e-2
 
 
+@pytest.mark.parametrize("shape", ["small", "cmu", "long"])
+def test_attention_fp8_backward(H, shape):
+    """BASELINE configs[4], backward: S = Q K^T and dP = dO V^T recomputed on the block-scaled fp8 matrix instruction in both
+    passes (mca_attn_quant_bwd_mxfp8 + mca_attn_bwd_dq_fp8 / mca_attn_bwd_dkv_fp8), gradient products in bf16.  Checked against
+    the oracle's restatement of the same arithmetic (oracle._Fp8AttentionCore.backward): the four quantised operands value for
+    value, dq / dk / dv within a STATED 2e-2 rel-L2 (accumulation order, fp32 exp2, and delta from the kernel's own bf16 O), and
+    against the exact fp64 gradients: within 1.1 x the emulation's own distance + 5e-3 (what e4m3 operands cost on this stress
+    input).  Bitwise repeatable."""
+    from oracle import mca_oracle as O
+    S = importlib.import_module("mca-paper_amd.structure")
+    eng = importlib.import_module("mca-paper_amd.engine")
+    if shape == "small":
+        st, b, heads = S.FusionStructure([70, 45, 30], 8, (3, 2), fcl=True), 3, 2
+    elif shape == "cmu":
+        st, b, heads = S.FusionStructure([1500, 450, 450, 50], 88, (4, 3, 2), fcl=True), 2, 2
+    else:
+        st, b, heads = S.FusionStructure([1500, 1500, 1500, 1500], 88, (4, 3, 2), fcl=True), 1, 1          # N = 6088
+    dev = "cuda"
+    N, D = st.n_tokens, heads * 64
+    g = torch.Generator(device=dev).manual_seed(23)
+    sf = eng._Sched(st.attn_schedule(128, 64), dev)
+    sb = eng._Sched(st.attn_schedule(64, 128), dev)
+    qmask = torch.from_numpy(st.qmask_attn.astype(np.uint32).view(np.int32)).to(dev)
+    bits = (st.qmask_attn.astype(np.uint32)[:, None] >> np.arange(16, dtype=np.uint32)[None, :]) & 1
+    bits[:, 15] = 0
+    qblk = torch.from_numpy(np.where(bits == 1, 0.0, -32768.0).astype(np.float32)).to(torch.bfloat16).to(dev).contiguous()
+    kgroup = torch.from_numpy(st.kgroup).to(dev)
+    allowed = torch.from_numpy(~st.dense_attn_mask()).to(dev)
+    pad = torch.zeros(b, N, dtype=torch.bool, device=dev)
+    off = 0
+    for mi, n in enumerate(st.token_dims):
+        ln = torch.randint(1, n + 1, (b,), generator=g, device=dev)
+        if mi == 0:
+            ln[0] = 0                                   # a dropped modality: uniform rows
+        pad[:, off:off + n] = torch.arange(n, device=dev)[None] >= ln[:, None]
+        off += n
+    qkv = torch.randn(b, N, 3 * D, device=dev, generator=g)
+    qkv[:, :, D:2 * D] *= torch.exp2(torch.randint(-2, 3, (b, N, 1), device=dev, generator=g).float())
+    qkv = bf(qkv)
+    qkv[:, :, :D] = bf(qkv[:, :, :D].float() * C2)
+    d_o = bf(torch.randn(b * N, D, device=dev, generator=g) * torch.exp2(torch.randint(-2, 3, (b * N, 1), device=dev, generator=g).float()))
+    nk_pad = (N + 255) // 256 * 256
+    nt = (N + 63) // 64
+    keyinfo = torch.empty(b, nk_pad, dtype=torch.uint8, device=dev)
+    kflags = torch.empty(b, nt, dtype=torch.uint8, device=dev)
+    H.call("mca_build_keyinfo", pad.to(torch.uint8).data_ptr(), kgroup.data_ptr(), keyinfo.data_ptr(), kflags.data_ptr(), b, N, nk_pad, H.stream_ptr())
+    khot = torch.empty(b, nk_pad, 16, dtype=torch.bfloat16, device=dev)
+    H.call("mca_build_keyhot", keyinfo.data_ptr(), khot.data_ptr(), b, nk_pad, H.stream_ptr())
+    vmean = torch.empty(b, D, device=dev)
+    kptr, vptr = qkv.data_ptr() + D * 2, qkv.data_ptr() + 2 * D * 2
+    H.call("mca_attn_vmean", vptr, N * 3 * D, 3 * D, vmean.data_ptr(), b, N, heads, H.stream_ptr())
+    u8 = lambda *s_: torch.zeros(*s_, dtype=torch.uint8, device=dev)
+    f = H.AttnFp8Operands()
+    fb_ = {k: (u8(b, heads, nt, 64, 64) if k == "v8t" else u8(b, heads, nt, 64, 2) if k == "vs" else u8(b, heads, nt * 64, 64 if k.endswith("8") else 2))
+           for k in ("q8", "qs", "k8", "ks", "v8t", "vs")}
+    for k_, t in fb_.items():
+        setattr(f, k_, t.data_ptr())
+    f.n_ktiles = nt
+    H.call("mca_attn_quant_mxfp8", qkv.data_ptr(), N * 3 * D, 3 * D, kptr, vptr, N * 3 * D, 3 * D, C.byref(f), b, heads, N, H.stream_ptr())
+    o = torch.zeros(b * N, D, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(b, heads, N, device=dev)
+    a = H.AttnFwdArgs()
+    a.q, a.q_bstride, a.q_ld = qkv.data_ptr(), N * 3 * D, 3 * D
+    a.k, a.v, a.kv_bstride, a.kv_ld = kptr, vptr, N * 3 * D, 3 * D
+    a.o, a.o_bstride, a.o_ld, a.lse = o.data_ptr(), N * D, D, lse.data_ptr()
+    a.qmask, a.keyinfo, a.ktile_flags = qmask.data_ptr(), keyinfo.data_ptr(), kflags.data_ptr()
+    a.q_ptr, a.q_kt, a.q_order = sf.q_ptr.data_ptr(), sf.q_kt.data_ptr(), sf.q_order.data_ptr()
+    a.vmean, a.khot = vmean.data_ptr(), khot.data_ptr()
+    a.batch, a.heads, a.nq, a.nk, a.nk_pad, a.n_qtiles, a.n_ktiles, a.scale = b, heads, N, N, nk_pad, sf.s.n_q, sf.s.n_k, 0.125
+    a.flags = H.ATTN_Q_PRESCALED
+    H.call("mca_attn_fwd_fp8", C.byref(a), C.byref(f), H.stream_ptr())
+    # ---- backward
+    delta = torch.empty(b, heads, N, device=dev)
+    dvmean = torch.empty(b, D, device=dev)
+    H.call("mca_attn_bwd_prep", o.data_ptr(), d_o.data_ptr(), N * D, D, lse.data_ptr(), delta.data_ptr(), dvmean.data_ptr(), b, heads, N, N, H.stream_ptr())
+    fo = H.AttnFp8BwdOperands()
+    ob = {k: u8(b, heads, nt * 64, 64 if k.endswith("8") else 2) for k in ("q8", "qs", "k8", "ks", "v8", "vs", "do8", "dos")}
+    for k_, t in ob.items():
+        setattr(fo, k_, t.data_ptr())
+    fo.n_ktiles = nt
+    H.call("mca_attn_quant_bwd_mxfp8", qkv.data_ptr(), N * 3 * D, 3 * D, kptr, vptr, N * 3 * D, 3 * D, d_o.data_ptr(), N * D, D, C.byref(fo), b, heads, N, H.stream_ptr())
+    torch.cuda.synchronize()
+    sp4 = lambda t: t.float().view(b, N, heads, 64).permute(0, 2, 1, 3)
+    q4, k4, v4, do4 = sp4(qkv[:, :, :D]), sp4(qkv[:, :, D:2 * D]), sp4(qkv[:, :, 2 * D:]), sp4(d_o.view(b, N, D))
+    deq = lambda x8, xs: x8.view(torch.float8_e4m3fn).float().view(*x8.shape[:-1], 2, 32) * torch.exp2(xs.float() - 127.0)[..., None]
+    for name, ref in (("q", q4), ("k", k4), ("v", v4), ("do", do4)):
+        got = deq(ob[name + "8"], ob[name + "s"]).flatten(-2)
+        assert torch.equal(got[:, :, :N], O.mx_e4m3(ref, -1)), name
+        assert float(got[:, :, N:].abs().max()) == 0 if nt * 64 > N else True
+    assert torch.equal(ob["q8"], fb_["q8"]) and torch.equal(ob["k8"], fb_["k8"])          # the forward's operands, bit for bit
+    dqkv = torch.zeros(b * N, 3 * D, dtype=torch.bfloat16, device=dev)
+
+    def run():
+        dqkv.zero_()
+        a2 = H.AttnBwd2Args()
+        a2.q, a2.q_bstride, a2.q_ld = qkv.data_ptr(), N * 3 * D, 3 * D
+        a2.k, a2.v, a2.kv_bstride, a2.kv_ld = kptr, vptr, N * 3 * D, 3 * D
+        a2.d_o, a2.o_bstride, a2.o_ld = d_o.data_ptr(), N * D, D
+        a2.lse, a2.delta, a2.dvmean = lse.data_ptr(), delta.data_ptr(), dvmean.data_ptr()
+        a2.dq, a2.dq_bstride, a2.dq_ld, a2.dq_f32 = dqkv.data_ptr(), N * 3 * D, 3 * D, 0
+        a2.dk, a2.dv, a2.dkv_bstride, a2.dkv_ld = dqkv.data_ptr() + D * 2, dqkv.data_ptr() + 2 * D * 2, N * 3 * D, 3 * D
+        a2.qmask, a2.keyinfo, a2.ktile_flags = qmask.data_ptr(), keyinfo.data_ptr(), kflags.data_ptr()
+        a2.q_ptr, a2.q_kt, a2.q_order, a2.n_qtiles128, a2.n_ktiles64 = sf.q_ptr.data_ptr(), sf.q_kt.data_ptr(), sf.q_order.data_ptr(), sf.s.n_q, sf.s.n_k
+        a2.k_wg, a2.k_qt, a2.n_qtiles64, a2.n_kblocks256 = sb.k_wg.data_ptr(), sb.k_qt.data_ptr(), sb.s.n_q, sb.s.n_k
+        a2.batch, a2.heads, a2.nq, a2.nk, a2.nk_pad, a2.scale, a2.flags = b, heads, N, N, nk_pad, 0.125, H.ATTN_Q_PRESCALED
+        a2.khot, a2.qblk, a2.kblock_keys = khot.data_ptr(), qblk.data_ptr(), 128
+        H.call("mca_attn_bwd_dkv_fp8", C.byref(a2), C.byref(fo), H.stream_ptr())
+        H.call("mca_attn_bwd_dq_fp8", C.byref(a2), C.byref(fo), H.stream_ptr())
+        torch.cuda.synchronize()
+        return dqkv.clone()
+
+    g1, g2 = run(), run()
+    assert torch.equal(g1, g2)                                   # no atomics: bitwise repeatable
+    # ---- the oracle's restatement of both directions
+    blocked = (~allowed)[None, None] | pad[:, None, None, :]
+    # (a) both directions emulated; (b) the backward alone, from the KERNEL's forward results (o, lse): isolates the two
+    # backward kernels from the forward's own rounding (delta = rowsum(dO o O) amplifies an O difference on peaked rows)
+    qe, ke, ve = (t.clone().requires_grad_(True) for t in (q4, k4, v4))
+    oe = O.fp8_attention_core(qe, ke, ve, blocked)
+    oe.backward(do4)
+    iso = O.fp8_attention_backward(q4, k4, v4, blocked, sp4(o.view(b, N, D)), lse[..., None], do4)
+    # exact fp64 attention gradients on the same (bf16) inputs; q4 is the log2-domain query: S = q4 . k * ln 2
+    qx, kx, vx = (t.double().clone().requires_grad_(True) for t in (q4, k4, v4))
+    sx = (torch.einsum("bhid,bhjd->bhij", qx, kx) * 0.6931471805599453).masked_fill(blocked, -torch.finfo(torch.float64).max)
+    torch.einsum("bhij,bhjd->bhid", sx.softmax(-1), vx).backward(do4.double())
+    got = g1.float().view(b, N, 3, heads, 64).permute(2, 0, 3, 1, 4)          # (3, b, h, N, 64)
+    # the kernel's dq is the gradient w.r.t. the UNSCALED q (= dq2 * scale * log2 e, include/mca_hip.h)
+    for i, (name, emu, exact, fac) in enumerate((("dq", qe.grad, qx.grad, C2), ("dk", ke.grad, kx.grad, 1.0), ("dv", ve.grad, vx.grad, 1.0))):
+        e_emu, e_exact, e_floor = rel(got[i], emu * fac), rel(got[i], (exact * fac).float()), rel(emu * fac, (exact * fac).float())
+        e_iso = rel(got[i], iso[i] * fac)
+        assert e_emu < 2e-2, f"{name}: fp8 backward vs its emulation {e_emu}"
+        assert e_iso < 1e-2, f"{name}: fp8 backward kernels vs their restatement on the kernel's own forward results {e_iso}"
+        assert e_exact < 1.1 * e_floor + 5e-3, f"{name}: vs exact {e_exact} (emulation itself {e_floor})"
+        # per-row check (a wrong sub-tile hides in the global norm); rows with a near-zero gradient are measured against a
+        # twentieth of the mean row norm
+        rn = (iso[i] * fac).norm(dim=-1)
+        rows = (got[i] - iso[i] * fac).norm(dim=-1) / (rn + 0.05 * rn.mean())
+        assert float(rows.max()) < 0.1, f"{name}: worst row {float(rows.max())} e_iso {e_iso}"
+
+
 # ------------------------------------------------------------------------------------------------ loss
 @pytest.mark.parametrize("variant,world", [("mca", 1), ("bimodal", 1), ("zorro", 1), ("mca", 2), ("bimodal", 4)])
 def test_contrastive_loss(H, variant, world):

@@ -236,12 +236,13 @@ def test_long_sequence_forward_vs_oracle(P):
 
 @pytest.mark.parametrize("variant", ["mca", "zorro"])
 def test_small_step_fp8_attention_vs_fp8emu_oracle(P, variant):
-    """engine.set_attention_dtype('fp8') (BASELINE configs[4]): the fusion layers' forward attention on MX-fp8 operands, the
-    backward in bf16 from the forward's log-sum-exp.  STATED TOLERANCES: pooled embeddings within 4e-3 rel-L2 of the oracle
-    emulating the same fp8 arithmetic (fp8emu; measured 0.7-1.1e-3) and within 6e-3 of the fp32 oracle (measured 1.3-1.6e-3:
-    at this size the e4m3 operands cost about what bf16 storage costs); gradients: per-tensor rel-L2 to the fp8emu oracle's
-    (straight-through) <= 0.12, median <= 0.04 (measured 0.05 / 0.014: the bf16 backward recomputes P from bf16 scores and
-    the fp8 forward's log-sum-exp; that inconsistency is what the bound prices)."""
+    """engine.set_attention_dtype('fp8') (BASELINE configs[4]): the fusion layers' attention with MX-fp8 operands in BOTH
+    directions (forward Q K^T and P V; backward the S and dP recomputes of both passes, gradient products in bf16).  The oracle's
+    fp8emu mode restates the same arithmetic in both directions (oracle._Fp8AttentionCore: nothing straight-through).  STATED
+    TOLERANCES: pooled embeddings within 4e-3 rel-L2 of fp8emu (measured 0.7-1.1e-3) and within 6e-3 of the fp32 oracle
+    (measured 1.3-1.6e-3: at this size the e4m3 operands cost about what bf16 storage costs); gradients: per-tensor rel-L2 to
+    fp8emu <= 0.08, median <= 0.03 (measured 0.045-0.050 / 0.010-0.014: delta = rowsum(dO o O) is taken from the kernel's own
+    bf16 O, whose rounding differs from the emulation's, and the whole chain below the attention runs in bf16)."""
     from oracle import mca_oracle as O
     cfg = small_config(variant)
     batch = P.data.synthetic_batch(cfg, 6, seed=5, p_drop=0.3)
@@ -274,7 +275,8 @@ def test_small_step_fp8_attention_vs_fp8emu_oracle(P, variant):
         errs.append((rel_err(p.grad.cpu(), gref), n))
     errs.sort()
     print("fp8 step", variant, "grad errs median", errs[len(errs) // 2], "max", errs[-1])
-    assert errs[-1][0] <= 0.12 and errs[len(errs) // 2][0] <= 0.04, (errs[-1], errs[len(errs) // 2])
+    assert errs[-1][0] <= 0.08 and errs[len(errs) // 2][0] <= 0.03, (errs[-1], errs[len(errs) // 2])
+    assert model.engine.fp8_backward_on(model.engine.workspace(6), model.engine.N)          # the fp8 backward really ran
 
 
 def test_dropin_loop_and_no_loss(P):
