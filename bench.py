@@ -78,9 +78,10 @@ def host_cpu():
 
 def cpu_baseline(P, workload: str, variant: str, protocol: str):
     """the oracle's full step (fwd + bwd + clip + AdamW), fp32, b = 8, the same synthetic CMU-shaped
-    batch generator, all physical cores this process may use (count and CPU model stated).  protocol 'short' (default, keeps
-    the bench within minutes): 1 warm-up + 3 timed steps; 'full': >= 3 warm-up + >= 5 timed steps and an 8-thread run beside
-    it (the figure comparable with BASELINE.md section 2's container numbers).  LONG: b = 1, 1 + 1 steps (N = 6088 dense)."""
+    batch generator (count of threads and CPU model stated).  protocol 'short' (default, keeps the bench within minutes):
+    1 warm-up + 3 timed steps on min(physical cores, 16) threads, and 1 + 2 steps on 8 threads (`value_8_threads`: the figure
+    comparable with BASELINE.md section 2's container numbers); 'full': 3 warm-up + 5 timed steps on every physical core
+    and on 8 threads.  LONG: b = 1, 1 + 1 steps (N = 6088 dense)."""
     from oracle import mca_oracle as O
     model, phys = host_cpu()
     long_seq = workload == "long"
@@ -105,7 +106,7 @@ def cpu_baseline(P, workload: str, variant: str, protocol: str):
             ts.append(time.perf_counter() - t0)
         return b * timed / sum(ts[warm:]), sum(ts)
 
-    warm, timed = (1, 1) if long_seq else ((3, 5) if protocol == "full" else (1, 2))
+    warm, timed = (1, 1) if long_seq else ((3, 5) if protocol == "full" else (1, 3))
     # default: the 16 host threads that are one GPU's share of the box (measured on the 2 x 64-core EPYC 9575F host: 0.59
     # samples/s on 16 threads, 0.32 on all 128: the oracle's small ops do not scale across sockets); 'full': every physical core
     threads = phys if protocol == "full" else min(phys, 16)
@@ -113,10 +114,11 @@ def cpu_baseline(P, workload: str, variant: str, protocol: str):
     out = {"value": round(v, 4), "unit": "samples/s", "cores": threads, "physical_cores": phys, "cpu_model": model, "kind": "port",
            "sample": f"{'LONG 4x1500' if long_seq else 'CMU 4-modality'} {variant.upper()} fp32 full step (fwd+bwd+clip+AdamW) "
                      f"at batch {b}, uniform lengths, {timed} timed steps after {warm} warm-up ({spent:.0f} s of CPU work on {threads} threads)"}
-    if protocol == "full" and not long_seq:
-        v8, spent8 = run(min(8, phys), 3, 5)
+    if not long_seq:
+        w8, t8 = (3, 5) if protocol == "full" else (1, 2)
+        v8, spent8 = run(min(8, phys), w8, t8)
         out["value_8_threads"] = round(v8, 4)
-        out["sample"] += f"; 8-thread run {spent8:.0f} s"
+        out["sample"] += f"; 8-thread run: {t8} timed steps after {w8} warm-up, {spent8:.0f} s"
     return out
 
 
@@ -240,12 +242,12 @@ def main():
 
     for w in range(args.warmup):
         exclusive = w == 0 and not args.no_kernel_timing and args.warmup > 1 and not use_graph      # also warm the schedule the sampled steps use
-        saved = (eng.overlap_wgrad, eng.micro_batches)
+        saved = eng.overlap_wgrad
         if exclusive:
-            eng.overlap_wgrad, eng.micro_batches = False, 1
+            eng.overlap_wgrad = False
         step()
-        eng.overlap_wgrad, eng.micro_batches = saved
-    timed = ("mca_attn_fwd", "mca_attn_fwd_fp8", "mca_attn_quant_mxfp8", "mca_attn_bwd", "mca_attn_bwd_dq", "mca_attn_bwd_dkv", "mca_attn_bwd_dq_fp8", "mca_attn_bwd_dkv_fp8", "mca_attn_quant_bwd_mxfp8", "mca_gemm_nt", "mca_gemm_nt_lnres", "mca_gemm_nt_geglu_fwd", "mca_gemm_nt_geglu_bwd",
+        eng.overlap_wgrad = saved
+    timed = ("mca_attn_fwd", "mca_attn_fwd_fp8", "mca_attn_quant_mxfp8", "mca_attn_bwd_dq", "mca_attn_bwd_dkv", "mca_attn_bwd_dq_fp8", "mca_attn_bwd_dkv_fp8", "mca_attn_quant_bwd_mxfp8", "mca_gemm_nt", "mca_gemm_nt_lnres", "mca_gemm_nt_geglu_fwd", "mca_gemm_nt_geglu_bwd",
              "mca_gemm_tn_acc", "mca_gemm_tn_acc_group")
     kernel_timing = not args.no_kernel_timing
     if world > 1:
@@ -261,17 +263,17 @@ def main():
         sampled += int(rec)
         if rec:
             torch.cuda.synchronize()          # sampled step starts on an empty queue ...
-            # ... and runs every kernel alone (no side-stream weight gradients, no half-batch interleave), so that an
+            # ... and runs every kernel alone (no side-stream weight gradients), so that an
             # event pair brackets ONE kernel's own duration; the other steps run the overlapped production schedule
-            saved = (eng.overlap_wgrad, eng.micro_batches)
-            eng.overlap_wgrad, eng.micro_batches = False, 1
+            saved = eng.overlap_wgrad
+            eng.overlap_wgrad = False
         if graphed is not None:
             loss = graphed.step(h2d() if host_batch is not None else None, eager=rec)          # (a sampled step of the replayed loop runs its body eagerly)
         else:
             loss = step()
         if rec:
             hip.profile_collect()             # its timing events are resolved and released right away
-            eng.overlap_wgrad, eng.micro_batches = saved
+            eng.overlap_wgrad = saved
     hip.profile_enable(True)
     torch.cuda.synchronize()
     if world > 1:

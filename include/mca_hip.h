@@ -262,31 +262,15 @@ int mca_attn_bwd_prep(const uint16_t* o, const uint16_t* d_o, int64_t o_bstride,
                       const float* lse, float* delta, float* dvmean,
                       int batch, int heads, int nq, int nk, mca_stream_t stream);
 
-typedef struct {
-  const uint16_t* q; int64_t q_bstride; int64_t q_ld;
-  const uint16_t* k; const uint16_t* v; int64_t kv_bstride; int64_t kv_ld;
-  const uint16_t* d_o; int64_t o_bstride; int64_t o_ld;
-  const float* lse; const float* delta; const float* dvmean;
-  float* dq; int64_t dq_bstride; int64_t dq_ld;           /* fp32, ACCUMULATED with atomics       */
-  uint16_t* dk; uint16_t* dv; int64_t dkv_bstride; int64_t dkv_ld;   /* bf16, written once        */
-  const uint32_t* qmask; const uint8_t* keyinfo; const uint8_t* ktile_flags;
-  const int32_t* k_ptr; const uint32_t* k_qt; const int32_t* k_order;   /* k_qt: query-tile index | (full << 31) */
-  int batch, heads, nq, nk, nk_pad, n_qtiles, n_ktiles;
-  float scale;
-  /* optional (may be NULL): per launch slot i < n_ktiles the four int32 {k_order[i], k_ptr[k_order[i]], number of entries,
-   * query tile of the first entry}: one 16-byte load at workgroup start instead of the k_order -> k_ptr -> k_qt chain    */
-  const int32_t* k_wg;
-  int flags;                        /* MCA_ATTN_* bits (MCA_ATTN_Q_PRESCALED)                      */
-} mca_attn_bwd_args;
-/* key block 256 (one workgroup), query step 64.                                                  */
-int mca_attn_bwd(const mca_attn_bwd_args* args, mca_stream_t stream);
-
-/* The same backward in two passes WITHOUT atomics (production path; float atomics run at ~1.3 TB/s chip-wide on MI355X and
- * put a 690 us floor under the one-pass kernel): every output element has one owner, results are bitwise reproducible.
+/* The backward runs in two passes WITHOUT atomics (float atomics run at ~1.3 TB/s chip-wide on MI355X: the 0.9 GB of fp32 dQ
+ * adds per layer put a 690 us floor under a one-pass kernel, which left the library in round 3): every output element has
+ * one owner, results are bitwise reproducible.  MCA_ATTN_Q_PRESCALED is required (MCA_E_UNSUPPORTED otherwise).
  *   mca_attn_bwd_dq : one workgroup per 128-row query tile, key tiles of 64 (the forward's schedule); dq written once,
  *                     bf16 (dq_f32 == 0) or fp32, no pre-zeroing.  Needs q_ptr / q_kt / q_order, n_qtiles128, n_ktiles64.
- *   mca_attn_bwd_dkv: one workgroup per 256-key block, query steps of 64 (the one-pass kernel's schedule); dk, dv bf16.
- *                     Needs k_wg (see mca_attn_bwd_args) / k_qt, n_qtiles64, n_kblocks256, dvmean.
+ *   mca_attn_bwd_dkv: one workgroup per 256- or 128-key block (kblock_keys), query steps of 64; dk, dv bf16.  Needs k_qt
+ *                     (per key block the list of 64-row query tiles | full << 31), k_wg (per launch slot the four int32
+ *                     {key block, first list entry, number of entries, query tile of the first entry}: one 16-byte load at
+ *                     workgroup start), n_qtiles64, n_kblocks256, dvmean.
  * Both need mca_attn_bwd_prep's delta (and dvmean).  The two launches are independent of each other.                     */
 typedef struct {
   const uint16_t* q; int64_t q_bstride; int64_t q_ld;

@@ -36,8 +36,8 @@ __device__ __forceinline__ int k_off(int r, int c) { return r * 64 + ((c ^ ((r >
 // fall into 4 distinct 64-byte bank quarters
 __device__ __forceinline__ int v_off(int r, int c) { return r * 64 + ((c ^ (((r >> 1) & 1) << 2)) << 3); }
 
-template <bool PRESCALED>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int dbg) {
+  constexpr bool PRESCALED = true;          // q arrives pre-scaled by scale * log2 e (MCA_ATTN_Q_PRESCALED, required)
   __shared__ __attribute__((aligned(16))) u16 lds[2 * 2 * AK * DH];   // K,V double-buffered: 32 KiB
   __shared__ __attribute__((aligned(16))) uint8_t kinfo[2][AK];
   __shared__ __attribute__((aligned(16))) u16 hot_s[2][AK * 16];   // one-hot key groups of the tile (mask product operand)
@@ -307,324 +307,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
 
 
 
-// =====================================================================================================
-// Forward, second form (production): the same tiling and operand paths as attn_fwd_kernel with the softmax arithmetic cut to
-// what the VALU cannot avoid.  The first form is VALU-issue-bound at d_head = 64 (per 32 x 64 block ~1,200 issue cycles of
-// fma / exp / add / max / cvt / rescale against 512 MFMA cycles); here, per score element, only v_exp_f32, half a v_max3,
-// one v_add and half a v_cvt_pk remain:
-//   * q arrives PRE-SCALED by scale * log2(e) (folded into the bf16 copy of W_q, MCA_ATTN_Q_PRESCALED): S is already in the
-//     log2 domain, no multiply;
-//   * the row reference m is the C operand of the first S MFMA (sixteen registers holding -m, rewritten only when m moves):
-//     the product comes out as S - m, no subtraction;
-//   * m is LAZY (guide T13): it moves only when a tile's scores exceed it by more than 2^TAU (or at a row's first valid key),
-//     decided with one ballot per tile; the accumulator rescale (16 v_pk_mul) and the cross-half maximum run only then.
-//     P <= 2^TAU = 256 in bf16 (8 significant bits at any magnitude), sums and O in fp32: same error as an exact maximum;
-//   * the row sum is kept per lane half (of the ROUNDED P, one v_dot2c per bf16 pair) and the halves meet once, in the epilogue;
-//   * the eight K fragment reads of a tile are issued together with counted waits; the tile list is read two entries ahead.
-// Softmax is shift-invariant, so the result is that of the exact-maximum form up to bf16 rounding of P.
-// =====================================================================================================
-#define FW2_TAU 8.0f
-#ifndef FW2_MINWAVES
-#define FW2_MINWAVES 2
-#endif
-#ifndef FW_ABL          // timing-only ablation builds of the second form (tools/ablate_fwd.py): 1 no exp, 2 plain adds for the row
-#define FW_ABL 0        // sum, 4 no P.V, 8 no S, 16 no LDS stage writes, 32 no barrier, 64 no row sum
-#endif
-typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-// LDS fragment read the compiler does not wait for: its completion is counted by hand (s_waitcnt lgkmcnt(N) below)
-#define FW_DSREAD128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
-#define FW_WAIT_LGKM(N) do { asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-// sum of the two bf16 halves of a packed pair into an fp32 accumulator (the ROUNDED values, see the kernel comment)
-__device__ __forceinline__ void dot2_ones(float& acc, uint32_t pk, uint32_t ones) {
-  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(pk), "v"(ones));
-}
-template <bool PRESCALED>
-__global__ __launch_bounds__(256, FW2_MINWAVES) void attn_fwd2_kernel(mca_attn_fwd_args a, int dbg) {
-  __shared__ __attribute__((aligned(16))) u16 lds[2 * 2 * AK * DH];   // K,V double-buffered: 32 KiB
-  __shared__ __attribute__((aligned(16))) uint8_t kinfo[2][AK];
-  __shared__ uint8_t flags_s[MAX_KTILES];
-  __shared__ uint32_t live_s[MAX_KTILES + 2];
-  __shared__ int n_live_s;
-  u16* Ks = lds;
-  u16* Vs = lds + 2 * AK * DH;
-
-  const int lin0 = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
-  const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y * gridDim.z));
-  const int qt = a.q_order[lin % (int)gridDim.x];
-  const int h = (lin / (int)gridDim.x) % (int)gridDim.y, b = lin / (int)(gridDim.x * gridDim.y);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int q0 = qt * AQ + wave * 32;
-  int qrow = q0 + l31;
-  const bool qvalid = qrow < a.nq;
-  if (qrow > a.nq - 1) qrow = a.nq - 1;
-
-  bf16x8 qf[4];
-  {
-    const u16* qp = a.q + (int64_t)b * a.q_bstride + (int64_t)qrow * a.q_ld + h * DH + 8 * lh;
-#pragma unroll
-    for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
-  }
-  const uint32_t qm = a.qmask[qrow];
-  const float c2 = a.scale * 1.4426950408889634f;      // only used when q is not pre-scaled
-
-  f32x16 o[2];
-#pragma unroll
-  for (int n = 0; n < 2; n++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) o[n][r] = 0.f;
-  f32x16 negm;                                   // -m of this lane's query row, the start value of every S accumulator
-#pragma unroll
-  for (int r = 0; r < 16; r++) negm[r] = 0.f;
-  float l_half = 0.f;                            // sum of the ROUNDED P over THIS lane half's keys
-  bool has_ref = false;                          // the row has seen a valid key (m is meaningful)
-
-  const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
-  const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
-  const uint8_t* kinfo_g = a.keyinfo + (int64_t)b * a.nk_pad;
-  {
-    const uint8_t* flags_g = a.ktile_flags + (int64_t)b * a.n_ktiles;
-    for (int i = tid; i < a.n_ktiles; i += 256) flags_s[i] = flags_g[i];
-  }
-  __syncthreads();
-
-  int srow[2], sc[2];
-  unsigned loff[2];
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int id = tid + 256 * i; srow[i] = id >> 3; sc[i] = id & 7;
-    loff[i] = (unsigned)(srow[i] * (int)a.kv_ld + sc[i] * 8);
-  }
-  const int last_kt = a.n_ktiles - 1;
-  bf16x8 rk[2], rv[2];
-  uint32_t rinfo = 0;
-  auto gload = [&](int kt) {
-    const u16* kb = kbase + (int64_t)kt * AK * a.kv_ld;
-    const u16* vb = vbase + (int64_t)kt * AK * a.kv_ld;
-    if (kt != last_kt) {
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        rk[i] = *reinterpret_cast<const bf16x8*>(kb + loff[i]);
-        rv[i] = *reinterpret_cast<const bf16x8*>(vb + loff[i]);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        int key = kt * AK + srow[i]; if (key > a.nk - 1) key = a.nk - 1;
-        rk[i] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * a.kv_ld + sc[i] * 8);
-        rv[i] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * a.kv_ld + sc[i] * 8);
-      }
-    }
-    if (tid < 16) rinfo = *reinterpret_cast<const uint32_t*>(kinfo_g + kt * AK + tid * 4);
-  };
-  auto swrite = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      *reinterpret_cast<bf16x8*>(Ks + buf * AK * DH + k_off(srow[i], sc[i])) = rk[i];
-      *reinterpret_cast<bf16x8*>(Vs + buf * AK * DH + v_off(srow[i], sc[i])) = rv[i];
-    }
-    if (tid < 16) *reinterpret_cast<uint32_t*>(&kinfo[buf][tid * 4]) = rinfo;
-  };
-
-  // live tile list of this query tile: entries whose key tile has a valid key in this sample; bit 31 = no element-wise mask
-  // needed (structurally full AND every key valid), so the loop never looks at the flags again
-  if (wave == 0) {
-    const int lb = a.q_ptr[qt], le = a.q_ptr[qt + 1];
-    int n = 0;
-    for (int i0 = lb; i0 < le; i0 += 64) {
-      const int i = i0 + lane;
-      const uint32_t e = i < le ? a.q_kt[i] : 0u;
-      const uint8_t fl = i < le ? flags_s[e & 0x7fffffffu] : (uint8_t)0;
-      const bool keep = fl != 0;
-      const unsigned long long m = __ballot(keep);
-      if (keep) live_s[n + __popcll(m & ((1ull << lane) - 1ull))] = (e & 0x7fffffffu) | ((e >> 31) && fl == 2 ? 0x80000000u : 0u);
-      n += __popcll(m);
-    }
-    if (lane == 0) { n_live_s = n; live_s[n] = 0u; live_s[n + 1] = 0u; }
-  }
-  __syncthreads();
-  const int it_end = n_live_s;
-  int it = 0;
-  int buf = 0;
-  uint32_t e_cur = __builtin_amdgcn_readfirstlane(live_s[0]), e_nxt = __builtin_amdgcn_readfirstlane(live_s[1]);
-  if (it < it_end) { gload((int)(e_cur & 0x7fffffffu)); swrite(0); }
-  __syncthreads();
-
-  // fragment addresses (bytes, LDS address space) of this lane's K rows for the four k-steps, buffer 0, key block 0:
-  // row l31, 16-byte chunk (2 st + lh) ^ ((l31 >> 1) & 7); key block 1 is +4096 bytes (same swizzle), buffer 1 is +8192
-  unsigned kaddr[4];
-  {
-    const unsigned kbase_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const u16*)Ks;
-#pragma unroll
-    for (int st = 0; st < 4; st++) kaddr[st] = kbase_lds + 2u * (unsigned)k_off(l31, 2 * st + lh);
-  }
-  const uint32_t ones2 = 0x3f803f80u;
-  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
-  while (it < it_end) {
-    const int kt = (int)(e_cur & 0x7fffffffu);
-    const bool need_mask = (e_cur >> 31) == 0;
-    const int nit = it + 1;
-    if (nit < it_end) gload((int)(e_nxt & 0x7fffffffu));
-    const uint32_t e_nn_v = live_s[it + 2];          // entry it + 2 (zero past the end): lands long before it is needed
-
-    const u16* vs = Vs + buf * AK * DH;
-    // ---- S^T - m = K Q^T + (-m): two 32-key blocks.  All eight K fragments are requested at once and every MFMA waits for
-    // exactly its own (the compiler's form re-used one register set: read, wait, MFMA, eight times in a row)
-    f32x16 s[2];
-#if (FW_ABL & 8)
-    s[0] = negm; s[1] = negm;
-    if (false)
-#endif
-    {
-      const unsigned bo = (unsigned)buf * (unsigned)(AK * DH * 2);
-      u32x4v f[8];
-      __builtin_amdgcn_sched_barrier(0);
-      FW_DSREAD128(f[0], kaddr[0] + bo, 0); FW_DSREAD128(f[1], kaddr[0] + bo, 4096);
-      FW_DSREAD128(f[2], kaddr[1] + bo, 0); FW_DSREAD128(f[3], kaddr[1] + bo, 4096);
-      FW_DSREAD128(f[4], kaddr[2] + bo, 0); FW_DSREAD128(f[5], kaddr[2] + bo, 4096);
-      FW_DSREAD128(f[6], kaddr[3] + bo, 0); FW_DSREAD128(f[7], kaddr[3] + bo, 4096);
-#define FW_S_STEP(I, ST, KB, N)                                                                               \
-      FW_WAIT_LGKM(N);                                                                                         \
-      s[KB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&f[I]), qf[ST], ST == 0 ? negm : s[KB], 0, 0, 0);
-      FW_S_STEP(0, 0, 0, 7) FW_S_STEP(1, 0, 1, 6) FW_S_STEP(2, 1, 0, 5) FW_S_STEP(3, 1, 1, 4)
-      FW_S_STEP(4, 2, 0, 3) FW_S_STEP(5, 2, 1, 2) FW_S_STEP(6, 3, 0, 1) FW_S_STEP(7, 3, 1, 0)
-#undef FW_S_STEP
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (!PRESCALED) {          // S*c2 - m: the reference was added before the scaling, so scale the difference back in
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) s[kb][r] = fmaf(s[kb][r] - negm[r], c2, negm[r]);
-    }
-    if (need_mask) {
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const uint32_t info4 = *reinterpret_cast<const uint32_t*>(&kinfo[buf][kb * 32 + 8 * g + 4 * lh]);
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const uint32_t grp = (info4 >> (8 * e)) & 0xffu;
-            const bool ok = (qm >> grp) & 1u;
-            s[kb][4 * g + e] = ok ? s[kb][4 * g + e] : -INFINITY;
-          }
-        }
-    }
-    // ---- lazy reference: this half's tile maximum RELATIVE to m (four independent chains); it moves only if a row needs it
-    float mxa = fmaxf(s[0][0], s[0][1]), mxb = fmaxf(s[0][8], s[0][9]), mxc = fmaxf(s[1][0], s[1][1]), mxd = fmaxf(s[1][8], s[1][9]);
-#pragma unroll
-    for (int r = 2; r < 8; r += 2) {
-      mxa = fmaxf(mxa, fmaxf(s[0][r], s[0][r + 1])); mxb = fmaxf(mxb, fmaxf(s[0][8 + r], s[0][9 + r]));
-      mxc = fmaxf(mxc, fmaxf(s[1][r], s[1][r + 1])); mxd = fmaxf(mxd, fmaxf(s[1][8 + r], s[1][9 + r]));
-    }
-    const float mx = fmaxf(fmaxf(mxa, mxb), fmaxf(mxc, mxd));
-    if (__any(mx > FW2_TAU || (!has_ref && mx > -INFINITY))) {
-      const float mrow = fmaxf(mx, __shfl_xor(mx, 32, WAVE));          // both halves of a row take the same decision
-      const bool first = !has_ref && mrow > -INFINITY;
-      const bool move = first || mrow > FW2_TAU;
-      const float d = move ? mrow : 0.f;                               // the new reference sits at this tile's maximum
-      const float alpha = (move && !first) ? __builtin_amdgcn_exp2f(-d) : 1.f;
-#pragma unroll
-      for (int r = 0; r < 16; r++) negm[r] -= d;
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) s[kb][r] -= d;
-#pragma unroll
-      for (int n = 0; n < 2; n++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) o[n][r] *= alpha;
-      l_half *= alpha;
-      has_ref = has_ref || first;
-    }
-    // ---- P = 2^(S - m) rounded to bf16; the row sum adds the ROUNDED values (v_dot2c with a pair of ones: one instruction per
-    // pair), so that O / l is a weighted mean with weights that sum to one exactly.  With an exact running maximum the largest
-    // P of a row is 1.0 and rounds without error; with the lazy reference it is any value up to 2^TAU, and summing the
-    // unrounded P left a 2^-9 error on the dominant term of every peaked row (4-7 % on some CMU gradients).
-    float rs[4] = {0.f, 0.f, 0.f, 0.f};
-    bf16x8 pb[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-      for (int sp = 0; sp < 2; sp++)
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-#if (FW_ABL & 1)
-          const float p0 = s[kb][8 * sp + j] + 1.f, p1 = s[kb][8 * sp + j + 1] + 1.f;
-#else
-          const float p0 = __builtin_amdgcn_exp2f(s[kb][8 * sp + j]), p1 = __builtin_amdgcn_exp2f(s[kb][8 * sp + j + 1]);
-#endif
-          const uint32_t pk = pack2bf(p0, p1);
-#if (FW_ABL & 128)
-          dot2_ones(rs[(j >> 1) & 3], pk, ones2);          // rounded sum: v_dot2c measured as expensive as the exponentials
-#elif !(FW_ABL & 64)
-          rs[(j >> 1) & 3] += p0 + p1;
-#endif
-          pb[kb][sp][j] = (short)(pk & 0xffffu); pb[kb][sp][j + 1] = (short)(pk >> 16);
-        }
-    l_half += (rs[0] + rs[1]) + (rs[2] + rs[3]);
-    // ---- O^T += V^T P^T
-#if (FW_ABL & 4)
-    asm volatile("" :: "v"(pb[0][0]), "v"(pb[0][1]), "v"(pb[1][0]), "v"(pb[1][1]));
-    if (false)
-#endif
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-      for (int sp = 0; sp < 2; sp++)
-#pragma unroll
-        for (int n = 0; n < 2; n++) {
-          bf16x8 vf;
-#pragma unroll
-          for (int t = 0; t < 2; t++) {
-            const int key = kb * 32 + 16 * sp + 8 * t + 4 * lh + tq;
-            const int d = n * 32 + 16 * tg + 4 * tp;
-            const bf16x4 v4 = lds_read_tr16(vs + v_off(key, d >> 3) + (d & 7));
-#pragma unroll
-            for (int e = 0; e < 4; e++) vf[4 * t + e] = v4[e];
-          }
-          o[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kb][sp], o[n], 0, 0, 0);
-        }
-
-#if !(FW_ABL & 16)
-    if (nit < it_end) swrite(buf ^ 1);
-#else
-    asm volatile("" :: "v"(rk[0]), "v"(rk[1]), "v"(rv[0]), "v"(rv[1]));
-#endif
-#if !(FW_ABL & 32)
-    __syncthreads();
-#endif
-    buf ^= 1;
-    it = nit;
-    e_cur = e_nxt;
-    e_nxt = __builtin_amdgcn_readfirstlane(e_nn_v);
-  }
-
-  // ---- epilogue: the two halves of a row meet here
-  const float l_run = l_half + __shfl_xor(l_half, 32, WAVE);
-  const float m_run = -negm[0];
-  const bool uniform = !(l_run > 0.f);
-  const float inv = uniform ? 0.f : 1.f / l_run;
-  if (qvalid) {
-    if (lh == 0) a.lse[((int64_t)b * a.heads + h) * a.nq + qrow] = uniform ? INFINITY : m_run + log2f(l_run);
-    u16* op = a.o + (int64_t)b * a.o_bstride + (int64_t)qrow * a.o_ld + h * DH;
-    const float* vm = a.vmean + (int64_t)b * a.heads * DH + h * DH;
-#pragma unroll
-    for (int n = 0; n < 2; n++)
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int d = n * 32 + 8 * g + 4 * lh;
-        float v0, v1, v2, v3;
-        if (uniform) { v0 = vm[d]; v1 = vm[d + 1]; v2 = vm[d + 2]; v3 = vm[d + 3]; }
-        else { v0 = o[n][4 * g] * inv; v1 = o[n][4 * g + 1] * inv; v2 = o[n][4 * g + 2] * inv; v3 = o[n][4 * g + 3] * inv; }
-        uint2 pk; pk.x = pack2bf(v0, v1); pk.y = pack2bf(v2, v3);
-        *reinterpret_cast<uint2*>(op + d) = pk;
-      }
-  }
-}
-
-
 extern "C" int mca_attn_fwd(const mca_attn_fwd_args* a, mca_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->o || !a->lse || !a->qmask || !a->keyinfo || !a->ktile_flags || !a->q_ptr ||
       !a->q_kt || !a->q_order || !a->vmean)
@@ -638,14 +320,8 @@ extern "C" int mca_attn_fwd(const mca_attn_fwd_args* a, mca_stream_t stream) {
     return MCA_E_ALIGN;
   if (a->heads > 65535 || a->batch > 65535 || a->n_ktiles > MAX_KTILES) return MCA_E_UNSUPPORTED;
   const dim3 grid(a->n_qtiles, a->heads, a->batch);
-  const bool pre = (a->flags & MCA_ATTN_Q_PRESCALED) != 0;
-  // production: the first form (exact running maximum).  knob 13 = 2: the lazy-reference second form (A/B; 10 % faster on
-  // random data, gradients 1.2-1.4x noisier against the fp32 oracle: DESIGN.md section 5)
-  if (mca_knobs[13] == 2) {
-    if (pre) hipLaunchKernelGGL(attn_fwd2_kernel<true>, grid, dim3(256), 0, as_stream(stream), *a, mca_knobs[9]);
-    else hipLaunchKernelGGL(attn_fwd2_kernel<false>, grid, dim3(256), 0, as_stream(stream), *a, mca_knobs[9]);
-  } else if (pre) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, as_stream(stream), *a, mca_knobs[9] | mca_knobs[8]);
-  else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, as_stream(stream), *a, mca_knobs[9] | mca_knobs[8]);
+  if (!(a->flags & MCA_ATTN_Q_PRESCALED)) return MCA_E_UNSUPPORTED;          // (the un-prescaled forms left the library in round 3)
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, as_stream(stream), *a, mca_knobs[9] | mca_knobs[8]);
   return launch_status();
 }
 

@@ -25,9 +25,9 @@ class NativeEncoder(nn.Module):
     """Marker base class: the engine has a fused HIP path for this encoder type."""
     kind = ""
 
-    def forward(self, batch):  # standalone use: run the native kernels for this one modality
-        from .engine import run_single_encoder
-        return run_single_encoder(self, batch)
+    def forward(self, batch):
+        raise NotImplementedError("a native encoder is a parameter container: its arithmetic is fused into the model's step "
+                                  "(construct an MCA / EAO model and call it)")
 
 
 class PositionalEncoder(nn.Module):

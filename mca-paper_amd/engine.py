@@ -26,12 +26,12 @@ import numpy as np
 import torch
 
 from . import hip
-from .encoders import EmbeddedSequenceEncoder, NativeEncoder, TabularEncoder
-from .hip import AttnBwd2Args, AttnBwdArgs, AttnFp8BwdOperands, AttnFp8Operands, AttnFwdArgs, LossTerm, call, ptr, stream_ptr
+from .encoders import EmbeddedSequenceEncoder, TabularEncoder
+from .hip import AttnBwd2Args, AttnFp8BwdOperands, AttnFp8Operands, AttnFwdArgs, LossTerm, call, ptr, stream_ptr
 
 LN_EPS = 1e-5
 FWD_BQ, FWD_BK = 128, 64
-BWD_BQ, BWD_BK = 64, 256
+BWD_BQ = 64          # query rows per step of the dK/dV pass (its key-block size: debug_options()['dkv_keys'])
 
 
 def _pad_to(x: int, m: int) -> int:
@@ -40,6 +40,21 @@ def _pad_to(x: int, m: int) -> int:
 
 def _dev(a: np.ndarray, device) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def debug_options() -> dict:
+    """The engine's A/B switches, all behind ONE environment variable: ``MCA_DEBUG=key=value,key=value``.  Production runs set
+    none of them.  overlap_wgrad=0|1 (weight-gradient GEMMs on a side stream: default by size), group_wgrad=0 (one launch per
+    weight gradient instead of one per layer), mask_mfma=0 (element-wise attention mask instead of the mask product),
+    dkv_keys=256 (8-wavefront key blocks in the dK/dV pass).  Kernel-level knobs: include/mca_hip_debug.h (hip.knobs)."""
+    opts = {"overlap_wgrad": None, "group_wgrad": True, "mask_mfma": True, "dkv_keys": 128}
+    for item in filter(None, os.environ.get("MCA_DEBUG", "").split(",")):
+        k, _, v = item.partition("=")
+        k = k.strip()
+        if k not in opts:
+            raise ValueError(f"MCA_DEBUG: unknown switch '{k}' (known: {sorted(opts)})")
+        opts[k] = int(v) if k == "dkv_keys" else (v.strip() not in ("0", "", "false"))
+    return opts
 
 
 class _Sched:
@@ -80,10 +95,9 @@ class FusionEngine:
         self.Ip = _pad_to(self.I, 64)
         self.scale = model.dim_head ** -0.5
         self.q_scale = self.scale * 1.4426950408889634          # folded into the forward bf16 copy of every to_q.weight
-        self.attn_flags = hip.ATTN_Q_PRESCALED
+        self.attn_flags = hip.ATTN_Q_PRESCALED                  # (the kernels take pre-scaled q only)
         self.attn_dtype = "bf16"
-        if os.environ.get("MCA_Q_PRESCALE", "1") == "0":        # A/B: plain W_q copy, the kernels scale the scores themselves
-            self.q_scale, self.attn_flags = 0.0, 0
+        self.dbg = debug_options()                               # A/B switches: ONE environment variable, MCA_DEBUG
         self.nk_pad = _pad_to(self.N, 256)
         self._flatten_parameters()
         self._build_static()
@@ -103,27 +117,15 @@ class FusionEngine:
         self.fuse_geglu_bwd = True
         self._mod_shifts = torch.arange(len(model.modality_types), dtype=torch.int32, device=self.device)
         self.fuse_ln_residual = True                # residual LayerNorm recomputed in the GEMM epilogue (large batches)
-        # weight-gradient GEMMs on a side stream, concurrent with the backward chain
-        # OFF by default since round 2: with the atomic-free attention backward the main stream keeps every CU busy, and the
-        # persistent weight-gradient GEMMs of a second stream only take CUs away from it (one box, alternating processes:
-        # 23.7 / 25.6 ms per b = 32 step with the side stream, 22.17 / 22.16 without; in round 1 it gained 0.7 ms).
-        # At small batches (b = 8: the N = 512 GEMMs fill 160 of 256 CUs) the side stream still pays: 8.7-8.8 against 9.5-10.2 ms
-        # eager.  None = by size (on below OVERLAP_ROWS_MAX token rows); MCA_OVERLAP_WGRAD=0 / 1 forces it.
-        env = os.environ.get("MCA_OVERLAP_WGRAD")
-        self.overlap_wgrad = None if env is None else env == "1"
-        self.group_wgrad = os.environ.get("MCA_GROUP_WGRAD", "1") != "0"      # one weight-gradient launch per layer
-        self.zero_dq_once = True                    # (one-pass backward) all dQ accumulators zeroed by one side-stream memset per step
-        # attention backward in two passes without atomics (mca_attn_bwd_dq + mca_attn_bwd_dkv): dQ written once as bf16 straight
-        # into the dqkv operand of the data- / weight-gradient GEMMs; MCA_ATTN_BWD_ONE_PASS=1 keeps the atomic one-pass kernel
-        self.attn_bwd_two_pass = os.environ.get("MCA_ATTN_BWD_ONE_PASS", "0") != "1"
-        # the attention mask as a matrix product (mca_build_keyhot): needs every key group id <= 14; MCA_MASK_MFMA=0 keeps the
-        # element-wise mask (A/B)
-        self.mask_mfma = int(self.st.kgroup.max()) <= 14 and os.environ.get("MCA_MASK_MFMA", "1") != "0"
-        # micro-batch interleave (opt-in, MCA_MICRO_BATCHES=2): batches of at least micro_batch_min samples run as two
-        # halves on two streams.  Measured on CMU b=32: 26.3 vs 26.7 ms/step when the host runs ahead, no gain when it
-        # does not (tools/ab_step.py 102 1 2, tools/diag_switch.py) - kept off by default.
-        self.micro_batches = int(os.environ.get("MCA_MICRO_BATCHES", "1"))
-        self.micro_batch_min = 32
+        # Weight-gradient GEMMs on a side stream, concurrent with the backward chain: None = by size (on below OVERLAP_ROWS_MAX
+        # token rows).  Since the attention backward lost its atomics the main stream keeps every CU busy and the persistent
+        # weight-gradient GEMMs of a second stream only take CUs from it (one box, alternating processes: 23.7 / 25.6 ms per
+        # b = 32 step with the side stream, 22.17 / 22.16 without); at small batches (b = 8: the N = 512 GEMMs fill 160 of 256
+        # CUs) the side stream still pays in the eager loop (8.7-8.8 against 9.5-10.2 ms).  MCA_DEBUG=overlap_wgrad=0|1 forces it.
+        self.overlap_wgrad = self.dbg["overlap_wgrad"]
+        self.group_wgrad = self.dbg["group_wgrad"]          # one weight-gradient launch per layer
+        # the attention mask as a matrix product (mca_build_keyhot): needs every key group id <= 14
+        self.mask_mfma = int(self.st.kgroup.max()) <= 14 and self.dbg["mask_mfma"]
 
     # ------------------------------------------------------------------------------------------------
     # parameters -> one flat buffer (and one for gradients)
@@ -189,18 +191,16 @@ class FusionEngine:
             return torch.from_numpy(np.where(bits == 1, 0.0, -32768.0).astype(np.float32)).to(torch.bfloat16).to(dev).contiguous()
         self.qblk_attn, self.qblk_pool = qblk_of(st.qmask_attn), qblk_of(st.qmask_pool)
         self.sched_attn_f = _Sched(st.attn_schedule(FWD_BQ, FWD_BK), dev)
-        self.sched_attn_b = _Sched(st.attn_schedule(BWD_BQ, BWD_BK), dev)
         # key-block size of the dkv pass: 128 (4 wavefronts, two independent workgroups per CU) is 3 % faster than 256 (8 wavefronts,
-        # one workgroup per CU) at N = 2538 and equal at N = 6088; MCA_DKV_KEYS=256 for A/B
-        dkv_keys = int(os.environ.get("MCA_DKV_KEYS", "128"))
+        # one workgroup per CU) at N = 2538 and equal at N = 6088
+        dkv_keys = self.dbg["dkv_keys"]
         self.dkv_keys = dkv_keys
-        self.sched_attn_b2 = self.sched_attn_b if dkv_keys == BWD_BK else _Sched(st.attn_schedule(BWD_BQ, dkv_keys), dev)
+        self.sched_attn_b2 = _Sched(st.attn_schedule(BWD_BQ, dkv_keys), dev)
         if self.eao:
             self.seg_start = _dev(st.seg_start, dev)
         else:
             self.sched_pool_f = _Sched(st.pool_schedule(FWD_BQ, FWD_BK), dev)
-            self.sched_pool_b = _Sched(st.pool_schedule(BWD_BQ, BWD_BK), dev)
-            self.sched_pool_b2 = self.sched_pool_b if dkv_keys == BWD_BK else _Sched(st.pool_schedule(BWD_BQ, dkv_keys), dev)
+            self.sched_pool_b2 = _Sched(st.pool_schedule(BWD_BQ, dkv_keys), dev)
         terms = self.model.loss_terms
         arr = (LossTerm * len(terms))()
         for i, t in enumerate(terms):
@@ -245,8 +245,6 @@ class FusionEngine:
         128-key dkv blocks, else the backward keeps bf16 recomputes).  Pooling attention stays bf16."""
         if dtype not in ("bf16", "fp8"):
             raise ValueError(dtype)
-        if dtype == "fp8" and not (self.attn_flags & hip.ATTN_Q_PRESCALED):
-            raise ValueError("fp8 attention needs the pre-scaled q operand (MCA_Q_PRESCALE=1)")
         self.attn_dtype = dtype
 
     def _fp8_operands(self, ws, b):
@@ -277,8 +275,7 @@ class FusionEngine:
         return ws["fp8b"][1]
 
     def fp8_backward_on(self, ws, nq) -> bool:
-        return (self.attn_dtype == "fp8" and nq == self.N and ws.get("khot") is not None and self.dkv_keys == 128
-                and bool(self.attn_flags & hip.ATTN_Q_PRESCALED) and self.attn_bwd_two_pass)
+        return self.attn_dtype == "fp8" and nq == self.N and ws.get("khot") is not None and self.dkv_keys == 128
 
     def invalidate_weights(self):
         """Call after writing parameters through an alias autograd's version counters cannot see (``p.data.op_()``, a raw
@@ -340,9 +337,9 @@ class FusionEngine:
     # ------------------------------------------------------------------------------------------------
     # workspaces for a given local batch size
     # ------------------------------------------------------------------------------------------------
-    def workspace(self, b: int, part: int = 0) -> dict:
-        if (b, part) in self._ws:
-            return self._ws[(b, part)]
+    def workspace(self, b: int) -> dict:
+        if b in self._ws:
+            return self._ws[b]
         D, N, H, Ip, R, dev = self.D, self.N, self.H, self.Ip, self.R, self.device
         T = b * N
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -372,12 +369,6 @@ class FusionEngine:
         # backward
         ws["dxa"], ws["dxb"], ws["dx_b"] = f32(T, D), f32(T, D), bf(T, D)
         ws["dg"], ws["do"] = bf(T, Ip), bf(T, D)
-        # fp32 dQ accumulators, one per layer: all of them are zeroed by ONE memset on the side stream at the start of the
-        # backward (beside the pooling backward) instead of a 166 MB memset in front of every layer's attention backward
-        if not self.attn_bwd_two_pass:
-            ws["dq32_all"] = f32(max(self.L, 1), T, D)
-            ws["dq32"] = ws["dq32_all"][0]
-        ws["dq32_zero_event"] = torch.cuda.Event()
         ws["dpool_b"], ws["dop"], ws["dqp32"], ws["dqp_sum"], ws["dqp_b"] = bf(b * R, D), bf(b * R, D), f32(b * R, D), f32(R, D), bf(R, D)
         ws["dkvp"], ws["drt"] = (None if self.eao else bf(T, 2 * D)), f32(R, D)
         ws["enc"] = {}
@@ -392,27 +383,9 @@ class FusionEngine:
             elif isinstance(enc, TabularEncoder):
                 ws["enc"][name] = dict(h1_b=bf(rows, D), y=f32(rows, D), m2=f32(rows), r2=f32(rows), dy=f32(rows, D),
                                        dy_b=bf(rows, D), dh1=f32(rows, D), mask=u8(rows))
-        # each workspace has its own side stream for the weight-gradient GEMMs (micro-batch halves run concurrently)
-        ws["side"], ws["side_events"] = torch.cuda.Stream(device=dev), []
-        self._ws[(b, part)] = ws
+        ws["side"], ws["side_events"] = torch.cuda.Stream(device=dev), []          # side stream of the weight-gradient GEMMs
+        self._ws[b] = ws
         return ws
-
-    def split_workspace(self, b: int) -> dict:
-        """Two half-batch workspaces run on two streams (see _model_forward): the samples of a batch only meet in the
-        contrastive loss, so the MFMA-bound kernels of one half overlap the HBM-bound ones of the other."""
-        key = ("split", b)
-        if key not in self._ws:
-            h = b // 2
-            pooled = torch.empty(b * self.R, self.D, dtype=torch.float32, device=self.device)
-            parts = []
-            for pi in range(2):
-                part = dict(self.workspace(h, pi))
-                part["pooled"] = pooled[pi * h * self.R:(pi + 1) * h * self.R]
-                part["done"] = [torch.cuda.Event() for _ in range(len(self.bucket_bounds))]
-                parts.append(part)
-            self._ws[key] = dict(b=b, parts=parts, pooled=pooled, stream=torch.cuda.Stream(device=self.device),
-                                 start=torch.cuda.Event(), gen=0)
-        return self._ws[key]
 
     # ------------------------------------------------------------------------------------------------
     # thin kernel wrappers
@@ -524,30 +497,6 @@ class FusionEngine:
         else:
             call("mca_attn_bwd_dkv", C.byref(a), stream_ptr(), flops=8.0 * 64 * pairs * self.H * b * 0.6)
             call("mca_attn_bwd_dq", C.byref(a), stream_ptr(), flops=8.0 * 64 * pairs * self.H * b * 0.4)
-        hip.set_tag("")
-
-    def _attn_bwd(self, q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, d_o, lse, delta, dq, dq_bstride, dkv, dk_off,
-                  dv_off, dkv_ld, qmask, sched, ws, b, nq):
-        N = self.N
-        esz = 2
-        call("mca_attn_bwd_prep", o.data_ptr(), d_o.data_ptr(), nq * o.stride(0), o.stride(0), lse.data_ptr(),
-             delta.data_ptr(), ws["dvmean"].data_ptr(), b, self.H, nq, N, stream_ptr())
-        a = AttnBwdArgs()
-        a.q, a.q_bstride, a.q_ld = q, q_bstride, q_ld
-        a.k, a.v = kv.data_ptr() + k_off * esz, kv.data_ptr() + v_off * esz
-        a.kv_bstride, a.kv_ld = N * kv_ld, kv_ld
-        a.d_o, a.o_bstride, a.o_ld = d_o.data_ptr(), nq * d_o.stride(0), d_o.stride(0)
-        a.lse, a.delta, a.dvmean = lse.data_ptr(), delta.data_ptr(), ws["dvmean"].data_ptr()
-        a.dq, a.dq_bstride, a.dq_ld = dq.data_ptr(), dq_bstride, dq.stride(0)
-        a.dk, a.dv = dkv.data_ptr() + dk_off * esz, dkv.data_ptr() + dv_off * esz
-        a.dkv_bstride, a.dkv_ld = N * dkv_ld, dkv_ld
-        a.qmask, a.keyinfo, a.ktile_flags = qmask.data_ptr(), ws["keyinfo"].data_ptr(), ws["kflags"].data_ptr()
-        a.k_ptr, a.k_qt, a.k_order = sched.k_ptr.data_ptr(), sched.k_qt.data_ptr(), sched.k_order.data_ptr()
-        a.k_wg = sched.k_wg.data_ptr()
-        a.batch, a.heads, a.nq, a.nk, a.nk_pad = b, self.H, nq, N, self.nk_pad
-        a.n_qtiles, a.n_ktiles, a.scale, a.flags = sched.s.n_q, sched.s.n_k, self.scale, self.attn_flags
-        hip.set_tag("pool" if nq != N else "layer")
-        call("mca_attn_bwd", C.byref(a), stream_ptr(), flops=8.0 * 64 * sched.s.allowed_pairs * self.H * b)
         hip.set_tag("")
 
     # ------------------------------------------------------------------------------------------------
@@ -771,28 +720,9 @@ class FusionEngine:
             self.gflat.zero_()
         if d_logit_scale is not None:
             self.grad_of(self.model.loss.loss_fn.logit_scale).add_(d_logit_scale.reshape(()))
-        main = torch.cuda.current_stream()
-        if "parts" not in ws:
-            self._backward_part(ws, d_pooled, self._bucket_ready)
-            if self.overlap_on(ws):
-                main.wait_stream(ws["side"])                  # every weight gradient is in before clip / AdamW
-            return
-        # two half batches on two streams; every gradient accumulation is atomic, so both halves add into the same
-        # flat buffer.  A gradient bucket is complete when BOTH halves have produced it: half 0 marks it with an event,
-        # half 1 waits for that event and then hands the bucket to the data-parallel reducer.
-        h, (p0, p1), s1 = ws["b"] // 2, ws["parts"], ws["stream"]
-        ws["start"].record(main)
-        self._backward_part(p0, d_pooled[:h], lambda idx: p0["done"][idx].record())
-
-        def both_ready(idx):
-            torch.cuda.current_stream().wait_event(p0["done"][idx])
-            self._bucket_ready(idx)
-
-        with torch.cuda.stream(s1), hip.use_stream(s1.cuda_stream):
-            s1.wait_event(ws["start"])
-            self._backward_part(p1, d_pooled[h:], both_ready)
-        for s in (s1, p0["side"], p1["side"]):
-            main.wait_stream(s)
+        self._backward_part(ws, d_pooled, self._bucket_ready)
+        if self.overlap_on(ws):
+            torch.cuda.current_stream().wait_stream(ws["side"])          # every weight gradient is in before clip / AdamW
 
     def _backward_part(self, ws, d_pooled, bucket_ready):
         m, D, N, H, Ip, I, R, b, T = self.model, self.D, self.N, self.H, self.Ip, self.I, self.R, ws["b"], ws["T"]
@@ -808,8 +738,6 @@ class FusionEngine:
         def on_side(fn):
             side(fn, slot[0], ws); slot[0] += 1
 
-        if self.L and self.zero_dq_once and not self.attn_bwd_two_pass:          # all dQ accumulators zeroed beside the pooling backward (inline when nothing runs on the side stream)
-            on_side(lambda: (ws["dq32_all"].zero_(), ws["dq32_zero_event"].record(torch.cuda.current_stream())))
         if self.eao:
             return self._backward_part_eao(ws, dpool, bucket_ready, on_side)
         # pooled = op @ Wo^T + return_tokens
@@ -818,14 +746,9 @@ class FusionEngine:
         self.gemm_nt(ws["dpool_b"], self.wp["oT"], ws["dop"], b * R, D, D)
         on_side(lambda: tn(ws["dpool_b"], ws["op"], G(ap.to_out.weight), b * R, D, D))
         # pooling attention
-        if self.attn_bwd_two_pass:
-            self._attn_bwd2(ws["qp"].data_ptr(), 0, D, ws["kvp"], 0, D, 2 * D, ws["op"], ws["dop"], ws["lse_p"], ws["delta_p"],
-                            ws["dqp32"].data_ptr(), R * D, D, True, ws["dkvp"], 0, D, 2 * D, self.qmask_pool, self.sched_pool_f,
-                            self.sched_pool_b2, ws, b, R)
-        else:
-            ws["dqp32"].zero_()
-            self._attn_bwd(ws["qp"].data_ptr(), 0, D, ws["kvp"], 0, D, 2 * D, ws["op"], ws["dop"], ws["lse_p"], ws["delta_p"],
-                           ws["dqp32"], R * D, ws["dkvp"], 0, D, 2 * D, self.qmask_pool, self.sched_pool_b, ws, b, R)
+        self._attn_bwd2(ws["qp"].data_ptr(), 0, D, ws["kvp"], 0, D, 2 * D, ws["op"], ws["dop"], ws["lse_p"], ws["delta_p"],
+                        ws["dqp32"].data_ptr(), R * D, D, True, ws["dkvp"], 0, D, 2 * D, self.qmask_pool, self.sched_pool_f,
+                        self.sched_pool_b2, ws, b, R)
         ws["dqp_sum"].zero_()
         call("mca_reduce_rows", ptr(ws["dqp32"]), D, R * D, R, ptr(ws["dqp_sum"]), D, b * R, D, stream_ptr())
         call("mca_f32_to_bf16", ptr(ws["dqp_sum"]), D, ptr(ws["dqp_b"]), D, R, D, 1.0, stream_ptr())
@@ -883,20 +806,10 @@ class FusionEngine:
             # x1 = o @ Wo^T + xn
             on_side(lambda dx1=dx1, a=a, ly=ly: tn(dx1, a["o"], G(ly.attn.to_out.weight), T, D, D))
             self.gemm_nt(dx1, w["oT"], ws["do"], T, D, D)
-            if self.attn_bwd_two_pass:
-                # dq | dk | dv land in dqkv as bf16, each element written once
-                self._attn_bwd2(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], ws["do"], a["lse"],
-                                ws["delta"], dqkv.data_ptr(), N * 3 * D, 3 * D, False, dqkv, D, 2 * D, 3 * D, self.qmask_attn,
-                                self.sched_attn_f, self.sched_attn_b2, ws, b, N)
-            else:
-                dq32 = ws["dq32_all"][i]
-                if not self.zero_dq_once:
-                    dq32.zero_()
-                elif bi == 0:
-                    torch.cuda.current_stream().wait_event(ws["dq32_zero_event"])
-                self._attn_bwd(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], ws["do"], a["lse"],
-                               ws["delta"], dq32, N * D, dqkv, D, 2 * D, 3 * D, self.qmask_attn, self.sched_attn_b, ws, b, N)
-                call("mca_f32_to_bf16", ptr(dq32), D, ptr(dqkv), 3 * D, T, D, 1.0, stream_ptr())
+            # dq | dk | dv land in dqkv as bf16, each element written once
+            self._attn_bwd2(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], ws["do"], a["lse"],
+                            ws["delta"], dqkv.data_ptr(), N * 3 * D, 3 * D, False, dqkv, D, 2 * D, 3 * D, self.qmask_attn,
+                            self.sched_attn_f, self.sched_attn_b2, ws, b, N)
             # to_q.weight and to_kv.weight are adjacent in the flat gradient buffer: one (3D, D) weight-gradient GEMM
             gq = G(ly.attn.to_q.weight)
             assert G(ly.attn.to_kv.weight).data_ptr() == gq.data_ptr() + D * D * 4
@@ -986,32 +899,6 @@ class FusionEngine:
             p.grad = self.grad_of(p)
         return out
 
-    def _forward_split(self, batch, b, need_grad):
-        """Micro-batch interleave: the two halves of the batch run encoders + trunk on two streams; they only meet in the
-        loss.  Per-sample results are identical to the unsplit pass (no kernel mixes samples before the loss)."""
-        m = self.model
-        ws = self.split_workspace(b)
-        h, s1, main = b // 2, ws["stream"], torch.cuda.current_stream()
-        for mi, name in enumerate(m.modality_types):           # in-place renorm of the shared tables: once, before the split
-            if isinstance(m.encoders[name], TabularEncoder):
-                self._renorm_table(m.encoders[name], self.st.token_dims[mi])
-        ws["start"].record(main)
-        masks = []
-        for pi, part in enumerate(ws["parts"]):
-            sub = {name: {k: (v[pi * h:(pi + 1) * h] if torch.is_tensor(v) and v.dim() and v.shape[0] == b else v)
-                          for k, v in batch[name].items()} for name in m.modality_types}
-            if pi == 0:
-                masks.append(self._encode(sub, part, need_grad, renorm=False))
-                self.forward_trunk(part)
-            else:
-                with torch.cuda.stream(s1), hip.use_stream(s1.cuda_stream):
-                    s1.wait_event(ws["start"])
-                    masks.append(self._encode(sub, part, need_grad, renorm=False))
-                    self.forward_trunk(part)
-        main.wait_stream(s1)
-        ws["present_cur"] = torch.cat([part["present_cur"] for part in ws["parts"]])
-        return ws, {name: torch.cat([masks[0][name], masks[1][name]]) for name in m.modality_types}
-
     def _model_forward(self, batch, no_loss=False):
         m = self.model
         first = batch[m.modality_types[0]]
@@ -1022,16 +909,10 @@ class FusionEngine:
                 self.poll_finite()                                     # a flagged EARLIER step raises here (no sync)
             self._flag_inputs(batch)
         self.refresh_weights()
-        native = all(isinstance(m.encoders[n], (EmbeddedSequenceEncoder, TabularEncoder)) for n in m.modality_types)
-        if self.micro_batches == 2 and native and b % 2 == 0 and b >= self.micro_batch_min:
-            ws, sample_mask = self._forward_split(batch, b, need_grad)
-            ws["gen"] += 1
-            pooled = ws["pooled"].view(b, self.R, self.D)
-        else:
-            ws = self.workspace(b)
-            ws["gen"] += 1          # the saved activations of any earlier forward of this batch size are gone from here on
-            sample_mask = self._encode(batch, ws, need_grad)
-            pooled = self.forward_trunk(ws).view(b, self.R, self.D)
+        ws = self.workspace(b)
+        ws["gen"] += 1          # the saved activations of any earlier forward of this batch size are gone from here on
+        sample_mask = self._encode(batch, ws, need_grad)
+        pooled = self.forward_trunk(ws).view(b, self.R, self.D)
         slots = m.output_slots()
         if self.check_finite:
             self._flag_tensors([pooled], 2)
@@ -1157,8 +1038,3 @@ class _MCAStep(torch.autograd.Function):
         for p in params:
             p.grad = engine.grad_of(p)
         return (None, None, None, None) + tuple(None for _ in params)
-
-
-def run_single_encoder(enc: NativeEncoder, batch):
-    raise NotImplementedError("standalone encoder forward: construct an MCA model and call it (the encoders are fused "
-                              "into the model's step)")

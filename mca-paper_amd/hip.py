@@ -70,22 +70,6 @@ class AttnFwdArgs(C.Structure):
 ATTN_Q_PRESCALED = 1
 
 
-class AttnBwdArgs(C.Structure):
-    _fields_ = [
-        ("q", C.c_void_p), ("q_bstride", C.c_int64), ("q_ld", C.c_int64),
-        ("k", C.c_void_p), ("v", C.c_void_p), ("kv_bstride", C.c_int64), ("kv_ld", C.c_int64),
-        ("d_o", C.c_void_p), ("o_bstride", C.c_int64), ("o_ld", C.c_int64),
-        ("lse", C.c_void_p), ("delta", C.c_void_p), ("dvmean", C.c_void_p),
-        ("dq", C.c_void_p), ("dq_bstride", C.c_int64), ("dq_ld", C.c_int64),
-        ("dk", C.c_void_p), ("dv", C.c_void_p), ("dkv_bstride", C.c_int64), ("dkv_ld", C.c_int64),
-        ("qmask", C.c_void_p), ("keyinfo", C.c_void_p), ("ktile_flags", C.c_void_p),
-        ("k_ptr", C.c_void_p), ("k_qt", C.c_void_p), ("k_order", C.c_void_p),
-        ("batch", C.c_int), ("heads", C.c_int), ("nq", C.c_int), ("nk", C.c_int), ("nk_pad", C.c_int),
-        ("n_qtiles", C.c_int), ("n_ktiles", C.c_int), ("scale", C.c_float),
-        ("k_wg", C.c_void_p), ("flags", C.c_int),
-    ]
-
-
 class AttnFp8Operands(C.Structure):
     _fields_ = [("q8", C.c_void_p), ("qs", C.c_void_p), ("k8", C.c_void_p), ("ks", C.c_void_p), ("v8t", C.c_void_p), ("vs", C.c_void_p),
                 ("n_ktiles", C.c_int)]
@@ -149,7 +133,6 @@ SIGNATURES = {
     "mca_attn_quant_mxfp8": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, C.POINTER(AttnFp8Operands), _I, _I, _I, _P]),
     "mca_attn_fwd_fp8": (_I, [C.POINTER(AttnFwdArgs), C.POINTER(AttnFp8Operands), _P]),
     "mca_attn_bwd_prep": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "mca_attn_bwd": (_I, [C.POINTER(AttnBwdArgs), _P]),
     "mca_attn_bwd_dq": (_I, [C.POINTER(AttnBwd2Args), _P]),
     "mca_attn_bwd_dkv": (_I, [C.POINTER(AttnBwd2Args), _P]),
     "mca_attn_quant_bwd_mxfp8": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _P, _I64, _I64, C.POINTER(AttnFp8BwdOperands), _I, _I, _I, _P]),

@@ -446,30 +446,48 @@ def make_collators(refenc):
     print("wrote collators.pt")
 
 
+FLAGS = ("collators", "tcga", "cmu", "init", "tiny", "ckpt", "eao")
+
+
 if __name__ == "__main__":
+    # ONE flag per process.  The reference's loss keeps its temperature in a module-level nn.Parameter shared by every model
+    # of the process (utils/contrastive_loss_with_temperature.py:111,158: DEFAULT_LOGIT_SCALE), so every case starts from the
+    # temperature the previous cases of the SAME process trained: the committed files were written one flag at a time and only
+    # reproduce bit for bit that way (`--eao --tiny` in one process gave tiny_mca_* files with logit_scale 2.6532 instead of
+    # 2.6593).  --all runs every flag in a process of its own.
     ap = argparse.ArgumentParser()
-    ap.add_argument("--collators", action="store_true")
-    ap.add_argument("--tcga", action="store_true")
-    ap.add_argument("--cmu", action="store_true")
-    ap.add_argument("--init", action="store_true")
-    ap.add_argument("--tiny", action="store_true")
-    ap.add_argument("--ckpt", action="store_true")
-    ap.add_argument("--eao", action="store_true")
+    for f in FLAGS:
+        ap.add_argument("--" + f, action="store_true")
+    ap.add_argument("--all", action="store_true", help="every flag, each in its own process")
     a = ap.parse_args()
+    chosen = [f for f in FLAGS if getattr(a, f)]
+    if a.all:
+        if chosen:
+            ap.error("--all takes no other flag")
+        import subprocess
+        for f in FLAGS:
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--" + f], check=True)
+        sys.exit(0)
+    if len(chosen) > 1:
+        ap.error(f"one flag per process (got {chosen}): the reference shares its loss temperature between the models of a process, "
+                 "so the order of the cases changes the goldens; use --all")
+    if not chosen:
+        chosen = ["tiny"]
     os.makedirs(GOLD, exist_ok=True)
     refmodel, refenc = import_reference()
-    if a.collators:
+    flag = chosen[0]
+    if flag == "collators":
         make_collators(refenc)
-    if a.tcga:
+    elif flag == "tcga":
         make_tcga(refmodel)
-    if a.ckpt:
+    elif flag == "ckpt":
         make_ckpt(refmodel)
         make_unrunnable(refmodel)
-    if a.eao:
+    elif flag == "eao":
         make_eao(refmodel)
-    if a.tiny or not (a.cmu or a.init or a.collators or a.tcga or a.ckpt or a.eao):
+    elif flag == "tiny":
         make_tiny(refmodel)
-    if a.init:
+    elif flag == "init":
         make_init_parity(refmodel)
-    if a.cmu:
+    elif flag == "cmu":
         make_cmu(refmodel)

@@ -452,28 +452,11 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first, prescaled=True, spi
            nq, N, H.stream_ptr())
     ref_delta = (d_o.float() * got_o).view(b, nq, heads, 64).sum(-1).permute(0, 2, 1)
     assert rel(delta, ref_delta) < 1e-4
-    dq = torch.zeros(b, nq, D, device=dev)
-    dkv = torch.zeros(b, N, 3 * D, dtype=torch.bfloat16, device=dev)
-    ab = H.AttnBwdArgs()
-    ab.q, ab.q_bstride, ab.q_ld = a.q, a.q_bstride, a.q_ld
-    ab.k, ab.v, ab.kv_bstride, ab.kv_ld = a.k, a.v, a.kv_bstride, a.kv_ld
-    ab.d_o, ab.o_bstride, ab.o_ld = d_o.data_ptr(), nq * D, D
-    ab.lse, ab.delta, ab.dvmean = lse.data_ptr(), delta.data_ptr(), dvmean.data_ptr()
-    ab.dq, ab.dq_bstride, ab.dq_ld = dq.data_ptr(), nq * D, D
-    ab.dk, ab.dv, ab.dkv_bstride, ab.dkv_ld = dkv.data_ptr() + D * 2, dkv.data_ptr() + 2 * D * 2, N * 3 * D, 3 * D
-    ab.qmask, ab.keyinfo, ab.ktile_flags = qmask.data_ptr(), keyinfo.data_ptr(), kflags.data_ptr()
-    ab.k_ptr, ab.k_qt, ab.k_order = sb.k_ptr.data_ptr(), sb.k_qt.data_ptr(), sb.k_order.data_ptr()
-    ab.batch, ab.heads, ab.nq, ab.nk, ab.nk_pad, ab.n_qtiles, ab.n_ktiles, ab.scale = b, heads, nq, N, nk_pad, sb.s.n_q, sb.s.n_k, 0.125
-    ab.flags = a.flags
-    H.call("mca_attn_bwd", C.byref(ab), H.stream_ptr())
-    torch.cuda.synchronize()
     rdq = q4r.grad.permute(0, 2, 1, 3).reshape(b, nq, D)
     rdk = k4r.grad.permute(0, 2, 1, 3).reshape(b, N, D)
     rdv = v4r.grad.permute(0, 2, 1, 3).reshape(b, N, D)
-    e_q, e_k, e_v = rel(dq, rdq), rel(dkv[:, :, D:2 * D].float(), rdk), rel(dkv[:, :, 2 * D:].float(), rdv)
-    assert e_q < 1.5e-2 and e_k < 1.5e-2 and e_v < 1.5e-2, f"attention backward rel err dq {e_q} dk {e_k} dv {e_v}"
 
-    # ---- the same backward in two passes without atomics (production path): dq written once (bf16 and fp32 forms)
+    # ---- backward in two passes without atomics: dq written once (bf16 and fp32 forms)
     for dq_f32 in (False, True):
         dq2 = torch.full((b, nq, D), 7.0, device=dev, dtype=torch.float32 if dq_f32 else torch.bfloat16)          # no pre-zeroing needed
         dkv2 = torch.zeros(b, N, 3 * D, dtype=torch.bfloat16, device=dev)
@@ -532,25 +515,32 @@ def test_attention_small(H, variant, pool, drop):
     _attention_case(H, st, b=3, heads=2, pool=pool, seed=11, drop_first=drop)
 
 
-@pytest.mark.parametrize("form", ["unscaled", "second-form", "second-form-unscaled"])
-def test_attention_other_forms(H, form):
-    """the un-prescaled entry of the production forward kernel, and the lazy-reference second form of the forward (knob 13 = 2,
-    opt-in: A/B measurements): same contract."""
-    S = importlib.import_module("mca-paper_amd.structure")
-    st = S.FusionStructure([70, 45, 30], 8, (3, 2), fcl=True)
-    with H.knobs(k13=2 if form.startswith("second") else 0):
-        _attention_case(H, st, b=3, heads=2, pool=False, seed=11, drop_first=True, prescaled=form == "second-form")
+def test_attention_unprescaled_q_is_refused(H):
+    """q must carry scale * log2 e (MCA_ATTN_Q_PRESCALED): the un-prescaled kernel forms (one of which spilled 579 registers)
+    left the library in round 3; every attention entry point refuses a call without the flag instead of computing something
+    else (MCA_E_UNSUPPORTED = -3)."""
+    a = H.AttnFwdArgs()
+    one = torch.zeros(64, dtype=torch.int32, device="cuda")
+    for f_ in ("q", "k", "v", "o", "lse", "qmask", "keyinfo", "ktile_flags", "q_ptr", "q_kt", "q_order", "vmean"):
+        setattr(a, f_, one.data_ptr())
+    a.batch, a.heads, a.nq, a.nk, a.nk_pad, a.n_qtiles, a.n_ktiles, a.scale, a.flags = 1, 1, 16, 16, 64, 1, 1, 0.125, 0
+    a.q_ld = a.kv_ld = a.o_ld = 64
+    assert H.lib().mca_attn_fwd(C.byref(a), None) == -3
+    a2 = H.AttnBwd2Args()
+    for f_ in ("q", "k", "v", "d_o", "lse", "delta", "dvmean", "dq", "dk", "dv", "qmask", "keyinfo", "ktile_flags", "q_ptr", "q_kt", "q_order", "k_wg", "k_qt"):
+        setattr(a2, f_, one.data_ptr())
+    a2.batch, a2.heads, a2.nq, a2.nk, a2.nk_pad, a2.scale, a2.flags = 1, 1, 16, 16, 256, 0.125, 0
+    a2.q_ld = a2.kv_ld = a2.o_ld = a2.dq_ld = a2.dkv_ld = 64
+    a2.n_qtiles128, a2.n_ktiles64, a2.n_qtiles64, a2.n_kblocks256, a2.kblock_keys = 1, 1, 1, 1, 256
+    assert H.lib().mca_attn_bwd_dq(C.byref(a2), None) == -3 and H.lib().mca_attn_bwd_dkv(C.byref(a2), None) == -3
 
 
-@pytest.mark.parametrize("prescaled,form", [(True, 0), (False, 0), (True, 2), (False, 2)])
-def test_attention_spiked_keys(H, prescaled, form):
+def test_attention_spiked_keys(H):
     """keys 40x larger than their neighbours in the first, second and third key tile of a row and at the very end: the running
-    maximum of the forward softmax jumps mid-row and starts from scores far below zero (for the second form: its lazy
-    reference has to move at a row's first tile and grow later)."""
+    maximum of the forward softmax jumps mid-row and starts from scores far below zero."""
     S = importlib.import_module("mca-paper_amd.structure")
     st = S.FusionStructure([300, 100, 60], 8, (3, 2), fcl=True)
-    with H.knobs(k13=form):
-        _attention_case(H, st, b=2, heads=2, pool=False, seed=17, drop_first=True, prescaled=prescaled, spike=True)
+    _attention_case(H, st, b=2, heads=2, pool=False, seed=17, drop_first=True, spike=True)
 
 
 @pytest.mark.parametrize("variant,pool", [("mca", False), ("zorro", False), ("mca", True)])

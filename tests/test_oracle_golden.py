@@ -106,3 +106,13 @@ def test_fp64_and_bf16emu_modes_run():
     e16 = (o16["pooled"].double() - o64["pooled"]).norm() / o64["pooled"].norm()
     assert e32 < 1e-5
     assert 1e-5 < e16 < 2e-2          # bf16 rounding is visible but bounded
+
+
+def test_golden_recipe_takes_one_flag_per_process():
+    """oracle/make_goldens.py refuses two flags in one process: the reference shares its loss temperature (a module-level
+    nn.Parameter) between the models of a process, so the order of the cases would change the goldens.
+    The refusal comes from the argument parser, before the reference is imported: it holds on the GPU box too."""
+    import os, subprocess, sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "make_goldens.py")
+    r = subprocess.run([sys.executable, script, "--eao", "--tiny"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "one flag per process" in r.stderr

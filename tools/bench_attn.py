@@ -26,23 +26,19 @@ a["qkv"][:, :D] *= 0.18          # q as the engine stores it (scale * log2 e fol
 ws["do"].copy_(torch.randn_like(ws["do"].float()).bfloat16())
 def fwd(): eng._attn_fwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], a["lse"], eng.qmask_attn, eng.sched_attn_f, ws, b, N)
 def bwd():
-    if eng.attn_bwd_two_pass:
-        eng._attn_bwd2(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], ws["do"], a["lse"], ws["delta"], a["dqkv"].data_ptr(), N*3*D, 3*D, False,
-                       a["dqkv"], D, 2*D, 3*D, eng.qmask_attn, eng.sched_attn_f, eng.sched_attn_b2, ws, b, N)
-    else:
-        ws["dq32"].zero_()
-        eng._attn_bwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], ws["do"], a["lse"], ws["delta"], ws["dq32"], N*D, a["dqkv"], D, 2*D, 3*D, eng.qmask_attn, eng.sched_attn_b, ws, b, N)
+    eng._attn_bwd2(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], ws["do"], a["lse"], ws["delta"], a["dqkv"].data_ptr(), N*3*D, 3*D, False,
+                   a["dqkv"], D, 2*D, 3*D, eng.qmask_attn, eng.sched_attn_f, eng.sched_attn_b2, ws, b, N)
 def timeit(fn, n=10):
     for _ in range(3): fn()
     torch.cuda.synchronize()
-    H.profile_start(("mca_attn_fwd", "mca_attn_fwd_fp8", "mca_attn_quant_mxfp8", "mca_attn_bwd", "mca_attn_bwd_dq", "mca_attn_bwd_dkv", "mca_attn_bwd_dq_fp8", "mca_attn_bwd_dkv_fp8", "mca_attn_quant_bwd_mxfp8"))
+    H.profile_start(("mca_attn_fwd", "mca_attn_fwd_fp8", "mca_attn_quant_mxfp8", "mca_attn_bwd_dq", "mca_attn_bwd_dkv", "mca_attn_bwd_dq_fp8", "mca_attn_bwd_dkv_fp8", "mca_attn_quant_bwd_mxfp8"))
     for _ in range(n): fn()
     return H.profile_stop()
 def fwd8():
     eng.set_attention_dtype("fp8"); fwd(); eng.set_attention_dtype("bf16")
 def bwd8():
     eng.set_attention_dtype("fp8"); bwd(); eng.set_attention_dtype("bf16")
-cases = [("fwd", fwd, {}), ("fwd second form", fwd, {13: 2}), ("fwd fp8", fwd8, {}), ("bwd", bwd, {}), ("bwd fp8", bwd8, {})]
+cases = [("fwd", fwd, {}), ("fwd fp8", fwd8, {}), ("bwd", bwd, {}), ("bwd fp8", bwd8, {})]
 if os.environ.get("MCA_BENCH_ATTN_ONLY"):
     cases = [c for c in cases if c[0] == os.environ["MCA_BENCH_ATTN_ONLY"]]
 if os.environ.get("MCA_BENCH_ATTN_EXTRA"):

@@ -1,5 +1,5 @@
 """Run-to-run noise of the production step's gradients (same weights, same batch): per-tensor rel-L2 between repeats, under
-the engine's A/B switches.  usage: diag_step_noise.py [kind] [b] [repeats]   env: MCA_ATTN_BWD_ONE_PASS, MCA_OVERLAP_WGRAD, ..."""
+the engine's A/B switches.  usage: diag_step_noise.py [kind] [b] [repeats]   env: MCA_DEBUG=overlap_wgrad=1,... (engine.debug_options)"""
 import sys, os, importlib, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 P = importlib.import_module("mca-paper_amd"); data = importlib.import_module("mca-paper_amd.data")

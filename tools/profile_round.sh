@@ -1,12 +1,12 @@
 #!/bin/bash
 # The rocprofv3 passes behind profiles/rNN_* (run on the GPU box from the repo root: bash tools/profile_round.sh <outdir>).
 # Kernel durations and counters come from SEPARATE runs (never --pmc together with --stats); weight gradients stay on the main
-# stream (MCA_OVERLAP_WGRAD=0) so that every duration is a kernel's own.
+# stream (MCA_DEBUG=overlap_wgrad=0) so that every duration is a kernel's own.
 set -o pipefail
 OUT=$(realpath -m "${1:-gpurun_out/prof}"); mkdir -p "$OUT"
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-export MCA_OVERLAP_WGRAD=0 PYTHONPATH=$ROOT
+export MCA_DEBUG=overlap_wgrad=0 PYTHONPATH=$ROOT
 B="$ROOT/bench.py"
 run() { echo "== $*"; timeout -k 10 400 "$@" > "$OUT/last.log" 2>&1 || { echo "FAILED: $*"; tail -5 "$OUT/last.log"; return 1; }; }
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o t -- python3 $B --launch eager --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing &&
