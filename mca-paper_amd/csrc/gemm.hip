@@ -1084,7 +1084,10 @@ extern "C" int mca_gemm_nt_geglu_bwd(const uint16_t* A, int64_t lda, const uint1
   const int tiles_n = (int)((N + BN - 1) / BN);
   const float* hres = reinterpret_cast<const float*>(h);
   void* C = dh;
-  if (M >= 2048) {
+  // below ~40k rows (the data-parallel configs' 8 samples per GPU: 20,304 rows) the 128 x 128 kernel, two or three workgroups
+  // per CU whose epilogues (0.9 GB of h / dh traffic at b = 32) overlap each other's k-loops, beats the persistent 256 x 128
+  // one (65 against 75 us at b = 8; 308 against 282 at b = 32: tools/bench_step_gemms.py); knob 1 = 1 forces it (A/B)
+  if (M >= 40960 && g_knob[1] != 1) {
     const int nwg2 = (int)((M + BM2 - 1) / BM2) * tiles_n;
     static bool attr = false;
     if (!attr) {

@@ -228,7 +228,8 @@ def test_gemm_geglu_fwd_fused(H, rows, ip, D):
     assert rel(out.float(), torch.nn.functional.gelu(hb[:, ip:]) * hb[:, :ip]) < 4e-3
 
 
-@pytest.mark.parametrize("rows,ip,D", [(500, 384, 128), (4100, 384, 128), (4100, 384, 512), (2304, 640, 320), (2100, 1408, 512)])
+@pytest.mark.parametrize("rows,ip,D", [(500, 384, 128), (4100, 384, 128), (4100, 384, 512), (2304, 640, 320), (2100, 1408, 512),
+                                       (41100, 384, 128), (41100, 384, 512)])          # >= 40,960 rows: the 256-row kernels
 def test_gemm_geglu_bwd_fused(H, rows, ip, D):
     g = torch.Generator(device="cuda").manual_seed(41)
     h = bf(torch.randn(rows, 2 * ip, device="cuda", generator=g))
