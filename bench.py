@@ -30,7 +30,7 @@ sys.path.insert(0, REPO)
 MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic GFLOP per sample per step, mask-aware, 2 flop/MAC, bwd = 2 x fwd
 STEP_GFLOP = {"cmu_mca": 334.8, "cmu_mma": 337.4, "long_mca": 885.7}
-PMC_JSON = os.path.join("profiles", "r02_hbm_traffic_pmc.json")
+PMC_JSON = os.path.join("profiles", "r03_hbm_traffic_pmc.json")
 
 
 def pmc_traffic(kernel_key: str):
@@ -40,8 +40,8 @@ def pmc_traffic(kernel_key: str):
     committed for that kernel."""
     path = os.path.join(REPO, PMC_JSON)
     names = {"mca_gemm_nt": "gemm_nt_", "mca_gemm_tn_acc": "gemm_tn_", "mca_gemm_tn_acc_group": "gemm_tn_256x256_group_kernel",
-             "mca_attn_fwd/layer": "attn_fwd", "mca_attn_bwd/layer": "attn_bwd_kernel", "mca_attn_bwd_dkv/layer": "attn_bwd_dkv",
-             "mca_attn_bwd_dq/layer": "attn_bwd_dq", "mca_gemm_nt_geglu_fwd": "gemm_nt_persist256_kernel<true>",
+             "mca_attn_fwd/layer": "attn_fwd_kernel", "mca_attn_bwd_dkv/layer": "attn_bwd_dkv_kernel",
+             "mca_attn_bwd_dq/layer": "attn_bwd_dq_kernel", "mca_gemm_nt_geglu_fwd": "gemm_nt_persist256_kernel<true>",
              "mca_gemm_nt_geglu_bwd": "gemm_nt_persist_kernel<3", "mca_gemm_nt_lnres": "gemm_nt_256_kernel<false, 1, 1, 2>"}
     if not os.path.exists(path) or kernel_key not in names:
         return None
