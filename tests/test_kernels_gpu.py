@@ -516,6 +516,51 @@ def test_attention_small(H, variant, pool, drop):
     _attention_case(H, st, b=3, heads=2, pool=pool, seed=11, drop_first=drop)
 
 
+@pytest.mark.parametrize("shape", ["small", "cmu"])
+def test_attention_register_staged_forward_form(H, shape):
+    """the forward kernel that structures with more than 15 key groups take (register staging, 3 wavefronts per SIMD) on a
+    structure that has the one-hot operand too (knob 13 = 1 selects it): same contract as the LDS-DMA production kernel."""
+    S = importlib.import_module("mca-paper_amd.structure")
+    st = S.FusionStructure([70, 45, 30], 8, (3, 2), fcl=True) if shape == "small" else S.FusionStructure([1500, 450, 450, 50], 88, (4, 3, 2), fcl=True)
+    with H.knobs(k13=1):
+        _attention_case(H, st, b=2, heads=2, pool=False, seed=13, drop_first=True)
+
+
+def test_attention_forward_kernels_agree_bit_for_bit(H):
+    """the LDS-DMA forward (production, 4 wavefronts per SIMD) and the register-staged one (knob 13 = 1) do the same
+    arithmetic in the same order: identical o and lse on the CMU structure with ragged lengths and a dropped modality"""
+    P = importlib.import_module("mca-paper_amd")
+    b = 3
+    cfg = P.config.cmu_model_config(batch_size=b); cfg["depth"] = 1
+    torch.manual_seed(0)
+    eng = P.MCA(**cfg).cuda().engine
+    ws = eng.workspace(b); N, D = eng.N, eng.D
+    g = torch.Generator(device="cuda").manual_seed(7)
+    ws["padding"].zero_()
+    for mi, n in enumerate(eng.st.token_dims):
+        ln = torch.randint(1, n + 1, (b,), device="cuda", generator=g)
+        if mi == 2:
+            ln[1] = 0
+        ws["padding"][:, eng.offsets[mi]:eng.offsets[mi] + n] = (torch.arange(n, device="cuda")[None] >= ln[:, None]).to(ws["padding"].dtype)
+    H.call("mca_build_keyinfo", ws["padding"].data_ptr(), eng.kgroup.data_ptr(), ws["keyinfo"].data_ptr(), ws["kflags"].data_ptr(), b, N, eng.nk_pad, H.stream_ptr())
+    H.call("mca_build_keyhot", ws["keyinfo"].data_ptr(), ws["khot"].data_ptr(), b, eng.nk_pad, H.stream_ptr())
+    a = ws["layers"][0]
+    a["qkv"].copy_((torch.randn(b * N, 3 * D, device="cuda", generator=g) * 2.0).bfloat16())
+    a["qkv"][:, :D] *= 0.18
+
+    def fwd():
+        a["o"].zero_()
+        eng._attn_fwd(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], a["lse"], eng.qmask_attn, eng.sched_attn_f, ws, b, N)
+        torch.cuda.synchronize()
+        return a["o"].clone(), a["lse"].clone()
+
+    o4, l4 = fwd()
+    with H.knobs(k13=1):
+        o1, l1 = fwd()
+    assert torch.isinf(l4).any() and torch.isfinite(l4).any()
+    assert torch.equal(o4, o1) and torch.equal(l4, l1)
+
+
 def test_attention_unprescaled_q_is_refused(H):
     """q must carry scale * log2 e (MCA_ATTN_Q_PRESCALED): the un-prescaled kernel forms (one of which spilled 579 registers)
     left the library in round 3; every attention entry point refuses a call without the flag instead of computing something

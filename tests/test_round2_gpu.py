@@ -327,27 +327,34 @@ def test_graphed_step_at_cmu_size_matches_eager(P):
     graph = importlib.import_module("mca-paper_amd.graph")
     cfg = P.config.cmu_model_config(batch_size=2)
     batch = P.data.synthetic_batch(cfg, 2, seed=1234, lengths="uniform", p_drop=0.3, device="cuda")
-    hist = {}
+    # Both loops run in lockstep and every step STARTS FROM THE SAME STATE (the eager model's weights, moments and step count are
+    # copied into the replayed one): the loss of this model is a difference of O(10^3) logits, so two free-running loops drift
+    # apart by ~1 % within three steps from the order of fp32 atomic adds alone (the eager loop against itself does), which
+    # would force a tolerance too wide to see a broken replay.
+    models = {}
     for mode in ("eager", "graph"):
         torch.manual_seed(43)
         m = P.MCA(**cfg).cuda(); m.engine.check_finite = "deferred"
         opt = optim.FusedAdamW(m, lr=1e-5)
-        g = graph.GraphedStep(m, opt, batch, clip=2.0) if mode == "graph" else None
-        rows = []
-        for _ in range(4):
-            if g is None:
-                out = m(batch); opt.zero_grad(); out["loss"].backward(); gn = optim.clip_grad_norm_(m, 2.0); opt.step()
-                rows.append((float(out["loss"].detach()), float(gn)))
-            else:
-                loss = g.step(batch)
-                rows.append((float(loss), float(g.gnorm)))
-            emb = (g.out if g is not None else out)[m.modality_types[0]]
-            assert bool(torch.isfinite(emb).all())
-        torch.cuda.synchronize(); m.engine.assert_finite()
-        assert bool(torch.isfinite(m.engine.gflat).all()) and float(m.engine.gflat.abs().max()) < 1e4
-        hist[mode] = rows
-    for (le, ge), (lg, gg) in zip(hist["eager"], hist["graph"]):
-        assert abs(le - lg) <= 5e-3 * abs(le) and abs(ge - gg) <= 2e-2 * ge, hist
+        models[mode] = (m, opt)
+    (me, oe), (mg, og) = models["eager"], models["graph"]
+    g = graph.GraphedStep(mg, og, batch, clip=2.0)
+    hist = []
+    for step in range(4):
+        mg.engine.flat.copy_(me.engine.flat); og.exp_avg.copy_(oe.exp_avg); og.exp_avg_sq.copy_(oe.exp_avg_sq); og.step_count = oe.step_count
+        mg.engine.invalidate_weights()
+        out = me(batch); oe.zero_grad(); out["loss"].backward(); gn = optim.clip_grad_norm_(me, 2.0); oe.step()
+        loss = g.step(batch)
+        torch.cuda.synchronize()
+        le, ge, lg, gg = float(out["loss"].detach()), float(gn), float(loss), float(g.gnorm)
+        hist.append((le, lg, ge, gg))
+        assert bool(torch.isfinite(g.out[mg.modality_types[0]]).all())
+        assert bool(torch.isfinite(mg.engine.gflat).all()) and float(mg.engine.gflat.abs().max()) < 1e4
+        # same weights, same kernels: the forward is bitwise reproducible; the gradients differ by atomic order only
+        assert abs(le - lg) <= 1e-6 * abs(le) and abs(ge - gg) <= 2e-3 * ge, hist
+        assert rel_err(mg.engine.gflat, me.engine.gflat) < 5e-3, hist
+    me.engine.assert_finite(); mg.engine.assert_finite()
+    assert hist[0][0] != hist[3][0]                      # the four steps really trained
 
 
 # ------------------------------------------------------------------------------------------------ the training script
