@@ -325,6 +325,10 @@ __global__ __launch_bounds__(256, FWD4_WAVES) void attn_fwd4_kernel(mca_attn_fwd
   __shared__ uint8_t flags_s[MAX_KTILES];
   __shared__ uint32_t live_s[MAX_KTILES];
   __shared__ int n_live_s;
+#ifdef FWD4_PAD_LDS          // measurement only (tools/ab_fwd_forms.py): dead LDS that caps the workgroups per CU at three
+  __shared__ uint32_t pad_s[FWD4_PAD_LDS / 4];
+  if (dbg == 0x7fffffff) pad_s[threadIdx.x] = 1;
+#endif
   u16* Ks = lds;
   u16* Vs = lds + 2 * AK * DH;
   u16* Hs = lds + 4 * AK * DH;
