@@ -233,12 +233,33 @@ def main():
         ok = torch.tensor([0 if err is not None else 1], device=dev, dtype=torch.int32)
         if world > 1:                   # every rank takes the same path
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok) and world > 1 and args.launch == "auto" and not args.graph:
+            # Guard for the data-parallel replay (graph segments with eager collectives between them): time two replayed against
+            # two eager steps (max over ranks) and keep the replay only if it is not slower.  The pool has one GPU per box, so the
+            # segmented replay has only met RCCL on a world of one rank; with gloo on one shared GPU it is pathologically slow
+            # (5.6 s per step: gloo's host threads synchronise streams while hipGraphLaunch holds the runtime) - a measurement
+            # must never pay for such an interaction.
+            def timed_pair(eager):
+                dist.barrier(); torch.cuda.synchronize(); t = time.perf_counter()
+                for _ in range(2):
+                    graphed.step(eager=eager)
+                torch.cuda.synchronize()
+                tt = torch.tensor([time.perf_counter() - t], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                return float(tt)
+            t_replay, t_eager = timed_pair(False), timed_pair(True)
+            if t_replay > 1.05 * t_eager:
+                if rank == 0:
+                    print(f"bench: segmented replay {t_replay / 2 * 1e3:.1f} ms/step against {t_eager / 2 * 1e3:.1f} ms eager: running the eager loop", file=sys.stderr, flush=True)
+                ok.zero_()
         if int(ok):
             step = graphed.step
         else:
-            print(f"bench: hipGraph capture failed on rank {rank} ({type(err).__name__ if err else 'another rank'}: {err}); running the eager loop", file=sys.stderr, flush=True)
+            if err is not None or graphed is None:
+                print(f"bench: hipGraph capture failed on rank {rank} ({type(err).__name__ if err else 'another rank'}: {err}); running the eager loop", file=sys.stderr, flush=True)
             use_graph, graphed = False, None
             opt.hyper_external = False
+            eng.overlap_wgrad = eng.dbg["overlap_wgrad"]          # (GraphedStep switched the side stream off)
 
     for w in range(args.warmup):
         exclusive = w == 0 and not args.no_kernel_timing and args.warmup > 1 and not use_graph      # also warm the schedule the sampled steps use

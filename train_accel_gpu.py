@@ -159,9 +159,9 @@ def main():
     step = config.start_epoch * steps_per_epoch
     if config.restart and "scheduler_last_epoch" in meta:          # the restored scheduler position, as load_state gives the reference
         step = meta["scheduler_last_epoch"] // sched_stride
-    # --graph (single GPU): the whole step replayed as one hipGraph (graph.GraphedStep; batches have static shapes: the
-    # collators pad every modality to its pad_len)
-    use_graph, graphed = "--graph" in sys.argv and world == 1, None
+    # --graph: the whole step replayed as one hipGraph, or under data parallelism as a chain of graph segments cut at the
+    # collectives (graph.GraphedStep; batches have static shapes: the collators pad every modality to its pad_len)
+    use_graph, graphed = "--graph" in sys.argv, None
     lr_at = lambda st: config.lr * lr_factor(config.lr_scheduler_type, st * sched_stride, config.num_warmup_steps, total_steps * sched_stride)
     model.train()
     for epoch in range(config.start_epoch, config.epochs):
@@ -177,7 +177,7 @@ def main():
                 g["lr"] = lr_at(step)
             if use_graph:
                 if graphed is None:
-                    graphed = importlib.import_module("mca-paper_amd.graph").GraphedStep(model, opt, batch, clip=config.clip or 0.0)
+                    graphed = importlib.import_module("mca-paper_amd.graph").GraphedStep(model, opt, batch, clip=config.clip or 0.0, dp=dp)
                 loss = graphed.step(batch)
                 outputs, gnorm = graphed.out, graphed.gnorm
                 step += 1
