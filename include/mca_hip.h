@@ -251,9 +251,11 @@ int mca_attn_fwd_fp8(const mca_attn_fwd_args* args, const mca_attn_fp8_operands*
  * 32 ALONG d, the contraction of both products), npad = n_ktiles * 64, rows >= n zero.  q8 / k8 are the arrays of
  * mca_attn_quant_mxfp8, so S is bit for bit the S of mca_attn_fwd_fp8 and P = 2^(S - lse) is consistent with its lse.   */
 typedef struct { uint8_t* q8; uint8_t* qs; uint8_t* k8; uint8_t* ks; uint8_t* v8; uint8_t* vs; uint8_t* do8; uint8_t* dos; int n_ktiles; } mca_attn_fp8_bwd_operands;
+/* which: bit 0 q, bit 1 k, bit 2 v, bit 3 dO are quantised by this call (15 = all; 12 = v and dO when f->q8 / f->k8 point at
+ * the arrays the forward's mca_attn_quant_mxfp8 wrote for the same layer)                                              */
 int mca_attn_quant_bwd_mxfp8(const uint16_t* q, int64_t q_bstride, int64_t q_ld, const uint16_t* k, const uint16_t* v,
                              int64_t kv_bstride, int64_t kv_ld, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld,
-                             const mca_attn_fp8_bwd_operands* f, int batch, int heads, int n, mca_stream_t stream);
+                             const mca_attn_fp8_bwd_operands* f, int which, int batch, int heads, int n, mca_stream_t stream);
 /* mca_attn_bwd_dq / mca_attn_bwd_dkv (arguments as documented below) with those operands; self-attention,
  * MCA_ATTN_Q_PRESCALED and the mask product (khot / qblk) required, kblock_keys = 128 for the dkv pass; the q / v pointers
  * of args are read only by the dkv pass (bf16 Q tile of the dK product); dQ, dK, dV products stay bf16 / fp32.            */

@@ -126,6 +126,9 @@ extern "C" int mca_attn_quant_mxfp8(const uint16_t* q, int64_t q_bstride, int64_
 // group then cover all 64 banks (64-byte rows: four rows per 256-byte bank row)
 __device__ __forceinline__ int t8_off(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
 
+// DMA: the K8 / V8T / scale / one-hot tiles go global -> LDS by LDS-DMA (needs the mask product's one-hot operand), the swizzle of
+// the tile images applied on the source chunk; otherwise through registers (structures with more than 15 key groups)
+template <bool DMA>
 __global__ __launch_bounds__(256) void attn_fwd8_kernel(mca_attn_fwd_args a, mca_attn_fp8_operands f, int dbg) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[2 * 2 * AK * DH];   // K8, V8T double-buffered: 16 KiB
   __shared__ __attribute__((aligned(16))) uint8_t sc_s[2][2][AK * 2];     // [buffer][K | V][row][half] scale bytes
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256) void attn_fwd8_kernel(mca_attn_fwd_args a, mca
   }
   const uint32_t qm = a.qmask[qrow];
   // the mask as a matrix product (mca_build_keyhot; a bf16 32x32x16 product into the same fp32 accumulators)
-  const bool use_hot = a.khot != nullptr;
+  const bool use_hot = DMA || a.khot != nullptr;
   bf16x8 qblk;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
@@ -210,6 +213,23 @@ __global__ __launch_bounds__(256) void attn_fwd8_kernel(mca_attn_fwd_args a, mca
     else if (tid < 16) *reinterpret_cast<uint32_t*>(&kinfo[buf][tid * 4]) = rinfo;
   };
 
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto stage_dma = [&](int kt, int buf) {
+    const int sw = scol ^ ((srow >> 2) & 3);          // t8_off: LDS slot scol of row srow holds source chunk scol ^ swizzle(row)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(k8b + ((int64_t)kt * AK + srow) * DH + 16 * sw),
+                                     (__attribute__((address_space(3))) void*)(Ks + buf * AK * DH + wave_u * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(v8b + ((int64_t)kt * DH + srow) * AK + 16 * sw),
+                                     (__attribute__((address_space(3))) void*)(Vs + buf * AK * DH + wave_u * 1024), 16, 0, 0);
+    if (wave_u < 2)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(khot_g + (int64_t)kt * (AK * 16) + tid * 8),
+                                       (__attribute__((address_space(3))) void*)(&hot_s[buf][wave_u * 512]), 16, 0, 0);
+    if (wave_u == 2) {          // 128 + 128 scale bytes: lanes 0..31 the K scales, 32..63 the V scales, 4 bytes each
+      const uint8_t* sp = (lane < 32 ? ksb + (int64_t)kt * AK * 2 : vsb + (int64_t)kt * DH * 2) + (lane & 31) * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                       (__attribute__((address_space(3))) void*)(&sc_s[buf][0][0]), 4, 0, 0);
+    }
+  };
+
   if (wave == 0) {
     const int lb = a.q_ptr[qt], le = a.q_ptr[qt + 1];
     int n = 0;
@@ -226,7 +246,10 @@ __global__ __launch_bounds__(256) void attn_fwd8_kernel(mca_attn_fwd_args a, mca
   __syncthreads();
   const int it_end = n_live_s;
   int it = 0, buf = 0;
-  if (it < it_end) { gload((int)(live_s[0] & 0x7fffffffu)); swrite(0); }
+  if (it < it_end) {
+    if (DMA) { stage_dma((int)(live_s[0] & 0x7fffffffu), 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    else { gload((int)(live_s[0] & 0x7fffffffu)); swrite(0); }
+  }
   __syncthreads();
 
   while (it < it_end) {
@@ -234,7 +257,7 @@ __global__ __launch_bounds__(256) void attn_fwd8_kernel(mca_attn_fwd_args a, mca
     const int kt = (int)(ent & 0x7fffffffu);
     const bool need_mask = (ent >> 31) == 0 || (flags_s[kt] != 2);
     const int nit = it + 1;
-    if (nit < it_end) gload((int)(live_s[nit] & 0x7fffffffu));
+    if (nit < it_end) { if (DMA) stage_dma((int)(live_s[nit] & 0x7fffffffu), buf ^ 1); else gload((int)(live_s[nit] & 0x7fffffffu)); }
 
     const uint8_t* ks = Ks + buf * AK * DH;
     const uint8_t* vs = Vs + buf * AK * DH;
@@ -314,7 +337,8 @@ __global__ __launch_bounds__(256) void attn_fwd8_kernel(mca_attn_fwd_args a, mca
       o[n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf, o[n], 0, 0, 0, vscale, 0, 127);
     }
 
-    if (nit < it_end) swrite(buf ^ 1);
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wavefront's pieces of the next tile have landed
+    else if (nit < it_end) swrite(buf ^ 1);
     __syncthreads();
     buf ^= 1;
     it = nit;
@@ -353,7 +377,9 @@ extern "C" int mca_attn_fwd_fp8(const mca_attn_fwd_args* a, const mca_attn_fp8_o
       (uintptr_t)f->ks % 4 || (uintptr_t)f->vs % 4 || (uintptr_t)a->khot % 16)
     return MCA_E_ALIGN;
   if (a->heads > 65535 || a->batch > 65535 || a->n_ktiles > MAX_KTILES) return MCA_E_UNSUPPORTED;
-  hipLaunchKernelGGL(attn_fwd8_kernel, dim3(a->n_qtiles, a->heads, a->batch), dim3(256), 0, as_stream(stream), *a, *f, mca_knobs[9]);
+  const dim3 grid(a->n_qtiles, a->heads, a->batch);
+  if (a->khot && !(mca_knobs[9] & 32)) hipLaunchKernelGGL(attn_fwd8_kernel<true>, grid, dim3(256), 0, as_stream(stream), *a, *f, mca_knobs[9]);          // knob 9 bit 32: register staging (A/B)
+  else hipLaunchKernelGGL(attn_fwd8_kernel<false>, grid, dim3(256), 0, as_stream(stream), *a, *f, mca_knobs[9]);
   return launch_status();
 }
 
@@ -373,7 +399,7 @@ __global__ __launch_bounds__(256) void attn_quant_rows4_kernel(const u16* __rest
                                                                 const u16* __restrict__ k, const u16* __restrict__ v,
                                                                 int64_t kv_bstride, int64_t kv_ld, const u16* __restrict__ d_o,
                                                                 int64_t o_bstride, int64_t o_ld, mca_attn_fp8_bwd_operands f,
-                                                                int heads, int n, int ntiles) {
+                                                                int heads, int n, int ntiles, int which_mask) {
   const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   const int r = tid >> 2, c = tid & 3;
   const int tok = kt * AK + r;
@@ -382,6 +408,7 @@ __global__ __launch_bounds__(256) void attn_quant_rows4_kernel(const u16* __rest
   const int64_t t = live ? tok : 0;
 #pragma unroll
   for (int which = 0; which < 4; which++) {
+    if (!((which_mask >> which) & 1)) continue;
     const u16* src = which == 0 ? q + (int64_t)b * q_bstride + t * q_ld
                    : which == 1 ? k + (int64_t)b * kv_bstride + t * kv_ld
                    : which == 2 ? v + (int64_t)b * kv_bstride + t * kv_ld
@@ -409,8 +436,8 @@ static int check_fp8_bwd_operands(const mca_attn_fp8_bwd_operands* f) {
 
 extern "C" int mca_attn_quant_bwd_mxfp8(const uint16_t* q, int64_t q_bstride, int64_t q_ld, const uint16_t* k, const uint16_t* v,
                                         int64_t kv_bstride, int64_t kv_ld, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld,
-                                        const mca_attn_fp8_bwd_operands* f, int batch, int heads, int n, mca_stream_t stream) {
-  if (!q || !k || !v || !d_o || batch <= 0 || heads <= 0 || n <= 0) return MCA_E_BADARG;
+                                        const mca_attn_fp8_bwd_operands* f, int which, int batch, int heads, int n, mca_stream_t stream) {
+  if (!q || !k || !v || !d_o || batch <= 0 || heads <= 0 || n <= 0 || which <= 0 || which > 15) return MCA_E_BADARG;
   const int rc = check_fp8_bwd_operands(f);
   if (rc != MCA_OK) return rc;
   if (q_ld % 8 || kv_ld % 8 || o_ld % 8 || q_bstride % 8 || kv_bstride % 8 || o_bstride % 8 || (uintptr_t)q % 16 || (uintptr_t)k % 16 ||
@@ -420,7 +447,7 @@ extern "C" int mca_attn_quant_bwd_mxfp8(const uint16_t* q, int64_t q_bstride, in
   if (f->n_ktiles != ntiles) return MCA_E_BADARG;
   if (heads > 65535 || batch > 65535) return MCA_E_UNSUPPORTED;
   hipLaunchKernelGGL(attn_quant_rows4_kernel, dim3(ntiles, heads, batch), dim3(256), 0, as_stream(stream), q, q_bstride, q_ld, k, v,
-                     kv_bstride, kv_ld, d_o, o_bstride, o_ld, *f, heads, n, ntiles);
+                     kv_bstride, kv_ld, d_o, o_bstride, o_ld, *f, heads, n, ntiles, which);
   return launch_status();
 }
 

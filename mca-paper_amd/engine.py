@@ -247,32 +247,42 @@ class FusionEngine:
             raise ValueError(dtype)
         self.attn_dtype = dtype
 
-    def _fp8_operands(self, ws, b):
-        """one set of MX-fp8 operand buffers per workspace (forward only: every layer reuses it)"""
-        if "fp8" not in ws:
+    def _fp8_operands(self, ws, b, layer):
+        """MX-fp8 forward operands: q8 / k8 (+ scales) PER LAYER (the backward's score recomputes read them again: 2 x 1.03 bytes
+        per q / k element and layer, 4 GB at configs[4]'s b = 128), one shared V^T set (forward only)"""
+        key = ("fp8", layer)
+        if key not in ws:
             nt = (self.N + 63) // 64
             u8 = lambda *s: torch.zeros(*s, dtype=torch.uint8, device=self.device)
+            if "fp8v" not in ws:
+                ws["fp8v"] = dict(v8t=u8(b, self.H, nt, 64, 64), vs=u8(b, self.H, nt, 64, 2))
             bufs = dict(q8=u8(b, self.H, nt * 64, 64), qs=u8(b, self.H, nt * 64, 2), k8=u8(b, self.H, nt * 64, 64), ks=u8(b, self.H, nt * 64, 2),
-                        v8t=u8(b, self.H, nt, 64, 64), vs=u8(b, self.H, nt, 64, 2))
+                        **ws["fp8v"])
             f = AttnFp8Operands()
             f.q8, f.qs, f.k8, f.ks, f.v8t, f.vs = (bufs[k].data_ptr() for k in ("q8", "qs", "k8", "ks", "v8t", "vs"))
             f.n_ktiles = nt
-            ws["fp8"] = (bufs, f)
-        return ws["fp8"][1]
+            ws[key] = (bufs, f)
+        return ws[key]
 
-    def _fp8_bwd_operands(self, ws, b):
-        """one set of MX-fp8 backward operand buffers per workspace (q, k, v, dO quantised along d; every layer reuses it)"""
-        if "fp8b" not in ws:
+    def _fp8_bwd_operands(self, ws, b, layer):
+        """MX-fp8 backward operands of a layer: q8 / k8 are the arrays its forward wrote (same bits as a re-quantisation), v and
+        dO (quantised along d) share one set of buffers across layers.  -> (operands, which-mask for mca_attn_quant_bwd_mxfp8)"""
+        key = ("fp8b", layer)
+        if key not in ws:
             nt = (self.N + 63) // 64
             u8 = lambda *s: torch.zeros(*s, dtype=torch.uint8, device=self.device)
-            bufs = {k: u8(b, self.H, nt * 64, 64) for k in ("q8", "k8", "v8", "do8")}
-            bufs.update({k: u8(b, self.H, nt * 64, 2) for k in ("qs", "ks", "vs", "dos")})
+            if "fp8bv" not in ws:
+                ws["fp8bv"] = {**{k: u8(b, self.H, nt * 64, 64) for k in ("v8", "do8")}, **{k: u8(b, self.H, nt * 64, 2) for k in ("vs", "dos")}}
+            fwd = self._fp8_operands(ws, b, layer)[0]
+            bufs = {**{k: fwd[k] for k in ("q8", "qs", "k8", "ks")}, **ws["fp8bv"]}
             f = AttnFp8BwdOperands()
             for k in ("q8", "qs", "k8", "ks", "v8", "vs", "do8", "dos"):
                 setattr(f, k, bufs[k].data_ptr())
             f.n_ktiles = nt
-            ws["fp8b"] = (bufs, f)
-        return ws["fp8b"][1]
+            ws[key] = (bufs, f)
+        # q8 / k8 hold this step's q, k only if THIS forward quantised them (a forward run in bf16 leaves them stale)
+        fresh = ws.get(("fp8gen", layer)) == ws["gen"]
+        return ws[key][1], (0b1100 if fresh else 0b1111)
 
     def fp8_backward_on(self, ws, nq) -> bool:
         return self.attn_dtype == "fp8" and nq == self.N and ws.get("khot") is not None and self.dkv_keys == 128
@@ -431,7 +441,7 @@ class FusionEngine:
              ptr(rowmask), ptr(dx), dx.stride(0) if dx is not None else 0, ptr(dx_bf16),
              dx_bf16.stride(0) if dx_bf16 is not None else 0, ptr(dgamma), ptr(dbeta), rows, cols, stream_ptr())
 
-    def _attn_fwd(self, q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, lse, qmask, sched, ws, b, nq):
+    def _attn_fwd(self, q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, lse, qmask, sched, ws, b, nq, layer=0):
         N = self.N
         a = AttnFwdArgs()
         esz = 2
@@ -454,7 +464,8 @@ class FusionEngine:
             call("mca_attn_vmean", a.v, a.kv_bstride, a.kv_ld, ws["vmean"].data_ptr(), b, N, self.H, stream_ptr())
         hip.set_tag("pool" if nq != N else "layer")
         if self.attn_dtype == "fp8" and nq == N:
-            f = self._fp8_operands(ws, b)
+            f = self._fp8_operands(ws, b, layer)[1]
+            ws[("fp8gen", layer)] = ws["gen"]
             call("mca_attn_quant_mxfp8", a.q, a.q_bstride, a.q_ld, a.k, a.v, a.kv_bstride, a.kv_ld, C.byref(f), b, self.H, N, stream_ptr())
             call("mca_attn_fwd_fp8", C.byref(a), C.byref(f), stream_ptr(), flops=4.0 * 64 * sched.s.allowed_pairs * self.H * b)
         else:
@@ -462,7 +473,7 @@ class FusionEngine:
         hip.set_tag("")
 
     def _attn_bwd2(self, q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, d_o, lse, delta, dq_ptr, dq_bstride, dq_ld, dq_f32, dkv,
-                   dk_off, dv_off, dkv_ld, qmask, sched_f, sched_b, ws, b, nq):
+                   dk_off, dv_off, dkv_ld, qmask, sched_f, sched_b, ws, b, nq, layer=0):
         """two-pass backward (attention_bwd2.hip): dq (bf16 or fp32) is WRITTEN, not accumulated."""
         N, esz = self.N, 2
         call("mca_attn_bwd_prep", o.data_ptr(), d_o.data_ptr(), nq * o.stride(0), o.stride(0), lse.data_ptr(),
@@ -489,9 +500,9 @@ class FusionEngine:
         # algorithmic flops of the whole backward (2 x forward) split 3 : 5 over the passes by their share of the five
         # products a one-pass backward needs (dq pass: S, dP, dQ minus the recomputed S, dP counted once)
         if self.fp8_backward_on(ws, nq):
-            f = self._fp8_bwd_operands(ws, b)
+            f, which = self._fp8_bwd_operands(ws, b, layer)
             call("mca_attn_quant_bwd_mxfp8", a.q, a.q_bstride, a.q_ld, a.k, a.v, a.kv_bstride, a.kv_ld, a.d_o, a.o_bstride, a.o_ld,
-                 C.byref(f), b, self.H, N, stream_ptr())
+                 C.byref(f), which, b, self.H, N, stream_ptr())
             call("mca_attn_bwd_dkv_fp8", C.byref(a), C.byref(f), stream_ptr(), flops=8.0 * 64 * pairs * self.H * b * 0.6)
             call("mca_attn_bwd_dq_fp8", C.byref(a), C.byref(f), stream_ptr(), flops=8.0 * 64 * pairs * self.H * b * 0.4)
         else:
@@ -633,7 +644,7 @@ class FusionEngine:
             self.ln_fwd(xin, g, T, D, a["m1"], a["r1"], y=None if ln_in_gemm else ws["xn"], ldy=D, y_bf16=a["xn_b"], cols_pad=D)
             self.gemm_nt(a["xn_b"], w["qkv"], a["qkv"], T, 3 * D, D)
             self._attn_fwd(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], a["lse"],
-                           self.qmask_attn, self.sched_attn_f, ws, b, N)
+                           self.qmask_attn, self.sched_attn_f, ws, b, N, layer=i)
             if ln_in_gemm:
                 call("mca_gemm_nt_lnres", ptr(a["o"]), D, ptr(w["o"]), D, ptr(a["x1"]), D, ptr(xin), D, ptr(a["m1"]), ptr(a["r1"]),
                      ptr(g.data), T, D, D, stream_ptr(), flops=2.0 * T * D * D)
@@ -809,7 +820,7 @@ class FusionEngine:
             # dq | dk | dv land in dqkv as bf16, each element written once
             self._attn_bwd2(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], ws["do"], a["lse"],
                             ws["delta"], dqkv.data_ptr(), N * 3 * D, 3 * D, False, dqkv, D, 2 * D, 3 * D, self.qmask_attn,
-                            self.sched_attn_f, self.sched_attn_b2, ws, b, N)
+                            self.sched_attn_f, self.sched_attn_b2, ws, b, N, layer=i)
             # to_q.weight and to_kv.weight are adjacent in the flat gradient buffer: one (3D, D) weight-gradient GEMM
             gq = G(ly.attn.to_q.weight)
             assert G(ly.attn.to_kv.weight).data_ptr() == gq.data_ptr() + D * D * 4

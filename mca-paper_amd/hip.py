@@ -135,7 +135,7 @@ SIGNATURES = {
     "mca_attn_bwd_prep": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mca_attn_bwd_dq": (_I, [C.POINTER(AttnBwd2Args), _P]),
     "mca_attn_bwd_dkv": (_I, [C.POINTER(AttnBwd2Args), _P]),
-    "mca_attn_quant_bwd_mxfp8": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _P, _I64, _I64, C.POINTER(AttnFp8BwdOperands), _I, _I, _I, _P]),
+    "mca_attn_quant_bwd_mxfp8": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _P, _I64, _I64, C.POINTER(AttnFp8BwdOperands), _I, _I, _I, _I, _P]),
     "mca_attn_bwd_dq_fp8": (_I, [C.POINTER(AttnBwd2Args), C.POINTER(AttnFp8BwdOperands), _P]),
     "mca_attn_bwd_dkv_fp8": (_I, [C.POINTER(AttnBwd2Args), C.POINTER(AttnFp8BwdOperands), _P]),
     "mca_contrastive_workspace_bytes": (_I64, [_I, _I]),

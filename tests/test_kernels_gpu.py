@@ -808,7 +808,7 @@ def test_attention_fp8_backward(H, shape):
     for k_, t in ob.items():
         setattr(fo, k_, t.data_ptr())
     fo.n_ktiles = nt
-    H.call("mca_attn_quant_bwd_mxfp8", qkv.data_ptr(), N * 3 * D, 3 * D, kptr, vptr, N * 3 * D, 3 * D, d_o.data_ptr(), N * D, D, C.byref(fo), b, heads, N, H.stream_ptr())
+    H.call("mca_attn_quant_bwd_mxfp8", qkv.data_ptr(), N * 3 * D, 3 * D, kptr, vptr, N * 3 * D, 3 * D, d_o.data_ptr(), N * D, D, C.byref(fo), 15, b, heads, N, H.stream_ptr())
     torch.cuda.synchronize()
     sp4 = lambda t: t.float().view(b, N, heads, 64).permute(0, 2, 1, 3)
     q4, k4, v4, do4 = sp4(qkv[:, :, :D]), sp4(qkv[:, :, D:2 * D]), sp4(qkv[:, :, 2 * D:]), sp4(d_o.view(b, N, D))

@@ -38,7 +38,7 @@ def fwd8():
     eng.set_attention_dtype("fp8"); fwd(); eng.set_attention_dtype("bf16")
 def bwd8():
     eng.set_attention_dtype("fp8"); bwd(); eng.set_attention_dtype("bf16")
-cases = [("fwd", fwd, {}), ("fwd register-staged (3 wavefronts per SIMD)", fwd, {13: 1}), ("fwd fp8", fwd8, {}), ("bwd", bwd, {}), ("bwd fp8", bwd8, {})]
+cases = [("fwd", fwd, {}), ("fwd register-staged (3 wavefronts per SIMD)", fwd, {13: 1}), ("fwd fp8", fwd8, {}), ("fwd fp8 register-staged", fwd8, {9: 32}), ("bwd", bwd, {}), ("bwd fp8", bwd8, {})]
 if os.environ.get("MCA_BENCH_ATTN_ONLY"):
     cases = [c for c in cases if c[0] == os.environ["MCA_BENCH_ATTN_ONLY"]]
 if os.environ.get("MCA_BENCH_ATTN_EXTRA"):
