@@ -644,14 +644,13 @@ extern "C" int mca_attn_bwd_dkv(const mca_attn_bwd2_args* a, mca_stream_t stream
 }
 
 // =====================================================================================================
-// delta[b,h,q] = sum_d dO[q,h,d] * O[q,h,d];  dvmean[b, h*64+d] = (1/nk) sum over uniform rows (lse = +inf) of dO
+// delta[b,h,q] = sum_d dO[q,h,d] * O[q,h,d]   (dvmean: attn_dvmean_kernel below)
 // one wavefront per (b, q) row: lane covers 8 contiguous columns of the 512-wide row -> head = lane / 8
 // =====================================================================================================
 #define PREP_ROWS 32
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restrict__ o, const u16* __restrict__ d_o,
                                                              int64_t bstride, int64_t ld, const float* __restrict__ lse,
-                                                             float* __restrict__ delta, float* __restrict__ dvmean,
-                                                             int heads, int nq, float inv_nk) {
+                                                             float* __restrict__ delta, int heads, int nq) {
   // lse / delta are (b, head, q): a row touches them at a stride of nq floats per head.  They cross LDS so that the global
   // accesses are 128-byte runs along q (one row at a time they were 4-byte accesses in 8 different lines per row).
   __shared__ float lse_s[8][PREP_ROWS], del_s[8][PREP_ROWS];
@@ -663,8 +662,6 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restric
     const int h0 = c0 / DH;
     const int c = c0 + lane * 8;
     const int hl = lane >> 3;          // head of this lane inside the 512-column slab
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool any = false;
     // all PREP_ROWS / 4 rows of this wavefront are requested before any is used (a row at a time the loop is latency-bound),
     // and before the lse values the block waits for at its first barrier
     bf16x8 ovs[PREP_ROWS / 4], dvs[PREP_ROWS / 4];
@@ -686,13 +683,8 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restric
       if (q >= q_end) break;
       float part = 0.f;
       if (c < cols) {
-        const bool uni = lse_s[hl][q - q_begin] == INFINITY;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const float dvj = bf2f((u16)dvs[k][j]);
-          part += dvj * bf2f((u16)ovs[k][j]);
-          if (uni) { acc[j] += dvj; any = true; }
-        }
+        for (int j = 0; j < 8; j++) part += bf2f((u16)dvs[k][j]) * bf2f((u16)ovs[k][j]);
       }
       // 8 lanes per head
       part += __shfl_xor(part, 1, WAVE); part += __shfl_xor(part, 2, WAVE); part += __shfl_xor(part, 4, WAVE);
@@ -703,28 +695,81 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restric
       const int hh = tid / PREP_ROWS, r = tid % PREP_ROWS;
       if (h0 + hh < heads && q_begin + r < q_end) delta[((int64_t)b * heads + h0 + hh) * nq + q_begin + r] = del_s[hh][r];
     }
-    if (any && c < cols) {
-#pragma unroll
-      for (int j = 0; j < 8; j++)
-        if (acc[j] != 0.f) atomicAdd(dvmean + (int64_t)b * cols + c + j, acc[j] * inv_nk);
-    }
     __syncthreads();
   }
 }
-// (a kernel, not hipMemsetAsync: as a memset NODE of a captured step the zeroing was not ordered against the kernels around it
-// when the captured graph was a single chain - the whole backward then started from a dvmean full of stale sums)
-__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) p[i] = 0.f;
+
+// dvmean[b, h*64 + d] = (1/nk) * sum over the uniform rows (lse = +inf) of dO, in ROW ORDER: one workgroup per (sample, head)
+// lists its uniform rows (usually none: they exist only where a dropped modality empties a query's key set) and adds them in
+// a fixed order, so the value - and with it dV of every key of that sample - is bitwise reproducible (per-block atomics,
+// rounds 1-2, made dV differ from run to run at the 2e-4 level whenever a modality was dropped).  Also the zeroing of dvmean
+// (a kernel, not hipMemsetAsync: as a memset NODE of a single-chain captured step the zeroing was not ordered against the
+// kernels around it - the whole backward then started from a dvmean full of stale sums).
+#define DVM_MAX_LIST 4096
+__global__ __launch_bounds__(256) void attn_dvmean_kernel(const u16* __restrict__ d_o, int64_t bstride, int64_t ld,
+                                                           const float* __restrict__ lse, float* __restrict__ dvmean,
+                                                           int heads, int nq, float inv_nk) {
+  __shared__ int list_s[DVM_MAX_LIST];
+  __shared__ int n_s;
+  __shared__ float red[32][DH + 1];
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* l = lse + ((int64_t)b * heads + h) * nq;
+  float* out = dvmean + (int64_t)b * heads * DH + h * DH;
+  {          // the common case first: no uniform row at all (one barrier)
+    int anyu = 0;
+    for (int q = tid; q < nq; q += 256) anyu |= (l[q] == INFINITY) ? 1 : 0;
+    if (tid == 0) n_s = 0;
+    if (!__syncthreads_or(anyu)) { if (tid < DH) out[tid] = 0.f; return; }
+  }
+  // ordered compaction of the uniform rows: wavefront w of round r owns rows 256 r + 64 w .. + 63; the rounds and the
+  // wavefronts of a round append in order (a barrier per wavefront turn).  8 lanes per row (8 columns each), 32 row groups
+  // striding the list; a full list is added up and emptied (the order stays a function of the data alone).
+  const int cl = tid & 7, rg = tid >> 3;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto flush = [&]() {          // every thread, behind a barrier that made the list visible
+    const int n = n_s;
+    for (int i = rg; i < n; i += 32) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(d_o + (int64_t)b * bstride + (int64_t)list_s[i] * ld + h * DH + cl * 8);
+#pragma unroll
+      for (int j = 0; j < 8; j++) acc[j] += bf2f((u16)v[j]);
+    }
+    __syncthreads();
+    if (tid == 0) n_s = 0;
+    __syncthreads();
+  };
+  for (int q0 = 0; q0 < nq; q0 += 256) {
+    const int q = q0 + tid;
+    const bool uni = q < nq && l[q] == INFINITY;
+    const unsigned long long m = __ballot(uni);
+    for (int w = 0; w < 4; w++) {
+      if (wave == w && m) {
+        const int base = n_s;
+        if (uni) list_s[base + __popcll(m & ((1ull << lane) - 1ull))] = q;
+        if (lane == 0) n_s = base + __popcll(m);
+      }
+      __syncthreads();
+    }
+    if (n_s > DVM_MAX_LIST - 256) flush();          // (uniform over the workgroup: n_s is read behind the barrier)
+  }
+  flush();
+#pragma unroll
+  for (int j = 0; j < 8; j++) red[rg][cl * 8 + j] = acc[j];
+  __syncthreads();
+  if (tid < DH) {
+    float t = 0.f;
+    for (int r = 0; r < 32; r++) t += red[r][tid];
+    out[tid] = t * inv_nk;
+  }
 }
 extern "C" int mca_attn_bwd_prep(const uint16_t* o, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld,
                                  const float* lse, float* delta, float* dvmean, int batch, int heads, int nq, int nk,
                                  mca_stream_t stream) {
   if (!o || !d_o || !lse || !delta || !dvmean || batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0) return MCA_E_BADARG;
   if (o_ld % 8 || o_bstride % 8 || (uintptr_t)o % 16 || (uintptr_t)d_o % 16) return MCA_E_ALIGN;
-  const int64_t nz = (int64_t)batch * heads * DH;
-  hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, as_stream(stream), dvmean, nz);
+  if (heads > 65535 || batch > 65535) return MCA_E_UNSUPPORTED;
+  hipLaunchKernelGGL(attn_dvmean_kernel, dim3(heads, batch), dim3(256), 0, as_stream(stream), d_o, o_bstride, o_ld, lse, dvmean, heads, nq,
+                     1.f / (float)nk);
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((nq + PREP_ROWS - 1) / PREP_ROWS, batch), dim3(256), 0, as_stream(stream), o, d_o,
-                     o_bstride, o_ld, lse, delta, dvmean, heads, nq, 1.f / (float)nk);
+                     o_bstride, o_ld, lse, delta, heads, nq);
   return launch_status();
 }

@@ -561,6 +561,32 @@ def test_attention_forward_kernels_agree_bit_for_bit(H):
     assert torch.equal(o4, o1) and torch.equal(l4, l1)
 
 
+def test_attention_backward_prep_is_bitwise_repeatable_with_uniform_rows(H):
+    """mca_attn_bwd_prep: delta, and dvmean = (1/nk) sum of dO over the uniform rows added in row order (no atomics): the same
+    bits on every launch, the values of a direct fp64 sum, zero for samples / heads without uniform rows"""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    b, heads, nq, nk = 3, 2, 1000, 1000
+    D = heads * 64
+    o = bf(torch.randn(b * nq, D, device="cuda", generator=g)); d_o = bf(torch.randn(b * nq, D, device="cuda", generator=g))
+    lse = torch.randn(b, heads, nq, device="cuda", generator=g)
+    uni = torch.rand(b, heads, nq, device="cuda", generator=g) < 0.3
+    uni[1] = False                                      # a sample without uniform rows
+    uni[2, 1] = False                                   # a head without
+    lse[uni] = float("inf")
+    outs = []
+    for _ in range(3):
+        delta = torch.empty(b, heads, nq, device="cuda"); dvm = torch.full((b, D), 7.0, device="cuda")
+        H.call("mca_attn_bwd_prep", o.data_ptr(), d_o.data_ptr(), nq * D, D, lse.data_ptr(), delta.data_ptr(), dvm.data_ptr(), b, heads, nq, nk, H.stream_ptr())
+        torch.cuda.synchronize()
+        outs.append((delta.clone(), dvm.clone()))
+    assert all(torch.equal(outs[0][0], x[0]) and torch.equal(outs[0][1], x[1]) for x in outs[1:])
+    d4 = d_o.double().view(b, nq, heads, 64)
+    want = (d4 * uni.permute(0, 2, 1)[..., None]).sum(1).reshape(b, D) / nk
+    assert rel(outs[0][1], want.float()) < 1e-5 and float(outs[0][1][1].abs().max()) == 0 and float(outs[0][1][2, 64:].abs().max()) == 0
+    want_delta = (d_o.double() * o.double()).view(b, nq, heads, 64).sum(-1).permute(0, 2, 1)
+    assert rel(outs[0][0], want_delta.float()) < 1e-5
+
+
 def test_attention_unprescaled_q_is_refused(H):
     """q must carry scale * log2 e (MCA_ATTN_Q_PRESCALED): the un-prescaled kernel forms (one of which spilled 579 registers)
     left the library in round 3; every attention entry point refuses a call without the flag instead of computing something

@@ -366,11 +366,11 @@ def test_attention_backward_bitwise_deterministic_at_cmu_size(P, variant):
         torch.cuda.synchronize()
         snaps.append(a["dqkv"].clone())
     assert torch.isfinite(snaps[0].float()).all()
-    # dvmean (gradient of the uniform rows' mean(V)) is summed with atomics by mca_attn_bwd_prep: dv may differ in rounding
-    # when a sample has dropped modalities; dq and dk have no such input
+    # dq, dk AND dv: since round 3 dvmean (gradient of the uniform rows' mean(V), 20 % of the modalities are dropped here) is
+    # summed in row order by mca_attn_bwd_prep, not with atomics
+    assert bool(torch.isinf(a["lse"]).any())          # uniform rows exist: the dvmean path is exercised
     for s_ in snaps[1:]:
-        assert torch.equal(s_[:, :2 * D], snaps[0][:, :2 * D])
-        assert (s_[:, 2 * D:].float() - snaps[0][:, 2 * D:].float()).abs().max() <= 1e-2 * snaps[0][:, 2 * D:].float().abs().max()
+        assert torch.equal(s_, snaps[0])
 
 
 @pytest.mark.parametrize("kind,b", [("cmu", 32), ("mma", 32), ("tcga", 16)])
