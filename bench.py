@@ -268,7 +268,7 @@ def main():
             eng.overlap_wgrad = False
         step()
         eng.overlap_wgrad = saved
-    timed = ("mca_attn_fwd", "mca_attn_fwd_fp8", "mca_attn_quant_mxfp8", "mca_attn_bwd_dq", "mca_attn_bwd_dkv", "mca_attn_bwd_dq_fp8", "mca_attn_bwd_dkv_fp8", "mca_attn_quant_bwd_mxfp8", "mca_gemm_nt", "mca_gemm_nt_lnres", "mca_gemm_nt_geglu_fwd", "mca_gemm_nt_geglu_bwd",
+    timed = ("mca_attn_bwd_prep", "mca_attn_vmean_if_needed", "mca_attn_vmean", "mca_layernorm_fwd", "mca_layernorm_bwd", "mca_attn_fwd", "mca_attn_fwd_fp8", "mca_attn_quant_mxfp8", "mca_attn_bwd_dq", "mca_attn_bwd_dkv", "mca_attn_bwd_dq_fp8", "mca_attn_bwd_dkv_fp8", "mca_attn_quant_bwd_mxfp8", "mca_gemm_nt", "mca_gemm_nt_lnres", "mca_gemm_nt_geglu_fwd", "mca_gemm_nt_geglu_bwd",
              "mca_gemm_tn_acc", "mca_gemm_tn_acc_group")
     kernel_timing = not args.no_kernel_timing
     if world > 1:
