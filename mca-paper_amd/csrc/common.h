@@ -89,5 +89,13 @@ extern int mca_knobs[16];      // A/B measurement knobs, set through mca_debug_s
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mca_trace_##NAME), sizeof(unsigned long long) * (n > 1024 ? 1024 : n)) == hipSuccess ? 0 : -1; \
   }
 
+// the "done" flag of a once-per-DEVICE call site: hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute, so a
+// process that drives a second GPU must set it there too (one process per GPU is the normal case: flag 0 only)
+static inline bool* mca_dev_flag(bool (&flags)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  return &flags[dev];
+}
+
 static inline hipStream_t as_stream(mca_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? MCA_OK : MCA_E_LAUNCH; }

@@ -986,7 +986,7 @@ extern "C" int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, in
                      ldc, bias, residual, ldres, res_period, (int)M, (int)N, (int)K, tiles_n, nwg)
 #define NT_LAUNCH_256(OB, RS, PFV)                                                                                          \
   do {                                                                                                                   \
-    static bool attr = false;                                                                                            \
+    static bool attr_dev[64] = {false}; bool& attr = *mca_dev_flag(attr_dev);                                                                                            \
     if (!attr) {                                                                                                         \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<OB, RS, PFV, 0>),                            \
                               hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS_BYTES) != hipSuccess)                \
@@ -1005,7 +1005,7 @@ extern "C" int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, in
   const bool ps_res = res == 1 && !out_bf16 && ldres % 4 == 0 && (uintptr_t)residual % 16 == 0 && g_knob[7] == 3;
   // bf16 output, N % 256 == 0: 256x256 tiles (knob 10 = 1: keep the 256x128 persistent kernel, A/B)
   if (big && g_knob[7] == 0 && g_knob[10] != 1 && out_bf16 && res == 0 && !bias && N % 256 == 0 && K >= 192 && K % 32 == 0 && c16) {
-    static bool attr = false;
+    static bool attr_dev[64] = {false}; bool& attr = *mca_dev_flag(attr_dev);
     if (!attr) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_persist256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               P2_LDS_BYTES) != hipSuccess)
@@ -1022,7 +1022,7 @@ extern "C" int mca_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, in
     const int grid = nwg2 < num_cus() ? nwg2 : num_cus();
 #define NT_LAUNCH_PS(MODE, BI)                                                                                               \
   do {                                                                                                                   \
-    static bool attr = false;                                                                                            \
+    static bool attr_dev[64] = {false}; bool& attr = *mca_dev_flag(attr_dev);                                                                                            \
     if (!attr) {                                                                                                         \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_persist_kernel<MODE, BI>),                           \
                               hipFuncAttributeMaxDynamicSharedMemorySize, NTPS_LDS_BYTES) != hipSuccess)                 \
@@ -1059,7 +1059,7 @@ extern "C" int mca_gemm_nt_lnres(const uint16_t* A, int64_t lda, const uint16_t*
   if (M < 2048 || M > (1LL << 30) || N % BN || K < 512) return MCA_E_UNSUPPORTED;
   const int tiles_n = (int)(N / BN);
   const int nwg2 = (int)((M + BM2 - 1) / BM2) * tiles_n;
-  static bool attr = false;
+  static bool attr_dev[64] = {false}; bool& attr = *mca_dev_flag(attr_dev);
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<false, 1, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             NT256LN_LDS_BYTES) != hipSuccess)
@@ -1089,7 +1089,7 @@ extern "C" int mca_gemm_nt_geglu_bwd(const uint16_t* A, int64_t lda, const uint1
   // one (65 against 75 us at b = 8; 308 against 282 at b = 32: tools/bench_step_gemms.py); knob 1 = 1 forces it (A/B)
   if (M >= 40960 && g_knob[1] != 1) {
     const int nwg2 = (int)((M + BM2 - 1) / BM2) * tiles_n;
-    static bool attr = false;
+    static bool attr_dev[64] = {false}; bool& attr = *mca_dev_flag(attr_dev);
     if (!attr) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<true, 0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               NT256_LDS_BYTES) != hipSuccess ||
@@ -1124,7 +1124,7 @@ extern "C" int mca_gemm_nt_geglu_fwd(const uint16_t* A, int64_t lda, const uint1
   if (lda < K || ldb < K || ldh < 2 * ip || ldg < ip) return MCA_E_BADARG;
   if (M > (1LL << 30)) return MCA_E_UNSUPPORTED;
   if (M >= 2048 && ip % 128 == 0 && K >= 192 && g_knob[7] != 1 && g_knob[10] != 1) {
-    static bool attr2 = false;
+    static bool attr2_dev[64] = {false}; bool& attr2 = *mca_dev_flag(attr2_dev);
     if (!attr2) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_persist256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               P2_LDS_BYTES) != hipSuccess)
@@ -1138,7 +1138,7 @@ extern "C" int mca_gemm_nt_geglu_fwd(const uint16_t* A, int64_t lda, const uint1
     return launch_status();
   }
   if (M >= 2048 && ip % 64 == 0 && K >= 320 && g_knob[7] != 1) {
-    static bool attr = false;
+    static bool attr_dev[64] = {false}; bool& attr = *mca_dev_flag(attr_dev);
     if (!attr) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_persist_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               NTPS_LDS_BYTES) != hipSuccess)
@@ -1650,7 +1650,7 @@ extern "C" int mca_gemm_tn_acc(const uint16_t* A, int64_t lda, const uint16_t* B
   rps = (rps + BR - 1) / BR * BR;
   splits = (R + rps - 1) / rps;
   if (huge) {
-    static bool attr = false;
+    static bool attr_dev[64] = {false}; bool& attr = *mca_dev_flag(attr_dev);
     if (!attr) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_256x256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               TN2_LDS_BYTES) != hipSuccess)
@@ -1662,7 +1662,7 @@ extern "C" int mca_gemm_tn_acc(const uint16_t* A, int64_t lda, const uint16_t* B
     return launch_status();
   }
   if (big) {
-    static bool attr = false;
+    static bool attr_dev[64] = {false}; bool& attr = *mca_dev_flag(attr_dev);
     if (!attr) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               TN256_LDS_BYTES) != hipSuccess)
@@ -1716,7 +1716,7 @@ extern "C" int mca_gemm_tn_acc_group(const mca_tn_desc* d, int n, int64_t R, mca
   rps = (rps + BR2 - 1) / BR2 * BR2;
   splits = (R + rps - 1) / rps;
   g.rows_per_split = (int)rps;
-  static bool attr = false;
+  static bool attr_dev[64] = {false}; bool& attr = *mca_dev_flag(attr_dev);
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_256x256_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             TN2_LDS_BYTES) != hipSuccess)

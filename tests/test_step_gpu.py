@@ -90,14 +90,27 @@ def test_small_step_vs_oracle(P, variant, p_drop):
         assert e < 4 * e_emu + 2e-2, (n, e, e_emu)
     assert sorted(errs)[len(errs) // 2] < TOL_GRAD_MEDIAN
     assert abs(nat["grad_norm"] - ref["grad_norm"]) < TOL_GN * ref["grad_norm"]
-    # one clip + AdamW step (lr 1e-3): Adam's first step is ~lr*sign(g), compare the update
+    # one clip + AdamW step (lr 1e-3).  Adam's first update is -lr * g / (|g| + eps) - lr * wd * w: a sign function of the
+    # gradient, so an element whose gradient is within the bf16 error of zero may legitimately move the other way.  Two checks
+    # that do not need a blanket allowance: (a) the optimizer's arithmetic, EXACTLY, on the native gradients (clip coefficient
+    # from the native norm); (b) against the oracle's update, on the elements whose reference gradient is above the noise floor
+    # (the larger half of |g| of each tensor): the same direction in at least 99.5 % of them.
+    clip = min(1.0, 2.0 / (nat["grad_norm"] + 1e-6))
     for n, w_ref in ref["state"].items():
         upd_ref = w_ref - sd[n]
         upd_nat = nat["state"][n] - sd[n]
         if upd_ref.abs().max() < 1e-7:
             continue
-        frac_bad = ((upd_nat - upd_ref).abs() > 0.35e-3).float().mean()
-        assert frac_bad < 0.08, (n, float(frac_bad))
+        if not n.endswith("embedding.weight"):          # (the forward renormalises the embedding table in place: its update is not the optimizer's alone)
+            gc = nat["grads"][n].double() * clip
+            m_hat, v_hat = gc, gc * gc                      # first step: bias-corrected moments are g and g^2
+            want = -1e-3 * (m_hat / (v_hat.sqrt() + 1e-8)) - 1e-3 * 0.01 * sd[n].double()
+            assert (upd_nat.double() - want).abs().max() < 2e-6, (n, float((upd_nat.double() - want).abs().max()))
+        g_ref = ref["grads"][n]
+        big = g_ref.abs() >= g_ref.abs().flatten().median()
+        if int(big.sum()) >= 8:
+            agree = (torch.sign(upd_nat[big]) == torch.sign(upd_ref[big])).float().mean()
+            assert agree > 0.995, (n, float(agree))
 
 
 @pytest.mark.parametrize("case", ["mca", "mma_d40"])

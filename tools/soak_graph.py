@@ -1,7 +1,7 @@
 """Replay vs eager over several optimizer steps on every model family / data shape: loss and global gradient norm per step
 (a replayed step that goes wrong silently shows here: DESIGN.md section 5, "A memset node that was not ordered").
 usage: soak_graph.py [steps]"""
-import importlib, torch, sys, os
+import sys, importlib, torch, sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 P = importlib.import_module("mca-paper_amd"); optim = importlib.import_module("mca-paper_amd.optim"); graph = importlib.import_module("mca-paper_amd.graph")
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
@@ -35,8 +35,9 @@ for name, (mk, dkw, opts) in CASES.items():
         hist[mode] = rows
         del m, opt, g
         torch.cuda.empty_cache()
-    worst = max(max(abs(a[0] - c[0]) / abs(a[0]), abs(a[1] - c[1]) / a[1]) for a, c in zip(hist["eager"], hist["graph"]))
+    worst = max(max(abs(a[0] - c[0]) / max(abs(a[0]), 1e-12), abs(a[1] - c[1]) / max(a[1], 1e-12)) for a, c in zip(hist["eager"], hist["graph"]))
     ok = worst < 3e-2 and all(x == x and abs(x) < 1e6 for r in hist["graph"] for x in r)
     bad += not ok
     print(f"{name:28s} {'OK ' if ok else 'BAD'} worst rel dev {worst:.2e}  eager last {hist['eager'][-1]}  graph last {hist['graph'][-1]}", flush=True)
 print("soak:", "all ok" if not bad else f"{bad} BAD")
+sys.exit(1 if bad else 0)
