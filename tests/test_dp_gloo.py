@@ -148,3 +148,59 @@ def test_dp_world2_matches_single_process(tmp_path):
     err = (got["flat"] - ref).abs().max() / ref.abs().max()
     assert err < 2e-5, err
     assert got["flat"].abs().max() > 0
+
+
+def _cut_worker(rank, world, port, out):
+    """dp.gather_pooled / dp.BucketReducer with a `cut` installed (what graph.GraphedStep does while it captures and replays the
+    data-parallel step as graph segments): every collective is handed to `cut` as a closure over STATIC buffers; running the
+    recorded closures again on new buffer contents must give the same result as issuing the collectives directly."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dp = importlib.import_module("mca-paper_amd.dp")
+        g = torch.Generator().manual_seed(100 + rank)
+        b, R, D = 3, 4, 8
+        program = []
+
+        def cut(fn):
+            fn()                          # the capture pass runs the collective too (on whatever the buffers hold)
+            program.append(fn)
+
+        pooled, present = torch.zeros(b, R, D), torch.zeros(b, dtype=torch.int32)
+        bufs = (torch.empty(b, R * D + 1), torch.empty(world * b, R * D + 1))
+        flat = torch.zeros(30)
+        red = dp.BucketReducer(flat)
+        red.cut = cut
+        # "capture" pass on zeros
+        dp.gather_pooled(pooled, present, None, bufs, cut)
+        for lo, hi in ((0, 10), (10, 30)):
+            red.bucket_ready(lo, hi)
+        red.finish()
+        assert len(program) == 4          # all-gather, two bucket all-reduces, the final wait
+        # "replay" on new contents: fill the static buffers the way the captured segments would, then run the closures in order
+        pooled2, present2 = torch.randn(b, R, D, generator=g), torch.randint(0, 15, (b,), generator=g, dtype=torch.int32)
+        grads = torch.randn(30, generator=g)
+        bufs[0][:, : R * D].copy_(pooled2.reshape(b, R * D)); bufs[0][:, R * D].copy_(present2)
+        program[0]()
+        got_all = bufs[1].clone()
+        flat.copy_(grads); flat.div_(world)          # (the pre-scale is a captured kernel in the real step)
+        for fn in program[1:]:
+            fn()
+        # the same exchanges, issued directly
+        want_pooled, want_present, row0 = dp.gather_pooled(pooled2, present2)
+        ref = grads.clone() / world
+        dist.all_reduce(ref)
+        assert row0 == rank * b
+        assert torch.equal(got_all[:, : R * D].reshape(world * b, R, D), want_pooled) and torch.equal(got_all[:, R * D].to(torch.int32), want_present)
+        assert torch.allclose(flat, ref, rtol=0, atol=0)
+        if rank == 0:
+            torch.save({"ok": True}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_collectives_through_the_segment_cutter(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "cut.pt")
+    mp.spawn(_cut_worker, args=(2, port, out), nprocs=2, join=True)
+    assert torch.load(out)["ok"]
