@@ -524,34 +524,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq8_kernel(mca_attn_bwd2_args
   }
   __syncthreads();
 
-  // staging per thread and tile: two 16-byte pieces of the bf16 K tile, one of K8, one of V8, 8 bytes of the one-hot image
-  int srow[2], scc[2];
+  // staging: the bf16 K tile (512 pieces of 16 bytes), K8 and V8 (256 each), the 256 scale bytes and the one-hot tile (128 pieces)
+  // go global -> LDS by LDS-DMA; the swizzles of the tile images sit on the SOURCE chunk (piece p lands at byte 16 p)
+  int srow[2];
+  unsigned koff[2];
 #pragma unroll
-  for (int i = 0; i < 2; i++) { const int id = tid + 256 * i; srow[i] = id >> 3; scc[i] = id & 7; }
-  const int s8row = tid >> 2, s8col = tid & 3;
+  for (int i = 0; i < 2; i++) {
+    const int id = tid + 256 * i, r = id >> 3, sl = id & 7;
+    srow[i] = r;
+    koff[i] = (unsigned)(r * (int)a.kv_ld + ((sl ^ (((r >> 1) & 7) ^ (((r >> 1) & 1) << 2))) << 3));          // rt8_off
+  }
+  const int s8row = tid >> 2, s8sw = (tid & 3) ^ ((s8row >> 2) & 3);                                           // t8_off
   const int last_kt = a.n_ktiles64 - 1;
-  bf16x8 rk[2];
-  uint4 rk8, rv8;
-  uint32_t rsk = 0, rsv = 0;
-  uint2 rhot = make_uint2(0, 0);
-  auto gload = [&](int kt) {
-    rhot = *reinterpret_cast<const uint2*>(khot_g + (int64_t)kt * (AK * 16) + tid * 4);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto stage = [&](int kt, int buf) {
+    const u16* kb = kbase + (int64_t)kt * AK * a.kv_ld;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      int key = kt * AK + srow[i]; if (kt == last_kt && key > a.nk - 1) key = a.nk - 1;
-      rk[i] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * a.kv_ld + scc[i] * 8);
+      unsigned ko = koff[i];
+      if (kt == last_kt) { const int over = kt * AK + srow[i] - (a.nk - 1); if (over > 0) ko -= (unsigned)(over * (int)a.kv_ld); }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + ko),
+                                       (__attribute__((address_space(3))) void*)(kbf_s + buf * AK * DH + (i * 4 + wave_u) * 512), 16, 0, 0);
     }
-    rk8 = *reinterpret_cast<const uint4*>(k8b + ((int64_t)kt * AK + s8row) * DH + 16 * s8col);
-    rv8 = *reinterpret_cast<const uint4*>(v8b + ((int64_t)kt * AK + s8row) * DH + 16 * s8col);
-    if (tid < 32) { rsk = *reinterpret_cast<const uint32_t*>(ksb + (int64_t)kt * AK * 2 + tid * 4); rsv = *reinterpret_cast<const uint32_t*>(vsb + (int64_t)kt * AK * 2 + tid * 4); }
-  };
-  auto swrite = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; i++) *reinterpret_cast<bf16x8*>(kbf_s + buf * AK * DH + rt8_off(srow[i], scc[i])) = rk[i];
-    *reinterpret_cast<uint4*>(K8s + buf * AK * DH + t8_off(s8row, s8col)) = rk8;
-    *reinterpret_cast<uint4*>(V8s + buf * AK * DH + t8_off(s8row, s8col)) = rv8;
-    if (tid < 32) { *reinterpret_cast<uint32_t*>(&sc_s[buf][0][tid * 4]) = rsk; *reinterpret_cast<uint32_t*>(&sc_s[buf][1][tid * 4]) = rsv; }
-    *reinterpret_cast<uint2*>(&hot_s[buf][tid * 4]) = rhot;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(k8b + ((int64_t)kt * AK + s8row) * DH + 16 * s8sw),
+                                     (__attribute__((address_space(3))) void*)(K8s + buf * AK * DH + wave_u * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(v8b + ((int64_t)kt * AK + s8row) * DH + 16 * s8sw),
+                                     (__attribute__((address_space(3))) void*)(V8s + buf * AK * DH + wave_u * 1024), 16, 0, 0);
+    if (wave_u < 2)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(khot_g + (int64_t)kt * (AK * 16) + tid * 8),
+                                       (__attribute__((address_space(3))) void*)(&hot_s[buf][wave_u * 512]), 16, 0, 0);
+    if (wave_u == 2) {          // lanes 0..31: the 128 K scale bytes, 32..63: the V scale bytes
+      const uint8_t* sp = (lane < 32 ? ksb : vsb) + (int64_t)kt * AK * 2 + (lane & 31) * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp, (__attribute__((address_space(3))) void*)(&sc_s[buf][0][0]), 4, 0, 0);
+    }
   };
 
   if (wave == 0) {
@@ -571,14 +576,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq8_kernel(mca_attn_bwd2_args
   __syncthreads();
   const int it_end = n_live_s;
   int buf = 0;
-  if (it_end > 0) { gload((int)(live_s[0] & 0x7fffffffu)); swrite(0); }
+  if (it_end > 0) { stage((int)(live_s[0] & 0x7fffffffu), 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   __syncthreads();
 
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
   for (int it = 0; it < it_end; it++) {
     const uint32_t ent = live_s[it];
     const bool need_mask = (ent >> 31) == 0;
-    if (it + 1 < it_end) gload((int)(live_s[it + 1] & 0x7fffffffu));
+    if (it + 1 < it_end) stage((int)(live_s[it + 1] & 0x7fffffffu), buf ^ 1);
     const u16* ks = kbf_s + buf * AK * DH;
     const uint8_t* k8 = K8s + buf * AK * DH;
     const uint8_t* v8 = V8s + buf * AK * DH;
@@ -637,7 +642,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq8_kernel(mca_attn_bwd2_args
           }
           dq[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, *reinterpret_cast<const bf16x8*>(&dsw[kb][sp]), dq[n], 0, 0, 0);
         }
-    if (it + 1 < it_end) swrite(buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wavefront's pieces of the next tile have landed
     __syncthreads();
     buf ^= 1;
   }
@@ -760,66 +765,63 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv8_kernel(mca_attn_bwd2_args a
   const float* lse_g = a.lse + bh * a.nq;
   const float* delta_g = a.delta + bh * a.nq;
 
-  const int srow = tid >> 3, sc = tid & 7;          // bf16 tiles: 512 pieces of 16 bytes, two per thread
-  const int s8row = tid >> 2, s8col = tid & 3;      // fp8 tiles: 256 pieces, one per thread
-  bf16x8 stage_q[2], stage_o[2];
-  uint4 stage_q8, stage_o8, stage_b = make_uint4(0, 0, 0, 0);
-  uint32_t stage_s = 0;
+  // staging: the bf16 Q and dO tiles (512 pieces of 16 bytes each), Q8 and dO8 (256 each), the 256 scale bytes and the qblk tile
+  // (128 pieces) go global -> LDS by LDS-DMA, the tile swizzles on the SOURCE chunk (piece p lands at byte 16 p); the two
+  // per-row constants pass through a register (negated, +inf / 0 for rows past nq)
+  const int srow = tid >> 3;                                                                           // (+32 for the second piece: same swizzle)
+  const int ssw = ((tid & 7) ^ (((srow >> 1) & 7) ^ (((srow >> 1) & 1) << 2))) << 3;                   // rt8_off
+  const int s8row = tid >> 2, s8sw = 16 * ((tid & 3) ^ ((s8row >> 2) & 3));                            // t8_off
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   float stage_c = 0.f;
   bool stage_oob = false;
   const int cwhich = tid >> 6 < 2 ? tid >> 6 : 2, crow = tid & 63;
   const float* cbase = cwhich == 0 ? lse_g : delta_g;
-  auto gload = [&](int qt) {
+  auto stage = [&](int qt, int buf) {
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       int q = qt * BQ8 + srow + u * 32; if (q > a.nq - 1) q = a.nq - 1;
-      stage_q[u] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)q * a.q_ld + sc * 8);
-      stage_o[u] = *reinterpret_cast<const bf16x8*>(obase + (int64_t)q * a.o_ld + sc * 8);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qbase + (int64_t)q * a.q_ld + ssw),
+                                       (__attribute__((address_space(3))) void*)(Qs + buf * BQ8 * DH + (u * 4 + wave_u) * 512), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(obase + (int64_t)q * a.o_ld + ssw),
+                                       (__attribute__((address_space(3))) void*)(Os + buf * BQ8 * DH + (u * 4 + wave_u) * 512), 16, 0, 0);
     }
     const int64_t r8 = row0 + (int64_t)qt * BQ8 + s8row;          // rows past nq are zero rows of the quantised arrays
-    stage_q8 = *reinterpret_cast<const uint4*>(f.q8 + r8 * DH + 16 * s8col);
-    stage_o8 = *reinterpret_cast<const uint4*>(f.do8 + r8 * DH + 16 * s8col);
-    if (tid < 64) {          // scale bytes of the 64 rows: 128 bytes of Q (threads 0..31), 128 of dO (32..63)
-      const uint8_t* sp = (tid < 32 ? f.qs : f.dos) + (row0 + (int64_t)qt * BQ8) * 2 + (tid & 31) * 4;
-      stage_s = *reinterpret_cast<const uint32_t*>(sp);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(f.q8 + r8 * DH + s8sw),
+                                     (__attribute__((address_space(3))) void*)(Q8s + buf * BQ8 * DH + wave_u * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(f.do8 + r8 * DH + s8sw),
+                                     (__attribute__((address_space(3))) void*)(O8s + buf * BQ8 * DH + wave_u * 1024), 16, 0, 0);
+    if (wave_u == 3) {          // scale bytes of the 64 rows: 128 bytes of Q (lanes 0..31), 128 of dO (32..63)
+      const uint8_t* sp = (lane < 32 ? f.qs : f.dos) + (row0 + (int64_t)qt * BQ8) * 2 + (lane & 31) * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                       (__attribute__((address_space(3))) void*)(sc8 + buf * (2 * BQ8 * 2)), 4, 0, 0);
     }
-    int qq = qt * BQ8 + crow;
-    stage_oob = qq >= a.nq;
-    if (qq > a.nq - 1) qq = a.nq - 1;
-    if (cwhich < 2) stage_c = cbase[qq];
-    if (tid < 128) {
+    if (wave_u < 2) {
       int qb = qt * BQ8 + (tid >> 1); if (qb > a.nq - 1) qb = a.nq - 1;
-      stage_b = *reinterpret_cast<const uint4*>(a.qblk + (int64_t)qb * 16 + (tid & 1) * 8);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.qblk + (int64_t)qb * 16 + (tid & 1) * 8),
+                                       (__attribute__((address_space(3))) void*)(qblk_s + buf * (BQ8 * 16) + wave_u * 512), 16, 0, 0);
+      int qq = qt * BQ8 + crow;
+      stage_oob = qq >= a.nq;
+      if (qq > a.nq - 1) qq = a.nq - 1;
+      stage_c = cbase[qq];
     }
   };
-  auto swrite = [&](int buf) {
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      *reinterpret_cast<bf16x8*>(Qs + buf * BQ8 * DH + rt8_off(srow + u * 32, sc)) = stage_q[u];
-      *reinterpret_cast<bf16x8*>(Os + buf * BQ8 * DH + rt8_off(srow + u * 32, sc)) = stage_o[u];
-    }
-    *reinterpret_cast<uint4*>(Q8s + buf * BQ8 * DH + t8_off(s8row, s8col)) = stage_q8;
-    *reinterpret_cast<uint4*>(O8s + buf * BQ8 * DH + t8_off(s8row, s8col)) = stage_o8;
-    if (tid < 64) *reinterpret_cast<uint32_t*>(sc8 + buf * (2 * BQ8 * 2) + (tid >> 5) * (BQ8 * 2) + (tid & 31) * 4) = stage_s;
-    if (tid < 128) {          // rows past nq contribute nothing: lse = +inf (P = 0), delta = 0
-      float v = stage_oob ? (cwhich == 0 ? INFINITY : 0.f) : stage_c;
-      rowc[buf * 192 + tid] = -v;
-    }
-    if (tid < 128) *reinterpret_cast<uint4*>(qblk_s + buf * (BQ8 * 16) + (tid >> 1) * 16 + (tid & 1) * 8) = stage_b;
+  auto swrite = [&](int buf) {          // rows past nq contribute nothing: lse = +inf (P = 0), delta = 0
+    if (tid < 128) rowc[buf * 192 + tid] = -(stage_oob ? (cwhich == 0 ? INFINITY : 0.f) : stage_c);
   };
 
-  if (n_it > 0) gload(first_qt);
+  if (n_it > 0) stage(first_qt, 0);
   for (int i = tid; i < n_it; i += NT) qlist[i] = a.k_qt[it_begin + i];
   if (tid < DH) dvm_s[tid] = a.dvmean[(int64_t)b * a.heads * DH + h * DH + tid];
   int buf = 0;
   if (n_it > 0) swrite(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
   for (int it = 0; it < n_it; it++) {
     const uint32_t ent = __builtin_amdgcn_readfirstlane(qlist[it]);
     const bool full = (ent >> 31) != 0;
-    if (it + 1 < n_it) gload((int)(__builtin_amdgcn_readfirstlane(qlist[it + 1]) & 0x7fffffffu));
+    if (it + 1 < n_it) stage((int)(__builtin_amdgcn_readfirstlane(qlist[it + 1]) & 0x7fffffffu), buf ^ 1);
     if (!wave_dead)
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
@@ -878,6 +880,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv8_kernel(mca_attn_bwd2_args a
         }
     }
     if (it + 1 < n_it) swrite(buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wavefront's pieces of the next tile have landed
     __syncthreads();
     buf ^= 1;
   }
