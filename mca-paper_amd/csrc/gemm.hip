@@ -1453,12 +1453,13 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(const u16* __restrict_
 // Weight gradient, 256(n) x 256(k) output tile: the k-loop of these GEMMs is bound by the L2 -> LDS path per CU
 // (DESIGN.md section 5), so the lever is bytes per flop: 32 KiB of operands per 32-row step feed 16 MFMAs per
 // wavefront, against 24 KiB for the same 16 MFMAs... per 2x the flops: 256x256 moves 2/3 of the bytes per flop of
-// 256x128.  8 wavefronts as 4 (n) x 2 (k), each 64 x 128 = 2 x 4 accumulators (128 VGPRs); FOUR LDS stages of
-// 32 rows (128 KiB), DMA three steps ahead; fragments by ds_read_b64_tr_b16 (12 per k16-step for 8 MFMAs).
+// 256x128.  8 wavefronts as 4 (n) x 2 (k), each 64 x 128 = 2 x 4 accumulators (128 VGPRs); FIVE LDS stages of
+// 32 rows (160 KiB), DMA four steps ahead; fragments by ds_read_b64_tr_b16 (12 per k16-step for 8 MFMAs).
 // ---------------------------------------------------------------------------------------------------------
 #define BR2 32
 #define TN2_STAGE (BR2 * 512)          // elements per stage: A image [32][256] then B image [32][256]
-#define TN2_LDS_BYTES (4 * TN2_STAGE * 2)
+#define TN2_NSTAGE 5
+#define TN2_LDS_BYTES (TN2_NSTAGE * TN2_STAGE * 2)
 __device__ __forceinline__ void tn_256x256_tile(const u16* __restrict__ A, int64_t lda, const u16* __restrict__ B, int64_t ldb,
                                                 float* __restrict__ C, int64_t ldc, int N, int K, int tn, int tk, int r_begin,
                                                 int r_end, u16* ldst) {
@@ -1470,30 +1471,39 @@ __device__ __forceinline__ void tn_256x256_tile(const u16* __restrict__ A, int64
   const u16* zero = reinterpret_cast<const u16*>(g_zero16);
 
   // DMA: an operand image is 1024 chunks of 16 B = 16 wave-instructions, two per wave; position p -> row p >> 5, chunk
-  // position p & 31 holds logical chunk (p & 31) ^ ((row & 3) << 2)
+  // position p & 31 holds logical chunk (p & 31) ^ ((row & 3) << 2).  Every lane keeps a running source pointer per load (rows
+  // advance by 32 per stage), so a stage whose 32 rows all exist
+  // costs four loads and four 64-bit adds; only a split's last, partial stage tests rows.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   int srow[2];
-  const u16* pa[2];
-  const u16* pb[2];
-  bool ca_ok[2], cb_ok[2];
+  const u16* cur_a[2];
+  const u16* cur_b[2];
+  const int64_t inc_a = (int64_t)BR2 * lda, inc_b = (int64_t)BR2 * ldb;
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     const int p = (i * 8 + wave) * 64 + lane, r = p >> 5, c = (p & 31) ^ ((r & 3) << 2);
     srow[i] = r;
-    ca_ok[i] = n0 + c * 8 < N; pa[i] = A + n0 + c * 8;
-    cb_ok[i] = k0 + c * 8 < K; pb[i] = B + k0 + c * 8;
+    // a column block past the matrix re-reads the last one inside it: those products land in rows / columns of C that are not stored
+    int ca = n0 + c * 8, cb = k0 + c * 8;
+    if (ca >= N) ca = (N - 1) & ~7;
+    if (cb >= K) cb = (K - 1) & ~7;
+    cur_a[i] = A + ca + (int64_t)(r_begin + r) * lda;
+    cur_b[i] = B + cb + (int64_t)(r_begin + r) * ldb;
   }
-  auto stage = [&](int r0, int st) {
+  int r_next = r_begin;          // first row of the next stage to be issued (stages are issued in row order)
+  auto stage = [&](int st) {
     u16* base = ldst + st * TN2_STAGE;
+    const bool whole = r_next + BR2 <= r_end;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      const int r = r0 + srow[i];
-      const u16* sa = (r < r_end && ca_ok[i]) ? pa[i] + (int64_t)r * lda : zero;
-      const u16* sb = (r < r_end && cb_ok[i]) ? pb[i] + (int64_t)r * ldb : zero;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
-                                       (__attribute__((address_space(3))) void*)(base + (i * 8 + wave) * 512), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
-                                       (__attribute__((address_space(3))) void*)(base + BR2 * 256 + (i * 8 + wave) * 512), 16, 0, 0);
+      const bool in = whole || r_next + srow[i] < r_end;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in ? cur_a[i] : zero),
+                                       (__attribute__((address_space(3))) void*)(base + (i * 8 + wave_u) * 512), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in ? cur_b[i] : zero),
+                                       (__attribute__((address_space(3))) void*)(base + BR2 * 256 + (i * 8 + wave_u) * 512), 16, 0, 0);
+      cur_a[i] += inc_a; cur_b[i] += inc_b;
     }
+    r_next += BR2;
   };
   f32x16 acc[2][4];
 #pragma unroll
@@ -1522,52 +1532,68 @@ __device__ __forceinline__ void tn_256x256_tile(const u16* __restrict__ A, int64
   }
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+  // FIVE stages of 32 rows (all 160 KiB of LDS), DMA four steps ahead.  The step is software-pipelined: the fragments of one
+  // k16-step are read in the gaps between the MFMAs of the k16-step before it (two reads per gap, none in a burst), and the step's
+  // one barrier sits between its two MFMA groups, followed by one MFMA before the next stage's DMA is issued.
   const int nsteps = (r_end - r_begin + BR2 - 1) / BR2;
-  stage(r_begin, 0);
-  if (nsteps > 1) stage(r_begin + BR2, 1);
-  if (nsteps > 2) stage(r_begin + 2 * BR2, 2);
-  int st = 0;
-  for (int sp = 0; sp < nsteps; sp++) {
-    // stage sp has landed once only the (4 loads each of the) younger stages are outstanding
-    if (sp + 2 < nsteps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (sp + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (sp + 3 < nsteps) stage(r_begin + (sp + 3) * BR2, (st + 3) & 3);
+  stage(0);
+  if (nsteps > 1) stage(1);
+  if (nsteps > 2) stage(2);
+  if (nsteps > 3) stage(3);
+  u32x2 fa[2][2][2], fb[2][4][2];          // [k16-step][block][t]
+#define TN2_SB __builtin_amdgcn_sched_barrier(0);
+#define TN2_RA(KS, I, SO) TR_READ(fa[KS][I][0], abase[I] + (SO), (KS) * 8192); TR_READ(fa[KS][I][1], abase[I] + (SO), (KS) * 8192 + 2048); TN2_SB
+#define TN2_RB(KS, J, SO) TR_READ(fb[KS][J][0], bbase[J] + (SO), (KS) * 8192); TR_READ(fb[KS][J][1], bbase[J] + (SO), (KS) * 8192 + 2048); TN2_SB
+#define TN2_AF(KS, I) __builtin_bit_cast(bf16x8, make_uint4(fa[KS][I][0][0], fa[KS][I][0][1], fa[KS][I][1][0], fa[KS][I][1][1]))
+#define TN2_BF(KS, J) __builtin_bit_cast(bf16x8, make_uint4(fb[KS][J][0][0], fb[KS][J][0][1], fb[KS][J][1][0], fb[KS][J][1][1]))
+#define TN2_MM(KS, I, J) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TN2_AF(KS, I), TN2_BF(KS, J), acc[I][J], 0, 0, 0); TN2_SB
+  // the MFMAs of k16-step KS with the reads of k16-step KN (at stage offset SO) in their gaps; MID runs after the first MFMA
+#define TN2_GROUP_READING(KS, KN, SO, MID)                                                              \
+    TN2_MM(KS, 0, 0) MID TN2_RA(KN, 0, SO) TN2_MM(KS, 0, 1) TN2_RB(KN, 0, SO) TN2_MM(KS, 0, 2) TN2_RB(KN, 1, SO) \
+    TN2_MM(KS, 0, 3) TN2_RB(KN, 2, SO) TN2_MM(KS, 1, 0) TN2_RB(KN, 3, SO) TN2_MM(KS, 1, 1) TN2_RA(KN, 1, SO)    \
+    TN2_MM(KS, 1, 2) TN2_MM(KS, 1, 3)
+#define TN2_GROUP(KS)                                                                                   \
+    TN2_MM(KS, 0, 0) TN2_MM(KS, 0, 1) TN2_MM(KS, 0, 2) TN2_MM(KS, 0, 3) TN2_MM(KS, 1, 0) TN2_MM(KS, 1, 1) TN2_MM(KS, 1, 2) TN2_MM(KS, 1, 3)
+  if (nsteps > 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (nsteps > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  TN2_SB
+  TN2_RA(0, 0, 0u) TN2_RB(0, 0, 0u) TN2_RB(0, 1, 0u) TN2_RB(0, 2, 0u) TN2_RB(0, 3, 0u) TN2_RA(0, 1, 0u)
+  int st = 0, prev = TN2_NSTAGE - 1;
+  for (int sp = 0; sp + 1 < nsteps; sp++) {
     const unsigned so = (unsigned)st * (unsigned)(TN2_STAGE * 2);
-    u32x2 fa[2][2][2], fb[2][4][2];          // [k16-step][block][t]
-#define TN2_ISSUE(KS)                                                                                   \
-    TR_READ(fa[KS][0][0], abase[0] + so, (KS) * 8192); TR_READ(fa[KS][0][1], abase[0] + so, (KS) * 8192 + 2048); \
-    TR_READ(fa[KS][1][0], abase[1] + so, (KS) * 8192); TR_READ(fa[KS][1][1], abase[1] + so, (KS) * 8192 + 2048); \
-    TR_READ(fb[KS][0][0], bbase[0] + so, (KS) * 8192); TR_READ(fb[KS][0][1], bbase[0] + so, (KS) * 8192 + 2048); \
-    TR_READ(fb[KS][1][0], bbase[1] + so, (KS) * 8192); TR_READ(fb[KS][1][1], bbase[1] + so, (KS) * 8192 + 2048); \
-    TR_READ(fb[KS][2][0], bbase[2] + so, (KS) * 8192); TR_READ(fb[KS][2][1], bbase[2] + so, (KS) * 8192 + 2048); \
-    TR_READ(fb[KS][3][0], bbase[3] + so, (KS) * 8192); TR_READ(fb[KS][3][1], bbase[3] + so, (KS) * 8192 + 2048);
-#define TN2_MFMA(KS)                                                                                    \
-    {                                                                                                   \
-      bf16x8 af[2], bfr[4];                                                                             \
-      _Pragma("unroll") for (int i = 0; i < 2; i++) {                                                   \
-        const uint4 ua = make_uint4(fa[KS][i][0][0], fa[KS][i][0][1], fa[KS][i][1][0], fa[KS][i][1][1]); \
-        af[i] = *reinterpret_cast<const bf16x8*>(&ua);                                                  \
-      }                                                                                                 \
-      _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                   \
-        const uint4 ub = make_uint4(fb[KS][j][0][0], fb[KS][j][0][1], fb[KS][j][1][0], fb[KS][j][1][1]); \
-        bfr[j] = *reinterpret_cast<const bf16x8*>(&ub);                                                 \
-      }                                                                                                 \
-      _Pragma("unroll") for (int i = 0; i < 2; i++)                                                     \
-        _Pragma("unroll") for (int j = 0; j < 4; j++)                                                   \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);       \
-    }
-    TN2_ISSUE(0)
-    TN2_ISSUE(1)
-    asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-    TN2_MFMA(0)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-    TN2_MFMA(1)
-    st = (st + 1) & 3;
+    const int nxt = st == TN2_NSTAGE - 1 ? 0 : st + 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); TN2_SB
+    TN2_GROUP_READING(0, 1, so, )
+    // stage sp + 1 has landed once only the (4 loads each of the) two younger stages are outstanding; past the barrier every
+    // wavefront has finished with stage sp - 1, whose buffer takes stage sp + 4
+    if (sp + 3 < nsteps) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if (sp + 2 < nsteps) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    TN2_SB
+    const unsigned son = (unsigned)nxt * (unsigned)(TN2_STAGE * 2);
+    const bool fetch = sp + 4 < nsteps;
+    TN2_GROUP_READING(1, 0, son, if (fetch) stage(prev); TN2_SB)
+    prev = st; st = nxt;
   }
-#undef TN2_ISSUE
-#undef TN2_MFMA
+  {          // the last stage: nothing left to wait for or to fetch
+    const unsigned so = (unsigned)st * (unsigned)(TN2_STAGE * 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); TN2_SB
+    TN2_GROUP_READING(0, 1, so, )
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); TN2_SB
+    TN2_GROUP(1)
+  }
+#undef TN2_SB
+#undef TN2_RA
+#undef TN2_RB
+#undef TN2_AF
+#undef TN2_BF
+#undef TN2_MM
+#undef TN2_GROUP_READING
+#undef TN2_GROUP
 #undef TR_READ
   // C[n][k]: row n in registers, column k on the lane -> 128-byte contiguous atomic segments per row
   const int l31 = lane & 31;
@@ -1620,8 +1646,12 @@ __global__ __launch_bounds__(512) void gemm_tn_256x256_group_kernel(tn_group g, 
   const int tile_id = tile_all - g.first_tile[p];
   const int r_begin = split_id * g.rows_per_split;
   int r_end = r_begin + g.rows_per_split; if (r_end > g.R) r_end = g.R;
+  // clock probe (knob 9 bit 8): shader cycles and 100 MHz ticks of every workgroup's lifetime (tools/ablate_tn_group.py)
+  const bool probe = (dbg & 8) && threadIdx.x == 0 && lin0 < 512;
+  const uint64_t c0 = probe ? __builtin_amdgcn_s_memtime() : 0, t0 = probe ? __builtin_amdgcn_s_memrealtime() : 0;
   tn_256x256_tile(g.A[p], g.lda[p], g.B[p], g.ldb[p], g.C[p], g.ldc[p], g.N[p], g.K[p], tile_id / g.tiles_k[p], tile_id % g.tiles_k[p],
                   r_begin, r_end, ldst);
+  if (probe) { mca_trace_gemm[2 * lin0] = __builtin_amdgcn_s_memtime() - c0; mca_trace_gemm[2 * lin0 + 1] = __builtin_amdgcn_s_memrealtime() - t0; }
 }
 
 extern "C" int mca_gemm_tn_acc(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,
