@@ -1,7 +1,7 @@
 set -o pipefail
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/r3h; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$ROOT
-for v in "LDS reads + MFMA alone" "whole kernel"; do
+for v in "whole kernel"; do
   tag=$(echo "$v" | tr -c 'a-zA-Z\n' '_')
   MCA_ABLATE_ONLY="$v" timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_$tag -o t -- python3 $ROOT/tools/ablate_tn_group.py 32 > $OUT/pmc_$tag.log 2>&1 || { echo FAILED $v; tail -5 $OUT/pmc_$tag.log; exit 1; }
   echo "== $v"; python3 $ROOT/tools/pmc_sum.py $OUT/pmc_$tag tn_256x256_group
