@@ -350,8 +350,12 @@ extern "C" int mca_layernorm_bwd(const float* dy, int64_t ldy, int64_t y_bstride
                    ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && (!dx || (uintptr_t)dx % 16 == 0);
   if (vec && !rowmask && period <= 0 && !dbeta && dgamma && (cols == 256 || cols == 512 || cols == 1024) &&
       (uintptr_t)gamma % 16 == 0 && mca_knobs[12] != 1) {          // knob 12 = 1: general kernel (A/B)
+    // one workgroup per CU at most: every workgroup ends with one atomic per column on dgamma, and 1024 of them on the same
+    // 512 addresses cost more than the extra loads in flight bring (b = 8: 40.8 -> 28.5 us, b = 32: 108.7 -> 104.0 us;
+    // knob 14 = another cap, tools/bench_ln.py)
     int64_t nb = (rows + 7) / 8;
-    if (nb > 1024) nb = 1024;
+    const int64_t cap = mca_knobs[14] > 0 ? mca_knobs[14] : 256;
+    if (nb > cap) nb = cap;
     if (cols == 256) hipLaunchKernelGGL(ln_bwd_trunk_kernel<1>, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), dy, ldy, x, ldx, gamma, mean, rstd, dx, lddx, dx_bf16, ld_bf16, dgamma, rows, cols);
     else if (cols == 512) hipLaunchKernelGGL(ln_bwd_trunk_kernel<2>, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), dy, ldy, x, ldx, gamma, mean, rstd, dx, lddx, dx_bf16, ld_bf16, dgamma, rows, cols);
     else hipLaunchKernelGGL(ln_bwd_trunk_kernel<4>, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), dy, ldy, x, ldx, gamma, mean, rstd, dx, lddx, dx_bf16, ld_bf16, dgamma, rows, cols);
