@@ -1,6 +1,6 @@
 #!/bin/bash
 # The bench lines recorded per round under profiles/rNN_bench_lines.json (run on the GPU box from the repo root:
-# bash tools/bench_lines.sh <outdir>; then python tools/bench_lines.sh is NOT needed: the script writes <outdir>/lines.json itself).
+# bash tools/bench_lines.sh <outdir>); writes one JSON per command and <outdir>/lines.json.
 set -o pipefail
 OUT="${1:-gpurun_out/lines}"; mkdir -p "$OUT"
 run() { local tag="$1"; shift; echo "== $tag: $*"; timeout -k 10 500 "$@" > "$OUT/$tag.json" 2> "$OUT/$tag.err" || { echo "FAILED $tag"; tail -3 "$OUT/$tag.err"; return 1; }; cut -c1-170 "$OUT/$tag.json" | tail -1; }

@@ -1,5 +1,8 @@
+#!/bin/bash
+# SQ / LDS counters of the grouped weight-gradient GEMM at the step's shapes (two rocprofv3 --pmc passes of
+# tools/ablate_tn_group.py, summed by tools/pmc_sum.py).  Run on the GPU box from the repo root: bash tools/pmc_tn_group.sh [outdir]
 set -o pipefail
-ROOT=$(pwd); OUT=$ROOT/gpurun_out/r3h; mkdir -p $OUT
+ROOT=$(pwd); OUT=$(realpath -m "${1:-gpurun_out/pmc_tn}"); mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$ROOT
 for v in "whole kernel"; do
   tag=$(echo "$v" | tr -c 'a-zA-Z\n' '_')
