@@ -19,3 +19,13 @@ for bq, bk in [(128, 64), (64, 256), (64, 64), (64, 32), (32, 32), (32, 256), (1
 # segment boundaries
 b = np.concatenate([[0], np.cumsum(st.token_dims), [N]])
 print("segment starts:", b.tolist())
+# tiles that never cross a segment boundary (a tile = a segment and an offset inside it; the last tile of a segment is partial)
+segs = [(int(b[i]), int(b[i + 1])) for i in range(len(b) - 1) if b[i + 1] > b[i]]
+for bq, bk in [(128, 64), (64, 64), (64, 128), (32, 64)]:
+    proc = 0
+    for (q0, q1) in segs:
+        for (k0, k1) in segs:
+            if m[q0:q1, k0:k1].any():
+                proc += (-(-(q1 - q0) // bq) * bq) * (-(-(k1 - k0) // bk) * bk)
+    nqt = sum(-(-(q1 - q0) // bq) for q0, q1 in segs); nkt = sum(-(-(k1 - k0) // bk) for k0, k1 in segs)
+    print(f"segment-aligned tiles {bq:3d} q x {bk:3d} k: {nqt} q tiles, {nkt} k tiles, processed/allowed = {proc / m.sum():.3f}")
