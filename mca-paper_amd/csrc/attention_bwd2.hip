@@ -649,11 +649,11 @@ extern "C" int mca_attn_bwd_dkv(const mca_attn_bwd2_args* a, mca_stream_t stream
 // =====================================================================================================
 #define PREP_ROWS 32
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restrict__ o, const u16* __restrict__ d_o,
-                                                             int64_t bstride, int64_t ld, const float* __restrict__ lse,
-                                                             float* __restrict__ delta, int heads, int nq) {
-  // lse / delta are (b, head, q): a row touches them at a stride of nq floats per head.  They cross LDS so that the global
-  // accesses are 128-byte runs along q (one row at a time they were 4-byte accesses in 8 different lines per row).
-  __shared__ float lse_s[8][PREP_ROWS], del_s[8][PREP_ROWS];
+                                                             int64_t bstride, int64_t ld, float* __restrict__ delta, int heads,
+                                                             int nq) {
+  // delta is (b, head, q): a row touches it at a stride of nq floats per head.  It crosses LDS so that the global accesses are
+  // 128-byte runs along q (one row at a time they were 4-byte accesses in 8 different lines per row).
+  __shared__ float del_s[8][PREP_ROWS];
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cols = heads * DH;
   const int q_begin = blockIdx.x * PREP_ROWS;
@@ -662,8 +662,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restric
     const int h0 = c0 / DH;
     const int c = c0 + lane * 8;
     const int hl = lane >> 3;          // head of this lane inside the 512-column slab
-    // all PREP_ROWS / 4 rows of this wavefront are requested before any is used (a row at a time the loop is latency-bound),
-    // and before the lse values the block waits for at its first barrier
+    // all PREP_ROWS / 4 rows of this wavefront are requested before any is used (a row at a time the loop is latency-bound)
     bf16x8 ovs[PREP_ROWS / 4], dvs[PREP_ROWS / 4];
 #pragma unroll
     for (int k = 0; k < PREP_ROWS / 4; k++) {
@@ -672,11 +671,6 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restric
       ovs[k] = *reinterpret_cast<const bf16x8*>(o + (int64_t)b * bstride + (int64_t)q * ld + cc);
       dvs[k] = *reinterpret_cast<const bf16x8*>(d_o + (int64_t)b * bstride + (int64_t)q * ld + cc);
     }
-    {
-      const int hh = tid / PREP_ROWS, r = tid % PREP_ROWS;          // 8 heads x 32 rows = 256 threads
-      if (h0 + hh < heads && q_begin + r < q_end) lse_s[hh][r] = lse[((int64_t)b * heads + h0 + hh) * nq + q_begin + r];
-    }
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < PREP_ROWS / 4; k++) {
       const int q = q_begin + wave + 4 * k;
@@ -692,7 +686,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restric
     }
     __syncthreads();
     {
-      const int hh = tid / PREP_ROWS, r = tid % PREP_ROWS;
+      const int hh = tid / PREP_ROWS, r = tid % PREP_ROWS;          // 8 heads x 32 rows = 256 threads
       if (h0 + hh < heads && q_begin + r < q_end) delta[((int64_t)b * heads + h0 + hh) * nq + q_begin + r] = del_s[hh][r];
     }
     __syncthreads();
@@ -770,6 +764,6 @@ extern "C" int mca_attn_bwd_prep(const uint16_t* o, const uint16_t* d_o, int64_t
   hipLaunchKernelGGL(attn_dvmean_kernel, dim3(heads, batch), dim3(256), 0, as_stream(stream), d_o, o_bstride, o_ld, lse, dvmean, heads, nq,
                      1.f / (float)nk);
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((nq + PREP_ROWS - 1) / PREP_ROWS, batch), dim3(256), 0, as_stream(stream), o, d_o,
-                     o_bstride, o_ld, lse, delta, heads, nq);
+                     o_bstride, o_ld, delta, heads, nq);
   return launch_status();
 }
