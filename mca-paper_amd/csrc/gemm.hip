@@ -791,13 +791,13 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(
 // ---------------------------------------------------------------------------------------------------------
 // PERSISTENT NT kernel with 256 x 256 tiles (bf16 output, N % 256 == 0): the k-loop of these GEMMs is bound by the
 // L2 -> LDS path per CU, and a 256x256 tile moves 2/3 of the operand bytes per flop of a 256x128 one.  8 wavefronts as
-// 4 (m) x 2 (n), each 64 x 128 = 2 x 4 accumulators (128 VGPRs, operands swapped: lane = row); k-steps of 32 so that FOUR
-// stages of 32 KiB fit (DMA three steps ahead); the next tile's first three stages are issued before the epilogue, which
-// uses the fourth slot + 32 KiB as 8 KiB of scratch per wave (two passes of 32 rows x 256 B).  vmcnt per wave: 4 loads per
-// stage, 16 stores per tile.
+// 4 (m) x 2 (n), each 64 x 128 = 2 x 4 accumulators (128 VGPRs, operands swapped: lane = row); k-steps of 32 in FIVE
+// slots of 32 KiB (DMA three to four steps ahead, software-pipelined fragment reads: see the k-loop); the next tile's first
+// three stages are issued before the epilogue, which uses slots 3 and 4 as 8 KiB of scratch per wave (two passes of 32 rows x
+// 256 B).  vmcnt per wave: 4 loads per stage, 16 stores per tile.
 // ---------------------------------------------------------------------------------------------------------
 #define P2_STAGE (512 * 32)          // elements per stage: A image [256][32] then B image [256][32]
-#define P2_LDS_BYTES (4 * P2_STAGE * 2 + 32768)
+#define P2_LDS_BYTES (5 * P2_STAGE * 2)
 // GEGLU = true: fused FF1 + GEGLU forward (see mca_gemm_nt_geglu_fwd): B = W1 [2*N, K] with N = ip, a column tile = 128 "a"
 // rows + the 128 "gate" rows of the same columns (wave column wn = 0 holds a, wn = 1 gate), C = h [M, 2*N], G = g [M, N].
 template <bool GEGLU>
@@ -865,39 +865,58 @@ __global__ __launch_bounds__(512) void gemm_nt_persist256_kernel(
       for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    for (int kt = 0; kt < nkt; kt++) {
-      // stage kt has landed once only the operations issued after its DMA are outstanding (host: nkt >= 6)
-      if (kt < 3) { if (first) ps_wait_vm<8>(); else ps_wait_vm<8 + NST>(); }
-      else if (kt + 2 < nkt) ps_wait_vm<8>();
-      else if (kt + 1 < nkt) ps_wait_vm<4>();
-      else ps_wait_vm<0>();
+    // FIVE slots of 32 KiB (the fifth is the half of the epilogue scratch that a k-loop does not need): stage kt lives in slot
+    // kt % 5, stages 0..2 were issued by the previous tile's epilogue (or the prologue), stage 3 goes out at the top of the tile and
+    // stage kt + 4 in the middle of step kt.  The step is software-pipelined as in tn_256x256_tile: the six fragment reads of a
+    // k16-step sit in the MFMA gaps of the k16-step before it, and the step's one barrier between its two MFMA groups.
+    // vmcnt, in issue order per wave: S0 S1 S2 [NST epilogue stores of the previous tile] S3 S4 ...: a stage has landed once only
+    // the operations issued after its DMA are outstanding (host: nkt >= 6).
+    u32x4v fa[2][2], fb[2][4];          // [k16-step][block]
+#define P2_SB __builtin_amdgcn_sched_barrier(0);
+#define P2_RA(KS, I, SO) NT_DSREAD(fa[KS][I], (fa_addr[I] + (SO)) ^ (32u * (KS))); P2_SB
+#define P2_RB(KS, J, SO) NT_DSREAD(fb[KS][J], (fb_addr[J] + (SO)) ^ (32u * (KS))); P2_SB
+#define P2_MM(KS, I, J) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&fb[KS][J]), \
+                                                                            *reinterpret_cast<const bf16x8*>(&fa[KS][I]), acc[I][J], 0, 0, 0); P2_SB
+#define P2_GROUP_READING(KS, KN, SO, MID)                                                                                    \
+      P2_MM(KS, 0, 0) MID P2_RA(KN, 0, SO) P2_MM(KS, 0, 1) P2_RB(KN, 0, SO) P2_MM(KS, 0, 2) P2_RB(KN, 1, SO) P2_MM(KS, 0, 3)   \
+      P2_RB(KN, 2, SO) P2_MM(KS, 1, 0) P2_RB(KN, 3, SO) P2_MM(KS, 1, 1) P2_RA(KN, 1, SO) P2_MM(KS, 1, 2) P2_MM(KS, 1, 3)
+    if (first) ps_wait_vm<8>(); else ps_wait_vm<8 + NST>();          // S0 has landed
+    __builtin_amdgcn_s_barrier();                                     // ... for everyone, and every wave has left the previous epilogue
+    stage(96, 3);
+    P2_SB
+    P2_RA(0, 0, 0u) P2_RB(0, 0, 0u) P2_RB(0, 1, 0u) P2_RB(0, 2, 0u) P2_RB(0, 3, 0u) P2_RA(0, 1, 0u)
+    int slot = 0, prev = 4;
+    for (int kt = 0; kt + 1 < nkt; kt++) {
+      const unsigned so = (unsigned)slot * (unsigned)(P2_STAGE * 2);
+      const int nxt = slot == 4 ? 0 : slot + 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); P2_SB
+      P2_GROUP_READING(0, 1, so, )
+      // stage kt + 1 has landed once only what was issued after it is outstanding; past the barrier every wave has finished with
+      // stage kt - 1, whose slot takes stage kt + 4
+      if (kt < 2) { if (first) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ps_wait_vm<8 + NST>(); } }
+      else if (kt + 3 < nkt) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (kt + 3 < nkt) stage((kt + 3) * 32, (kt + 3) & 3);
-      const unsigned so = (unsigned)(kt & 3) * (unsigned)(P2_STAGE * 2);
-      u32x4v fa[2][2], fb[2][4];          // [k16-step][block]
-#pragma unroll
-      for (int ks = 0; ks < 2; ks++) {
-#pragma unroll
-        for (int i = 0; i < 2; i++) NT_DSREAD(fa[ks][i], (fa_addr[i] + so) ^ (32u * ks));
-#pragma unroll
-        for (int j = 0; j < 4; j++) NT_DSREAD(fb[ks][j], (fb_addr[j] + so) ^ (32u * ks));
-      }
-      asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&fb[0][j]),
-                                                              *reinterpret_cast<const bf16x8*>(&fa[0][i]), acc[i][j], 0, 0, 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&fb[1][j]),
-                                                              *reinterpret_cast<const bf16x8*>(&fa[1][i]), acc[i][j], 0, 0, 0);
+      P2_SB
+      const unsigned son = (unsigned)nxt * (unsigned)(P2_STAGE * 2);
+      const bool fetch = kt + 4 < nkt;
+      P2_GROUP_READING(1, 0, son, if (fetch) stage((kt + 4) * 32, prev); P2_SB)
+      prev = slot; slot = nxt;
     }
-    __builtin_amdgcn_s_barrier();                  // every wave has read its last fragments: all four slots are free
+    {          // the last stage: nothing left to wait for or to fetch
+      const unsigned so = (unsigned)slot * (unsigned)(P2_STAGE * 2);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); P2_SB
+      P2_GROUP_READING(0, 1, so, )
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); P2_SB
+      P2_MM(1, 0, 0) P2_MM(1, 0, 1) P2_MM(1, 0, 2) P2_MM(1, 0, 3) P2_MM(1, 1, 0) P2_MM(1, 1, 1) P2_MM(1, 1, 2) P2_MM(1, 1, 3)
+    }
+#undef P2_SB
+#undef P2_RA
+#undef P2_RB
+#undef P2_MM
+#undef P2_GROUP_READING
+    __builtin_amdgcn_s_barrier();                  // every wave has read its last fragments: all five slots are free
     // ---------------- epilogue: acc[i][j][4q + e] = C[mw + 32i + l31][nw + 32j + 8q + 4lh + e] ----------------
     const int mw = m0 + wm * 64, nw = GEGLU ? (wn == 0 ? tn * 128 : N + tn * 128) : n0 + wn * 128;
     const bool edge = m0 + 256 > M;
