@@ -9,7 +9,18 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* knob[key] = value for key in [0, 16); returns 0.  All knobs are 0 in production. */
+/* knob[key] = value for key in [0, 16); returns 0.  All knobs are 0 in production.  What the library reads them for:
+ *    0  persistent NT GEMMs: 8 = s_memtime stamps of workgroup 0 (tools/trace_persist.py), 32 * P = P row panels per tile group
+ *    1  = 1: the 128 x 128 NT kernel for every shape;   2  bit 1: weight-gradient 128 x 128 kernel without its atomics (timing)
+ *    3  > 0: number of row splits of the weight-gradient kernels;   4  = 1: no residual prefetch in the fp32 + residual NT kernel
+ *    5  weight-gradient kernel: 1 = 128 x 128, 2 = 256 x 128 where 256 x 256 would be chosen
+ *    7  1 = one-tile-per-workgroup NT kernels only, 3 = persistent kernel for fp32 + residual as well;   10  = 1: 256 x 128 persistent
+ *       kernel where the 256 x 256 one would be chosen;   11  = 1: one launch per member of a weight-gradient group
+ *    8 / 9  attention kernels (9 also the weight-gradient kernels), bit mask: 8 = s_memtime stamps / clock probe of the launch
+ *       (trace build; gemm_tn_256x256_group_kernel in every build), 16 = launch order without the XCD remap, 32 = fp8 forward with
+ *       register staging instead of LDS-DMA
+ *   12  = 1: general LayerNorm kernels where the trunk forms would be chosen;   13  = 1: register-staged attention forward
+ *   14  > 0: cap on the workgroups of the trunk LayerNorm backward (default 256) */
 int mca_debug_set(int key, int value);
 /* every knob back to 0 */
 int mca_debug_reset(void);
