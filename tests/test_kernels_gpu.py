@@ -31,7 +31,8 @@ def bf(x):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(300, 200, 128), (1000, 1536, 512), (129, 2816, 512), (16, 512, 512), (4060, 512, 1408),
-                                   (4100, 1536, 320), (2600, 2816, 512)])          # last two: persistent kernel, grouped column tiles
+                                   (4100, 1536, 320), (2600, 2816, 512),          # persistent kernels, grouped column tiles
+                                   (17920, 1024, 192), (17700, 1024, 256)])       # 280 tiles of 256 x 256 on 256 CUs: second tile per workgroup, shortest k-loops
 def test_gemm_nt(H, M, N, K):
     g = torch.Generator(device="cuda").manual_seed(1)
     A = bf(torch.randn(M, K, device="cuda", generator=g))
@@ -212,7 +213,8 @@ def test_geglu(H):
     assert rel(dh.float(), hr.grad) < 4e-3
 
 
-@pytest.mark.parametrize("rows,ip,D", [(500, 384, 128), (4100, 384, 128), (4100, 384, 512), (2304, 448, 320), (2100, 1408, 512)])
+@pytest.mark.parametrize("rows,ip,D", [(500, 384, 128), (4100, 384, 128), (4100, 384, 512), (2304, 448, 320), (2100, 1408, 512),
+                                       (8200, 1408, 192), (8200, 1408, 512)])          # 363 tiles: a second tile per workgroup
 def test_gemm_geglu_fwd_fused(H, rows, ip, D):
     """h = x @ W1^T (both halves, bf16) and g = a * gelu(gate) in one pass; the large-K cases run the persistent kernel
     (tile columns = 64 "a" + 64 "gate" rows of W1), 4100 rows end in a partial 256-row tile."""
