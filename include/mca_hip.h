@@ -207,6 +207,13 @@ typedef struct {
   float scale;                      /* dim_head ** -0.5                                            */
   int flags;                        /* MCA_ATTN_* bits                                             */
   const uint16_t* khot;             /* optional (mca_build_keyhot): one-hot key groups, the mask as a matrix product */
+  /* optional QUERY-BLOCK schedule (needs khot): blocks of up to 256 query rows cut along the fusion structure, one workgroup
+   * each (4 wavefronts x 64 rows).  qb_desc[n_qblocks] = {first row, rows (1..256), first list entry, entries} in LAUNCH order
+   * (descending work), 16-byte aligned; qb_kt = per block its 64-key tiles | (structurally full << 31).  The blocks must cover
+   * every query row exactly once.  With it mca_attn_fwd runs the round-4 kernel (attention_fwd64.hip); without it (NULL) the
+   * 128-row-tile kernels, which also serve the pooling attention.  Same results up to rounding (the reference maximum of the
+   * online softmax moves lazily); lse, o and the uniform-row rule keep their meaning.                                     */
+  const int32_t* qb_desc; const uint32_t* qb_kt; int n_qblocks;
 } mca_attn_fwd_args;
 /* q already carries scale * log2(e) (folded into the bf16 copy of to_q.weight by mca_cast_pad_bf16_multi's per-tensor
  * scale): the kernels then take q.k as the log2-domain logit and never multiply a score.  lse, o, dq, dk, dv keep their

@@ -19,8 +19,11 @@ extern "C" {
  *    8 / 9  attention kernels (9 also the weight-gradient kernels), bit mask: 8 = s_memtime stamps / clock probe of the launch
  *       (trace build; gemm_tn_256x256_group_kernel in every build), 16 = launch order without the XCD remap, 32 = fp8 forward with
  *       register staging instead of LDS-DMA
- *   12  = 1: general LayerNorm kernels where the trunk forms would be chosen;   13  = 1: register-staged attention forward
- *   14  > 0: cap on the workgroups of the trunk LayerNorm backward (default 256) */
+ *   12  = 1: general LayerNorm kernels where the trunk forms would be chosen;   13  = 1: register-staged attention forward,
+ *       = 2: the 128-row-tile LDS-DMA forward where the query-block kernel (attention_fwd64.hip) would be chosen
+ *   14  > 0: cap on the workgroups of the trunk LayerNorm backward (default 256)
+ *   15  = t + 1: the query-block forward attention moves its lazy softmax reference when a score exceeds it by more than t
+ *       log2 units (default 12; 1 = at every increase, the textbook online softmax) */
 int mca_debug_set(int key, int value);
 /* every knob back to 0 */
 int mca_debug_reset(void);

@@ -523,6 +523,8 @@ __global__ __launch_bounds__(256, FWD4_WAVES) void attn_fwd4_kernel(mca_attn_fwd
   }
 }
 
+int mca_attn_fwd64_launch(const mca_attn_fwd_args* a, hipStream_t stream, int dbg);          // attention_fwd64.hip
+
 extern "C" int mca_attn_fwd(const mca_attn_fwd_args* a, mca_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->o || !a->lse || !a->qmask || !a->keyinfo || !a->ktile_flags || !a->q_ptr ||
       !a->q_kt || !a->q_order || !a->vmean)
@@ -540,6 +542,10 @@ extern "C" int mca_attn_fwd(const mca_attn_fwd_args* a, mca_stream_t stream) {
   // production: the LDS-DMA kernel (needs the mask product's one-hot operand and 32-bit tile offsets); structures with more
   // than 15 key groups (no khot) take the register-staged kernel with the element-wise mask.  knob 13 = 1 forces the latter (A/B)
   if ((uintptr_t)a->khot % 16) return MCA_E_ALIGN;
+  // round-4 structure, taken when the caller supplies the query-block schedule: blocks of up to 256 rows, one wavefront per
+  // SIMD (knob 13 = 2 forces the 128-row-tile kernel: A/B).  The engine does not supply it by default (MCA_DEBUG=fwd64=1 does).
+  if (a->qb_desc && a->khot && mca_knobs[13] == 0 && (int64_t)a->kv_ld * 64 < (1ll << 30))
+    return mca_attn_fwd64_launch(a, as_stream(stream), mca_knobs[9]);
   if (a->khot && mca_knobs[13] != 1 && (int64_t)a->kv_ld * 64 < (1ll << 30))
     hipLaunchKernelGGL(attn_fwd4_kernel, grid, dim3(256), 0, as_stream(stream), *a, mca_knobs[9]);
   else

@@ -46,8 +46,9 @@ def debug_options() -> dict:
     """The engine's A/B switches, all behind ONE environment variable: ``MCA_DEBUG=key=value,key=value``.  Production runs set
     none of them.  overlap_wgrad=0|1 (weight-gradient GEMMs on a side stream: default by size), group_wgrad=0 (one launch per
     weight gradient instead of one per layer), mask_mfma=0 (element-wise attention mask instead of the mask product),
-    dkv_keys=256 (8-wavefront key blocks in the dK/dV pass).  Kernel-level knobs: include/mca_hip_debug.h (hip.knobs)."""
-    opts = {"overlap_wgrad": None, "group_wgrad": True, "mask_mfma": True, "dkv_keys": 128}
+    dkv_keys=256 (8-wavefront key blocks in the dK/dV pass), fwd64=1 (the round-4 query-block forward attention kernel,
+    attention_fwd64.hip, instead of the 128-row-tile one: correct, measured 24 % slower).  Kernel-level knobs: include/mca_hip_debug.h (hip.knobs)."""
+    opts = {"overlap_wgrad": None, "group_wgrad": True, "mask_mfma": True, "dkv_keys": 128, "fwd64": False}
     for item in filter(None, os.environ.get("MCA_DEBUG", "").split(",")):
         k, _, v = item.partition("=")
         k = k.strip()
@@ -72,6 +73,16 @@ class _Sched:
             lo, hi = int(s.k_ptr[kb]), int(s.k_ptr[kb + 1])
             wg[i] = (kb, lo, hi - lo, int(s.k_qt[lo]) if hi > lo else 0)
         self.k_wg = _dev(wg, device)
+
+
+class _BlockSched:
+    """device copies of a structure.BlockSchedule (query blocks of the round-4 forward attention kernel)"""
+
+    def __init__(self, s, device):
+        self.s = s
+        self.desc = _dev(s.desc.astype(np.int32), device)
+        self.kt = _dev(s.kt.astype(np.uint32).view(np.int32), device)
+        self.n = int(s.desc.shape[0])
 
 
 class FusionEngine:
@@ -99,6 +110,8 @@ class FusionEngine:
         self.attn_dtype = "bf16"
         self.dbg = debug_options()                               # A/B switches: ONE environment variable, MCA_DEBUG
         self.nk_pad = _pad_to(self.N, 256)
+        # the attention mask as a matrix product (mca_build_keyhot): needs every key group id <= 14
+        self.mask_mfma = int(self.st.kgroup.max()) <= 14 and self.dbg["mask_mfma"]
         self._flatten_parameters()
         self._build_static()
         self._alloc_weights()
@@ -124,8 +137,6 @@ class FusionEngine:
         # CUs) the side stream still pays in the eager loop (8.7-8.8 against 9.5-10.2 ms).  MCA_DEBUG=overlap_wgrad=0|1 forces it.
         self.overlap_wgrad = self.dbg["overlap_wgrad"]
         self.group_wgrad = self.dbg["group_wgrad"]          # one weight-gradient launch per layer
-        # the attention mask as a matrix product (mca_build_keyhot): needs every key group id <= 14
-        self.mask_mfma = int(self.st.kgroup.max()) <= 14 and self.dbg["mask_mfma"]
 
     # ------------------------------------------------------------------------------------------------
     # parameters -> one flat buffer (and one for gradients)
@@ -191,6 +202,8 @@ class FusionEngine:
             return torch.from_numpy(np.where(bits == 1, 0.0, -32768.0).astype(np.float32)).to(torch.bfloat16).to(dev).contiguous()
         self.qblk_attn, self.qblk_pool = qblk_of(st.qmask_attn), qblk_of(st.qmask_pool)
         self.sched_attn_f = _Sched(st.attn_schedule(FWD_BQ, FWD_BK), dev)
+        # query blocks cut along the structure: the forward kernel of attention_fwd64.hip (needs the mask product); opt-in
+        self.bsched_attn = _BlockSched(st.attn_block_schedule(256, FWD_BK), dev) if (self.mask_mfma and self.dbg["fwd64"]) else None
         # key-block size of the dkv pass: 128 (4 wavefronts, two independent workgroups per CU) is 3 % faster than 256 (8 wavefronts,
         # one workgroup per CU) at N = 2538 and equal at N = 6088
         dkv_keys = self.dbg["dkv_keys"]
@@ -456,6 +469,8 @@ class FusionEngine:
         a.batch, a.heads, a.nq, a.nk, a.nk_pad = b, self.H, nq, N, self.nk_pad
         a.n_qtiles, a.n_ktiles, a.scale, a.flags = sched.s.n_q, sched.s.n_k, self.scale, self.attn_flags
         a.khot = ws["khot"].data_ptr() if ws.get("khot") is not None else None
+        if self.bsched_attn is not None and sched is self.sched_attn_f and a.khot:
+            a.qb_desc, a.qb_kt, a.n_qblocks = self.bsched_attn.desc.data_ptr(), self.bsched_attn.kt.data_ptr(), self.bsched_attn.n
         # mean(V) is the output of fully masked rows only: samples with every modality present have none and are skipped
         if ws.get("present_cur") is not None:
             call("mca_attn_vmean_if_needed", a.v, a.kv_bstride, a.kv_ld, ws["vmean"].data_ptr(), b, N, self.H, ptr(ws["present_cur"]),

@@ -99,6 +99,69 @@ def build_schedule(qmask: np.ndarray, kgroup: np.ndarray, bq: int, bk: int) -> T
 
 
 @dataclass
+class BlockSchedule:
+    """Query blocks of up to ``rows`` rows cut ALONG the structure (mca_attn_fwd_args.qb_desc / qb_kt): one workgroup each."""
+    rows: int
+    bk: int
+    desc: np.ndarray        # (nB, 4) int32 {first row, rows, first list entry, entries}, launch order (descending work)
+    kt: np.ndarray          # (nnz,) uint32 key-tile index | (structurally full << 31)
+    allowed_pairs: int
+    visited_pairs: int      # rows * bk per list entry (executed work of a full-width workgroup)
+
+
+def build_block_schedule(qmask: np.ndarray, kgroup: np.ndarray, rows: int = 256, bk: int = 64) -> BlockSchedule:
+    """Cut the query rows into blocks that follow the structure: a run of rows with one query mask (a modality, the Zorro
+    fusion block) of at least rows / 2 rows is split evenly into ceil(len / rows) blocks of its own; shorter runs (a small
+    modality, the MCA fusion sub-blocks) are merged with their neighbours up to ``rows`` rows.  A block of a large modality
+    then visits that modality's key tiles only, and almost all of them need no mask."""
+    n, nk = len(qmask), len(kgroup)
+    runs, start = [], 0
+    for i in range(1, n + 1):
+        if i == n or qmask[i] != qmask[start]:
+            runs.append((start, i - start))
+            start = i
+    blocks, pend = [], None
+    for r0, ln in runs:
+        if ln >= rows // 2:
+            if pend:
+                blocks.append(tuple(pend)); pend = None
+            nch = -(-ln // rows)
+            base, rem, at = ln // nch, ln % nch, r0
+            for c in range(nch):
+                sz = base + (1 if c < rem else 0)
+                blocks.append((at, sz)); at += sz
+        else:
+            if pend and pend[1] + ln <= rows and pend[0] + pend[1] == r0:
+                pend[1] += ln
+            else:
+                if pend:
+                    blocks.append(tuple(pend))
+                pend = [r0, ln]
+    if pend:
+        blocks.append(tuple(pend))
+    allowed = ((qmask[:, None].astype(np.uint32) >> kgroup[None, :].astype(np.uint32)) & 1).astype(bool)
+    nK = -(-nk // bk)
+    lists = []
+    for r0, ln in blocks:
+        sub = allowed[r0:r0 + ln]
+        ent = []
+        for ki in range(nK):
+            blk = sub[:, ki * bk:(ki + 1) * bk]
+            if blk.any():
+                full = bool(blk.all()) and (ki + 1) * bk <= nk
+                ent.append(np.uint32(ki) | (np.uint32(1 << 31) if full else np.uint32(0)))
+        lists.append(ent)
+    order = sorted(range(len(blocks)), key=lambda i: -len(lists[i]))
+    desc, kt = [], []
+    for i in order:
+        desc.append((blocks[i][0], blocks[i][1], len(kt), len(lists[i])))
+        kt.extend(lists[i])
+    assert sum(b[1] for b in blocks) == n
+    return BlockSchedule(rows=rows, bk=bk, desc=np.asarray(desc, np.int32).reshape(-1, 4), kt=np.asarray(kt, np.uint32),
+                         allowed_pairs=int(allowed.sum()), visited_pairs=len(kt) * rows * bk)
+
+
+@dataclass
 class FusionStructure:
     """Everything the reference's ``MCA.__init__`` derives from the config (model.py:305-372)."""
     token_dims: List[int]
@@ -220,6 +283,9 @@ class FusionStructure:
     def pool_schedule(self, bq: int = 32, bk: int = 64) -> TileSchedule:
         return build_schedule(self.qmask_pool, self.kgroup, bq, bk)
 
+    def attn_block_schedule(self, rows: int = 256, bk: int = 64) -> BlockSchedule:
+        return build_block_schedule(self.qmask_attn, self.kgroup, rows, bk)
+
 
 # --------------------------------------------------------------------------------------------------
 # EAO baseline: one SEGMENT per modality and per combination                    (model.py:481-596)
@@ -280,6 +346,9 @@ class EAOStructure:
 
     def attn_schedule(self, bq: int = 128, bk: int = 64) -> TileSchedule:
         return build_schedule(self.qmask_attn, self.kgroup, bq, bk)
+
+    def attn_block_schedule(self, rows: int = 256, bk: int = 64) -> BlockSchedule:
+        return build_block_schedule(self.qmask_attn, self.kgroup, rows, bk)
 
     def dense_attn_mask(self) -> np.ndarray:
         """True = blocked (the block-diagonal complement), as FusionStructure.dense_attn_mask"""

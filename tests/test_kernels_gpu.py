@@ -445,6 +445,35 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first, prescaled=True, spi
         assert (lse2[fin] - lse[fin]).abs().max() < 1e-4          # adding an exact 0 / an exp2 that underflows to exactly 0
         assert rel(o2.float(), o.float()) < 2e-3
         a.o, a.lse = o.data_ptr(), lse.data_ptr()
+        # ---- the query-block kernel (attention_fwd64.hip: self-attention, blocks of up to 256 rows cut along the structure, lazy
+        # softmax reference): same contract against the dense fp64 reference, bitwise repeatable, and the same with the reference
+        # moved at EVERY increase (knob 15 = 1: the rescale branch taken all the time) - cdna guide rule 26
+        if not pool:
+            S_ = importlib.import_module("mca-paper_amd.structure")
+            bs = eng._BlockSched(S_.build_block_schedule(qmask_np, st.kgroup, 256, 64), dev)
+            assert int(bs.s.desc[:, 1].sum()) == nq and int(bs.s.desc[:, 1].max()) <= 256
+            outs = []
+            for knob in (0, 0, 1):
+                o3 = torch.zeros_like(o); lse3 = torch.empty_like(lse)
+                a.o, a.lse = o3.data_ptr(), lse3.data_ptr()
+                a.qb_desc, a.qb_kt, a.n_qblocks = bs.desc.data_ptr(), bs.kt.data_ptr(), bs.n
+                H.lib().mca_debug_set(15, knob)          # (not H.knobs: leaving that context resets EVERY knob, the caller's too)
+                H.call("mca_attn_fwd", C.byref(a), H.stream_ptr())
+                torch.cuda.synchronize()
+                H.lib().mca_debug_set(15, 0)
+                got3 = o3.float().view(b, nq, D)
+                e3 = rel(got3, ref_o)
+                assert e3 < 6e-3, f"query-block forward rel err {e3} (knob 15 = {knob})"
+                row3 = (got3.double() - ref_o.detach()).norm(dim=-1) / (ref_o.detach().norm(dim=-1) + 1e-9)
+                assert float(row3.max()) < 3e-2, f"worst row of the query-block forward: {float(row3.max())} (knob 15 = {knob})"
+                assert torch.equal(torch.isinf(lse3[:, 0]), uni_ref)
+                assert (lse3[fin_rows].double() - lse_ref[fin_rows]).abs().max() < 1e-3
+                outs.append((o3, lse3))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])          # bitwise repeatable
+            # (two bf16 roundings of P against different references and of the output: 2.2-2.6e-3 measured at the CMU / LONG shapes)
+            assert rel(outs[2][0].float(), outs[0][0].float()) < 4e-3
+            a.qb_desc, a.qb_kt, a.n_qblocks = None, None, 0
+            a.o, a.lse = o.data_ptr(), lse.data_ptr()
 
     # ---- backward
     d_o = bf(torch.randn(b, nq, D, device=dev, generator=g))
@@ -529,8 +558,10 @@ def test_attention_register_staged_forward_form(H, shape):
 
 
 def test_attention_forward_kernels_agree_bit_for_bit(H):
-    """the LDS-DMA forward (production, 4 wavefronts per SIMD) and the register-staged one (knob 13 = 1) do the same
-    arithmetic in the same order: identical o and lse on the CMU structure with ragged lengths and a dropped modality"""
+    """the 128-row-tile LDS-DMA forward (knob 13 = 2; 4 wavefronts per SIMD) and the register-staged one (knob 13 = 1) do the
+    same arithmetic in the same order: identical o and lse on the CMU structure with ragged lengths and a dropped modality.
+    (The query-block kernel, production since round 4, moves its softmax reference lazily: equal up to rounding, see
+    _attention_case.)"""
     P = importlib.import_module("mca-paper_amd")
     b = 3
     cfg = P.config.cmu_model_config(batch_size=b); cfg["depth"] = 1
@@ -556,7 +587,8 @@ def test_attention_forward_kernels_agree_bit_for_bit(H):
         torch.cuda.synchronize()
         return a["o"].clone(), a["lse"].clone()
 
-    o4, l4 = fwd()
+    with H.knobs(k13=2):
+        o4, l4 = fwd()
     with H.knobs(k13=1):
         o1, l1 = fwd()
     assert torch.isinf(l4).any() and torch.isfinite(l4).any()

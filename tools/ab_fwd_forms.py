@@ -1,6 +1,9 @@
-"""Interleaved A/B (one process, one box) of the two forward attention kernels on the CMU structure: LDS-DMA staging, 4 wavefronts
-per SIMD (production) against register staging, 3 per SIMD (knob 13 = 1).  usage: ab_fwd_forms.py"""
-import importlib, os, sys, torch
+"""Interleaved A/B (one process, one box) of the forward attention kernels on the CMU structure: the query-block kernel (round 4:
+256-row blocks cut along the structure, one wavefront per SIMD, 64 rows each, lazy softmax reference; production) against the
+128-row-tile LDS-DMA kernel (knob 13 = 2) and the register-staged one (knob 13 = 1).  usage: ab_fwd_forms.py"""
+import importlib, os, sys
+os.environ.setdefault("MCA_DEBUG", "fwd64=1")          # the engine offers the query-block schedule only when asked
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 P = importlib.import_module("mca-paper_amd"); H = importlib.import_module("mca-paper_amd.hip")
 def setup(b, pad):
@@ -29,9 +32,10 @@ def t(fn, n=20):
     return s.elapsed_time(e) / n * 1e3
 for b, pad in ((32, 0), (32, 1), (16, 0), (8, 0), (8, 1), (4, 0)):
     fn = setup(b, pad)
-    r = {0: [], 1: []}
+    r = {0: [], 1: [], 2: []}
     for rnd in range(4):
-        for k in (0, 1):
+        for k in (0, 2, 1):
             with H.knobs(k13=k):
                 r[k].append(t(fn))
-    print(f"b={b} pad={pad}: lds-dma {min(r[0]):.1f} us   register-staged {min(r[1]):.1f} us   ratio {min(r[0]) / min(r[1]):.3f}", flush=True)
+    print(f"b={b} pad={pad}: query-block {min(r[0]):.1f} us   128-row lds-dma {min(r[2]):.1f} us   register-staged {min(r[1]):.1f} us   "
+          f"ratio {min(r[0]) / min(r[2]):.3f}", flush=True)

@@ -1,0 +1,147 @@
+// Slot-cost probe for the query-block attention forward (measurement tool, not part of the library): one wavefront per SIMD
+// (256 workgroups x 256 threads), the instruction stream of one pipeline step of attention_fwd64.hip without memory:
+// 16 slots of {one v_mfma_f32_32x32x16_bf16; 2 v_exp_f32, 2 v_add_f32, 1 v_cvt_pk_bf16_f32}, preceded by the 20 maxima.
+// Variants say where the accumulators live and what is left out; cycles per step by s_memtime of wavefront 0.
+//   build: hipcc -O3 --offload-arch=gfx950 -fno-slp-vectorize -shared -fPIC -o tools/probe_slot.so tools/probe_slot.hip
+#include <hip/hip_runtime.h>
+#include <cstdint>
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  const bf16x2v h = __builtin_convertvector(f32x2v{lo, hi}, bf16x2v);
+  return *reinterpret_cast<const uint32_t*>(&h);
+}
+#define SB() __builtin_amdgcn_sched_barrier(0)
+// MODE bits: 1 = O accumulators in AGPRs (else VGPRs)   2 = no vector work   4 = no matrix work   8 = S accumulators in AGPRs
+//            (their values are NOT moved to VGPRs: the exponentials read stand-ins)   16 = A / B operands of S in VGPRs
+//            32 = no maxima   64 = exponentials only (no add / pack)   128 = one exp per slot instead of two
+//            256 = one LDS fragment read per slot (13 per step) into the NEXT step's fragments, destinations in AGPRs;
+//            512 = the same with destinations in VGPRs (S operands then come from VGPRs)   1024 = the 13 reads in one burst at the step's start
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void probe(int iters, float* out, uint64_t* stamps) {
+  f32x16 o[4], sa[2], sb[2], negm[2];
+  u32x4v pa[2][2], pb[2][2];
+  bf16x8 kf[4], qf[2][4], vf[4], hf;
+  float l[2] = {0.f, 0.f};
+  const float tf = (float)threadIdx.x * 1e-4f;          // (lane-dependent start values: uniform ones would live in SGPRs)
+  const int tx = (int)threadIdx.x & 15;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) o[i][j] = tf;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) { sa[i][j] = -1.f - j * 0.01f - tf; sb[i][j] = -2.f - j * 0.01f - tf; negm[i][j] = -0.5f - tf; }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) { pa[i][k][j] = 0x3c003c00u + tx; pb[i][k][j] = 0x3c003c00u + tx; }
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    hf[j] = (short)tx;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { kf[i][j] = (short)(0x3c00 + tx + i); vf[i][j] = (short)(0x3b80 + i + tx); qf[0][i][j] = (short)(0x3a00 + tx); qf[1][i][j] = (short)(0x3a80 + tx); }
+  }
+  __shared__ __attribute__((aligned(16))) unsigned short lds_s[16384];
+  for (int i = threadIdx.x; i < 16384; i += 256) lds_s[i] = (unsigned short)(0x3c00 + (i & 15));
+  __syncthreads();
+  const unsigned short* lp = lds_s + (threadIdx.x & 63) * 8;          // 16-byte lane stride: conflict-free b128 reads
+  bf16x8 kg[4], hg;
+#pragma unroll
+  for (int j = 0; j < 8; j++) { hg[j] = hf[j]; kg[0][j] = kf[0][j]; kg[1][j] = kf[1][j]; kg[2][j] = kf[2][j]; kg[3][j] = kf[3][j]; }
+  const uint64_t t0 = __builtin_readcyclecounter();
+#define MF_S_INIT(D, A, B, C) do { if (!(MODE & 4)) { if (MODE & 8) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&a"(D) : "a"(A), "a"(B), "a"(C)); \
+    else if (MODE & (16 | 512)) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(D) : "v"(A), "v"(B), "v"(C)); \
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(D) : "a"(A), "a"(B), "v"(C)); } } while (0)
+#define MF_S_ACC(D, A, B) do { if (!(MODE & 4)) { if (MODE & 8) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(D) : "a"(A), "a"(B)); \
+    else if (MODE & (16 | 512)) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "v"(A), "v"(B)); \
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "a"(A), "a"(B)); } } while (0)
+#define MF_O(D, A, B) do { if (!(MODE & 4)) { if (MODE & 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(D) : "a"(A), "v"(B)); \
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "a"(A), "v"(B)); } } while (0)
+  // step: S(new) into SN, exponentiate SX -> PN, O += V . PO
+#define EXPG(G, SX, PN)                                                                           \
+  if (!(MODE & 2)) {                                                                              \
+    constexpr int qb_ = (G) >> 3, i_ = (G) & 7;                                                   \
+    const float p0_ = __builtin_amdgcn_exp2f(SX[qb_][2 * i_]);                                    \
+    const float p1_ = (MODE & 128) ? SX[qb_][2 * i_ + 1] : __builtin_amdgcn_exp2f(SX[qb_][2 * i_ + 1]); \
+    if (!(MODE & 64)) { l[qb_] += p0_; l[qb_] += p1_; PN[qb_][i_ >> 2][i_ & 3] = pack2(p0_, p1_); \
+      asm volatile("" :: "v"(PN[qb_][i_ >> 2][i_ & 3]), "v"(l[qb_])); }                            \
+    else asm volatile("" :: "v"(p0_), "v"(p1_));                                                   \
+  }                                                                                               \
+  SB();
+#define RDF(I, DST) if ((MODE & 256) || (MODE & 512)) { DST = *reinterpret_cast<const bf16x8*>(lp + (I) * 1024 + (it & 1) * 512); }
+#define RDS(I, DST) if (!(MODE & 1024)) RDF(I, DST)
+#define STEP_(SN, SX, PN, PO, KC, HC, KN, HN_)                                                    \
+  {                                                                                               \
+    float mx0 = 0.f, mx1 = 0.f;                                                                   \
+    if (MODE & 1024) { RDF(0, KN[0]) RDF(1, KN[1]) RDF(2, KN[2]) RDF(3, KN[3]) RDF(4, HN_) }                                                                   \
+    if (!(MODE & 2) && !(MODE & 32)) {                                                            \
+      mx0 = fmaxf(fmaxf(SX[0][0], SX[0][1]), SX[0][2]); mx1 = fmaxf(fmaxf(SX[1][0], SX[1][1]), SX[1][2]); \
+      _Pragma("unroll") for (int r = 3; r < 15; r += 2) { mx0 = fmaxf(fmaxf(mx0, SX[0][r]), SX[0][r + 1]); mx1 = fmaxf(fmaxf(mx1, SX[1][r]), SX[1][r + 1]); } \
+      asm volatile("" :: "v"(mx0), "v"(mx1));                                                     \
+    }                                                                                             \
+    SB();                                                                                         \
+    MF_O(o[0], vf[0], PO[0][0]); MF_O(o[2], vf[0], PO[1][0]); MF_O(o[1], vf[1], PO[0][0]); MF_O(o[3], vf[1], PO[1][0]); \
+    SB();                                                                                         \
+    MF_S_INIT(SN[0], KC[0], qf[0][0], negm[0]); RDS(0, KN[0]) EXPG(0, SX, PN)                     \
+    MF_S_INIT(SN[1], KC[0], qf[1][0], negm[1]); EXPG(1, SX, PN)                                   \
+    MF_O(o[0], vf[2], PO[0][1]); RDS(1, KN[1]) EXPG(2, SX, PN)                                    \
+    MF_O(o[2], vf[2], PO[1][1]); EXPG(3, SX, PN)                                                  \
+    MF_S_ACC(SN[0], KC[1], qf[0][1]); RDS(2, KN[2]) EXPG(4, SX, PN)                               \
+    MF_S_ACC(SN[1], KC[1], qf[1][1]); EXPG(5, SX, PN)                                             \
+    MF_O(o[1], vf[3], PO[0][1]); RDS(3, KN[3]) EXPG(6, SX, PN)                                    \
+    MF_O(o[3], vf[3], PO[1][1]); EXPG(7, SX, PN)                                                  \
+    MF_S_ACC(SN[0], KC[2], qf[0][2]); RDS(4, HN_) EXPG(8, SX, PN)                                 \
+    MF_S_ACC(SN[1], KC[2], qf[1][2]); EXPG(9, SX, PN)                                             \
+    MF_S_ACC(SN[0], KC[3], qf[0][3]); EXPG(10, SX, PN)                                            \
+    MF_S_ACC(SN[1], KC[3], qf[1][3]); EXPG(11, SX, PN)                                            \
+    MF_S_ACC(SN[0], HC, qf[0][0]); EXPG(12, SX, PN)                                               \
+    MF_S_ACC(SN[1], HC, qf[1][0]); EXPG(13, SX, PN)                                               \
+    EXPG(14, SX, PN) EXPG(15, SX, PN)                                                             \
+  }
+#define STEP(SN, SX, PN, PO) STEP_(SN, SX, PN, PO, kf, hf, kf, hf)
+  for (int it = 0; it < iters; it++) {
+    if (MODE & 8) {          // S in AGPRs: the exponentials read stand-ins that stay in VGPRs
+      f32x16 ta[2] = {negm[0], negm[1]}, tb[2] = {negm[0], negm[1]};
+      STEP(sa, tb, pa, pb)
+      STEP(sb, ta, pb, pa)
+    } else if (MODE & (256 | 512)) {          // fragments ping-pong between two register sets, five reads per step
+      STEP_(sa, sb, pa, pb, kf, hf, kg, hg)
+      STEP_(sb, sa, pb, pa, kg, hg, kf, hf)
+    } else {
+      STEP(sa, sb, pa, pb)
+      STEP(sb, sa, pb, pa)
+    }
+  }
+  const uint64_t t1 = __builtin_readcyclecounter();
+  float r = l[0] + l[1];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) r += o[i][j];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) r += sa[i][j] + sb[i][j];
+  if (r == 123.456f) out[0] = r;
+  if (blockIdx.x == 0 && threadIdx.x == 0) stamps[0] = t1 - t0;
+}
+
+extern "C" int probe_run(int mode, int blocks, int iters, float* out, uint64_t* stamps, float* ms) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+#define LAUNCH(M) case M: probe<M><<<blocks, 256>>>(10, out, stamps); hipEventRecord(e0); probe<M><<<blocks, 256>>>(iters, out, stamps); hipEventRecord(e1); break;
+  switch (mode) {
+    LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(9) LAUNCH(16) LAUNCH(17) LAUNCH(32) LAUNCH(33) LAUNCH(64) LAUNCH(65) LAUNCH(128) LAUNCH(129) LAUNCH(36) LAUNCH(68) LAUNCH(196) LAUNCH(256) LAUNCH(512) LAUNCH(1280) LAUNCH(1536) LAUNCH(258) LAUNCH(514)
+    default: return -1;
+  }
+  hipEventSynchronize(e1);
+  hipEventElapsedTime(ms, e0, e1);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
