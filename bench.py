@@ -222,6 +222,8 @@ def main():
     # under data parallelism the replayed step is a chain of graph segments cut at the collectives (graph.GraphedStep)
     use_graph = args.graph or (args.launch == "graph") or args.launch == "auto"
     graphed = None
+    # what was chosen and why goes into the JSON line (config.launch_choice), not only to stderr
+    choice = {"requested": "graph" if args.graph else args.launch, "chosen": "eager", "reason": "--launch eager"}
     if use_graph:
         err = None
         try:
@@ -248,13 +250,19 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 return float(tt)
             t_replay, t_eager = timed_pair(False), timed_pair(True)
+            choice["guard_ms_per_step"] = {"replay": round(t_replay / 2 * 1e3, 2), "eager": round(t_eager / 2 * 1e3, 2)}
             if t_replay > 1.05 * t_eager:
                 if rank == 0:
                     print(f"bench: segmented replay {t_replay / 2 * 1e3:.1f} ms/step against {t_eager / 2 * 1e3:.1f} ms eager: running the eager loop", file=sys.stderr, flush=True)
                 ok.zero_()
+                choice["reason"] = "segmented replay slower than the eager loop in the two-step guard (max over ranks)"
         if int(ok):
             step = graphed.step
+            choice.update(chosen="graph", reason=("one hipGraph per step" if world == 1 else "graph segments cut at the eager collectives" +
+                                                  (": not slower than the eager loop in the two-step guard" if "guard_ms_per_step" in choice else " (forced: no guard)")))
         else:
+            if choice["reason"] == "--launch eager":
+                choice["reason"] = f"capture failed ({type(err).__name__ if err else 'on another rank'}): every rank runs the eager loop"
             if err is not None or graphed is None:
                 print(f"bench: hipGraph capture failed on rank {rank} ({type(err).__name__ if err else 'another rank'}: {err}); running the eager loop", file=sys.stderr, flush=True)
             use_graph, graphed = False, None
@@ -329,6 +337,7 @@ def main():
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
                        "inputs": "device-resident, same batch every step" if host_batch is None else ("pinned host memory, copied to the device every step (PCIe-inclusive" + (", one step ahead on a copy stream)" if feed is not None else ", in the compute stream)")), "finite_checks": "on (device flag, polled)",
                        "attention_operands": args.attn, "launch": ("hipGraph replay (" + ("one launch per step" if world == 1 else f"{sum(1 for it in graphed.program if isinstance(it, torch.cuda.CUDAGraph))} graph segments cut at {sum(1 for it in graphed.program if not isinstance(it, torch.cuda.CUDAGraph))} eager collectives per step") + (f"; {sampled} of {args.steps} steps eager for the kernel timing)" if sampled else ")")) if use_graph else "eager",
+                       "launch_choice": choice,
                        "collectives": (f"{dist.get_backend()} over {dist.get_world_size()} ranks" if world > 1 else "none")},
         }
         if gf:

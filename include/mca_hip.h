@@ -219,6 +219,13 @@ typedef struct {
  * scale): the kernels then take q.k as the log2-domain logit and never multiply a score.  lse, o, dq, dk, dv keep their
  * meaning (dq is the gradient w.r.t. the UNSCALED q, so the data- and weight-gradient GEMMs are unchanged).              */
 #define MCA_ATTN_Q_PRESCALED 1
+/* mca_attn_fwd only, optional: LAZY softmax reference.  The score accumulators start from -m (the MFMA C operand) and m moves
+ * only when a score exceeds it by more than 12 (log2 units) or a row meets its first real key, instead of following every new
+ * row maximum: a third fewer vector instructions per tile (CMU b = 32: 304 against 336 us per layer).  Same contract (o, lse,
+ * uniform rows) and the same distance from the exact softmax (tests/test_kernels_gpu.py); P is rounded to bf16 against another
+ * reference, so results differ from the default form by rounding (2-3e-3 rel-L2 of o).  Off by default: the gradient
+ * statistics the step-level tests pin against the reference's own numbers were calibrated on the default form.           */
+#define MCA_ATTN_LAZY_REFERENCE 2
 /* dim_head is fixed at 64; query tile 128 rows, key tile 64.                                     */
 int mca_attn_fwd(const mca_attn_fwd_args* args, mca_stream_t stream);
 
@@ -328,7 +335,10 @@ int mca_contrastive_fwd_bwd(const float* pooled_all, const uint32_t* present_all
 /* ---------------------------------------------------------------------------------------------
  * clip_grad_norm_ + AdamW over one flat buffer (train_accel_gpu.py:116-118; torch AdamW defaults)
  * --------------------------------------------------------------------------------------------- */
-/* sqnorm[0] += sum g^2  (caller zeroes sqnorm)                                                   */
+/* sqnorm[0] += sum g^2  (caller zeroes sqnorm[0]).  sqnorm points at MCA_SQNORM_WORDS floats: words 1.. are scratch for the
+ * per-block partial sums, added in a fixed order (the same bits on every launch and on every data-parallel replica); the
+ * library itself holds no state, calls on different buffers may overlap.                          */
+#define MCA_SQNORM_WORDS 1025
 int mca_grad_sqnorm(const float* g, int64_t n, float* sqnorm, mca_stream_t stream);
 /* grads scaled by min(1, max_norm/(sqrt(sqnorm)+1e-6)) when max_norm > 0, then decoupled AdamW.
  * skip_flag (may be NULL): device word written by mca_nonfinite_flag; non-zero = the step is skipped,

@@ -20,9 +20,10 @@ extern "C" {
  *       (trace build; gemm_tn_256x256_group_kernel in every build), 16 = launch order without the XCD remap, 32 = fp8 forward with
  *       register staging instead of LDS-DMA
  *   12  = 1: general LayerNorm kernels where the trunk forms would be chosen;   13  = 1: register-staged attention forward,
- *       = 2: the 128-row-tile LDS-DMA forward where the query-block kernel (attention_fwd64.hip) would be chosen
+ *       = 2: the LDS-DMA forward (attn_fwd4_kernel) whatever the flags and schedules say, = 3: the query-block kernel
+ *       (attention_fwd64.hip) whenever the caller supplies its schedule
  *   14  > 0: cap on the workgroups of the trunk LayerNorm backward (default 256)
- *   15  = t + 1: the query-block forward attention moves its lazy softmax reference when a score exceeds it by more than t
+ *   15  = t + 1: the forward attention kernels move their lazy softmax reference when a score exceeds it by more than t
  *       log2 units (default 12; 1 = at every increase, the textbook online softmax) */
 int mca_debug_set(int key, int value);
 /* every knob back to 0 */

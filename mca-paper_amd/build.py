@@ -30,9 +30,12 @@ def needs_build() -> bool:
 TRACE_OUT = os.path.join(HERE, "libmca_hip_trace.so")
 
 
-def build_variant(out_path: str, defines=(), only=None) -> str:
+def build_variant(out_path: str, defines=(), only=None, overlays=None) -> str:
     """An A/B build of the same ABI with extra -D defines (tools/ab_lib_*.py load it through MCA_HIP_LIB).  only: the sources the
-    defines affect; every other object is taken from the product build directory (run build() first)."""
+    defines affect; every other object is taken from the product build directory (run build() first).
+    overlays: {source name: patch file}: measurement code that does NOT live in the product sources (timing-only ablations,
+    tools/overlays/*.patch) is patched into a copy of the source in the variant's build directory first; a patch that no longer
+    applies fails the build."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     bdir = os.path.join(HERE, "build_" + os.path.splitext(os.path.basename(out_path))[0])
     os.makedirs(bdir, exist_ok=True)
@@ -43,7 +46,13 @@ def build_variant(out_path: str, defines=(), only=None) -> str:
             continue
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, *[f"-D{d}" for d in defines], *EXTRA.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        src_path = os.path.join(CSRC, src)
+        if overlays and src in overlays:
+            src_path = os.path.join(bdir, src)
+            r = subprocess.run(["patch", "-s", "-o", src_path, os.path.join(CSRC, src), overlays[src]], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"overlay {overlays[src]} does not apply to {src}:\n{r.stdout}")
+        cmd = [hipcc, *FLAGS, *[f"-D{d}" for d in defines], *EXTRA.get(src, []), f"-I{CSRC}", "-c", src_path, "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for src, p in procs:
         out, _ = p.communicate()

@@ -12,9 +12,6 @@
 //                     without its dS^T image, K image, dQ product and atomics.
 // The price is S and dP computed twice (7 MFMA products instead of 5); both passes are bitwise reproducible.
 #include "common.h"
-#ifndef DKV_ABL
-#define DKV_ABL 0          // timing-only ablations of the dkv pass (tools/ablate_dkv.py): 1 no exp, 2 no dV / dK products, 4 no transposed reads
-#endif
 
 #define DH 64
 #define AQ 128      // dq pass: query rows per workgroup
@@ -535,11 +532,7 @@ __global__ __launch_bounds__(64 * W) void attn_bwd_dkv_kernel(mca_attn_bwd2_args
       if (clean || use_hot) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-#if DKV_ABL & 1
-          const float p0 = s[r], p1 = s[r + 1];
-#else
           const float p0 = __builtin_amdgcn_exp2f(PRESCALED ? s[r] : s[r] * c2), p1 = __builtin_amdgcn_exp2f(PRESCALED ? s[r + 1] : s[r + 1] * c2);
-#endif
           const uint32_t pp = pack2bf_pk(p0, p1), ss = pack2bf_pk(p0 * dp[r], p1 * dp[r + 1]);
           pbw[r >> 3][(r & 7) >> 1] = pp;
           sbw[r >> 3][(r & 7) >> 1] = ss;
@@ -561,10 +554,6 @@ __global__ __launch_bounds__(64 * W) void attn_bwd_dkv_kernel(mca_attn_bwd2_args
         }
       }
       // dV^T += dO^T P ; dK^T += Q^T dS   (element j of k-step sp carries q = 16sp + 8(j>>2) + 4lh + (j&3))
-#if DKV_ABL & 2
-      asm volatile("" :: "v"(pbw[0]), "v"(pbw[1]), "v"(sbw[0]), "v"(sbw[1]));
-      if (false)
-#endif
 #pragma unroll
       for (int sp = 0; sp < 2; sp++)
 #pragma unroll
@@ -574,12 +563,8 @@ __global__ __launch_bounds__(64 * W) void attn_bwd_dkv_kernel(mca_attn_bwd2_args
           for (int t = 0; t < 2; t++) {
             const int qr = 16 * sp + 8 * t + 4 * lh + tq;
             const int d = n * 32 + 16 * tg + 4 * tp;
-#if DKV_ABL & 4
-            const bf16x4 o4 = {(short)qr, 0, 0, 0}, q4 = {(short)d, 0, 0, 0};
-#else
             const bf16x4 o4 = lds_read_tr16(os + rt_off(qr, d >> 3) + (d & 7));
             const bf16x4 q4 = lds_read_tr16(qs + rt_off(qr, d >> 3) + (d & 7));
-#endif
 #pragma unroll
             for (int e = 0; e < 4; e++) { ot[4 * t + e] = o4[e]; qtf[4 * t + e] = q4[e]; }
           }

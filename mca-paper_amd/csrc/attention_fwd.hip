@@ -175,11 +175,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
     FW_STAMP();
     const uint32_t ent = live_s[it];
     const int kt = (int)(ent & 0x7fffffffu);
-#ifdef ABL_NOMASK
-    const bool need_mask = false;
-#else
     const bool need_mask = (ent >> 31) == 0 || (flags_s[kt] != 2);
-#endif
     const int nit = it + 1;
     if (nit < it_end) gload((int)(live_s[nit] & 0x7fffffffu));
 
@@ -317,18 +313,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
 // chip is full and 14 % where it is not: the loop is bound by vector / matrix ISSUE per SIMD, not by latency.
 // Same arithmetic in the same order as attn_fwd_kernel: the two give the same bits (tests/test_kernels_gpu.py).
 // =====================================================================================================
-#ifndef FWD4_WAVES
-#define FWD4_WAVES 4
-#endif
-__global__ __launch_bounds__(256, FWD4_WAVES) void attn_fwd4_kernel(mca_attn_fwd_args a, int dbg) {
+__global__ __launch_bounds__(256, 4) void attn_fwd4_kernel(mca_attn_fwd_args a, int dbg) {
   __shared__ __attribute__((aligned(16))) u16 lds[2 * 2 * AK * DH + 2 * AK * 16];   // K, V double-buffered (32 KiB) + one-hot tiles (4 KiB)
   __shared__ uint8_t flags_s[MAX_KTILES];
   __shared__ uint32_t live_s[MAX_KTILES];
   __shared__ int n_live_s;
-#ifdef FWD4_PAD_LDS          // measurement only (tools/ab_fwd_forms.py): dead LDS that caps the workgroups per CU at three
-  __shared__ uint32_t pad_s[FWD4_PAD_LDS / 4];
-  if (dbg == 0x7fffffff) pad_s[threadIdx.x] = 1;
-#endif
   u16* Ks = lds;
   u16* Vs = lds + 2 * AK * DH;
   u16* Hs = lds + 4 * AK * DH;
@@ -523,6 +512,232 @@ __global__ __launch_bounds__(256, FWD4_WAVES) void attn_fwd4_kernel(mca_attn_fwd
   }
 }
 
+// =====================================================================================================
+// The LDS-DMA kernel with a LAZY softmax reference (MCA_ATTN_LAZY_REFERENCE; round 4): same tiling, staging and mask product as
+// attn_fwd4_kernel, but the score accumulators start from -m (the MFMA C operand) and m moves only in a rare wave-uniform slow
+// path (attention_fwd64.hip explains the rule).  Per 32 x 64 block that removes 32 subtractions, the 32 multiplies that rescale
+// O, the exponential of the rescale factor and both cross-lane exchanges of the online softmax: a third of the vector
+// instructions of a loop that is bound by vector issue.  16 registers more (-m): three wavefronts per SIMD instead of four,
+// which this kernel does not notice (round 3: 338.5 us with three against 338.6 with four).  Results differ from
+// attn_fwd4_kernel by rounding only (P is rounded to bf16 against another reference); knob 15 = t + 1 sets the threshold t
+// (1: the reference follows every increase, the textbook recurrence).  NOT the default: the re-drawn rounding pattern moves the
+// cancellation-heavy gradient statistics of the CMU golden step (three bias-gradient norms 1.0 % -> 4.4 % off the reference's
+// numbers, pooled embeddings 6.1e-4 either way), and parity margins outrank 0.75 % of the step.
+// =====================================================================================================
+__global__ __launch_bounds__(256, 3) void attn_fwd4l_kernel(mca_attn_fwd_args a, int dbg, float thr) {
+  __shared__ __attribute__((aligned(16))) u16 lds[2 * 2 * AK * DH + 2 * AK * 16];   // K, V double-buffered (32 KiB) + one-hot tiles (4 KiB)
+  __shared__ uint8_t flags_s[MAX_KTILES];
+  __shared__ uint32_t live_s[MAX_KTILES];
+  __shared__ int n_live_s;
+  u16* Ks = lds;
+  u16* Vs = lds + 2 * AK * DH;
+  u16* Hs = lds + 4 * AK * DH;
+
+  const int lin0 = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+  const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y * gridDim.z));
+  const int qt = a.q_order[lin % (int)gridDim.x];
+  const int h = (lin / (int)gridDim.x) % (int)gridDim.y, b = lin / (int)(gridDim.x * gridDim.y);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int q0 = qt * AQ + wave * 32;
+  int qrow = q0 + l31;
+  const bool qvalid = qrow < a.nq;
+  if (qrow > a.nq - 1) qrow = a.nq - 1;
+
+  bf16x8 qf[4];
+  {
+    const u16* qp = a.q + (int64_t)b * a.q_bstride + (int64_t)qrow * a.q_ld + h * DH + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+  const uint32_t qm = a.qmask[qrow];
+  const uint32_t qm8 = ((qm >> (8 * lh)) & 0xffu) & (lh ? 0x7fu : 0xffu);
+
+  f32x16 o[2];
+#pragma unroll
+  for (int n = 0; n < 2; n++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[n][r] = 0.f;
+  // lazy reference maximum (attention_fwd64.hip's rule): the S^T accumulators START from -m, so the scores leave the matrix pipe as
+  // S - m; m moves only when a score exceeds it by more than thr, or when a row that has accumulated nothing meets its first
+  // REAL key (blocked scores, -32768 from the mask product, never set it); l_run is this LANE's share of the row sum
+  f32x16 negm;
+#pragma unroll
+  for (int r = 0; r < 16; r++) negm[r] = 0.f;
+  float l_run = 0.f;
+
+  const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
+  const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
+  const u16* khot_g = a.khot + (int64_t)b * a.nk_pad * 16;
+  {
+    const uint8_t* flags_g = a.ktile_flags + (int64_t)b * a.n_ktiles;
+    for (int i = tid; i < a.n_ktiles; i += 256) flags_s[i] = flags_g[i];
+  }
+  __syncthreads();
+
+  // DMA pieces: piece p = 256 i + tid of a tile image lands at byte 16 p; it must hold chunk c = slot ^ swizzle(row) of row
+  // p >> 3 (slot = p & 7): the swizzle sits on the SOURCE column
+  int prow[2];
+  unsigned koff[2], voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int p = 256 * i + tid, r = p >> 3, sl = p & 7;
+    prow[i] = r;
+    koff[i] = (unsigned)(r * (int)a.kv_ld + ((sl ^ ((r >> 1) & 7)) << 3));
+    voff[i] = (unsigned)(r * (int)a.kv_ld + ((sl ^ (((r >> 1) & 1) << 2)) << 3));
+  }
+  const int last_kt = a.n_ktiles - 1;
+  auto stage = [&](int kt, int buf) {
+    const u16* kb = kbase + (int64_t)kt * AK * a.kv_ld;
+    const u16* vb = vbase + (int64_t)kt * AK * a.kv_ld;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      unsigned ko = koff[i], vo = voff[i];
+      if (kt == last_kt) {          // rows past nk: re-read the last valid row (masked by its one-hot row)
+        int key = kt * AK + prow[i]; const int over = key - (a.nk - 1);
+        if (over > 0) { ko -= (unsigned)(over * (int)a.kv_ld); vo -= (unsigned)(over * (int)a.kv_ld); }
+      }
+      u16* dk = Ks + buf * AK * DH + (i * 4 + wave) * 512;
+      u16* dv = Vs + buf * AK * DH + (i * 4 + wave) * 512;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + ko), (__attribute__((address_space(3))) void*)dk, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + vo), (__attribute__((address_space(3))) void*)dv, 16, 0, 0);
+    }
+    if (wave < 2) {                 // 64 keys x 16 one-hot columns = 128 pieces
+      u16* dh = Hs + buf * AK * 16 + wave * 512;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(khot_g + (int64_t)kt * (AK * 16) + tid * 8),
+                                       (__attribute__((address_space(3))) void*)dh, 16, 0, 0);
+    }
+  };
+
+  if (wave == 0) {
+    const int lb = a.q_ptr[qt], le = a.q_ptr[qt + 1];
+    int n = 0;
+    for (int i0 = lb; i0 < le; i0 += 64) {
+      const int i = i0 + lane;
+      const uint32_t e = i < le ? a.q_kt[i] : 0u;
+      const uint8_t fl = i < le ? flags_s[e & 0x7fffffffu] : (uint8_t)0;
+      const bool keep = fl != 0;
+      const unsigned long long m = __ballot(keep);
+      if (keep) live_s[n + __popcll(m & ((1ull << lane) - 1ull))] = (e & 0x7fffffffu) | (((e >> 31) && fl == 2) ? 0x80000000u : 0u);
+      n += __popcll(m);
+    }
+    if (lane == 0) n_live_s = n;
+  }
+  __syncthreads();
+  const int it_end = n_live_s;
+  int buf = 0;
+  if (it_end > 0) stage((int)(live_s[0] & 0x7fffffffu), 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  for (int it = 0; it < it_end; it++) {
+    const uint32_t ent = live_s[it];
+    const bool need_mask = (ent >> 31) == 0;
+    if (it + 1 < it_end) stage((int)(live_s[it + 1] & 0x7fffffffu), buf ^ 1);
+    const u16* ks = Ks + buf * AK * DH;
+    const u16* vs = Vs + buf * AK * DH;
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+      for (int st = 0; st < 4; st++) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + k_off(kb * 32 + l31, 2 * st + lh));
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], st == 0 ? negm : s[kb], 0, 0, 0);
+      }
+    }
+    if (need_mask) {
+      u32x4v qb;
+#pragma unroll
+      for (int w = 0; w < 4; w++)
+        qb[w] = (((qm8 >> (2 * w)) & 1u) ? 0u : 0xC700u) | (((qm8 >> (2 * w + 1)) & 1u) ? 0u : 0xC7000000u);
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        const bf16x8 hf = *reinterpret_cast<const bf16x8*>(Hs + buf * AK * 16 + (kb * 32 + l31) * 16 + 8 * lh);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf, *reinterpret_cast<const bf16x8*>(&qb), s[kb], 0, 0, 0);
+      }
+    }
+    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[0][r]), s[0][r + 1]);
+    mx = fmaxf(fmaxf(mx, s[0][15]), s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[1][r]), s[1][r + 1]);
+    mx = fmaxf(mx, s[1][15]);
+    const bool over = (mx > thr) | ((l_run == 0.f) & (mx > -16384.f));
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(over) != 0ull, 0)) {
+      // slow path (wave-uniform, rare): everything at the old reference is rescaled exactly once.  Every P.V of earlier tiles
+      // is complete (this kernel does not pipeline across tiles), this tile's exponentials come afterwards.
+      const float mfull = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+      const float lrow = l_run + __shfl_xor(l_run, 32, WAVE);
+      const bool empty = !(lrow > 0.f), real = mfull > -16384.f;
+      const float delta = (empty && real) ? mfull : (mfull > thr ? mfull : 0.f);
+      const float alpha = empty ? 0.f : __builtin_amdgcn_exp2f(-delta);
+      l_run *= alpha;
+#pragma unroll
+      for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[n][r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { negm[r] -= delta; s[0][r] -= delta; s[1][r] -= delta; }
+    }
+    float rs = 0.f;
+    u32x4v pw[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int sp = 0; sp < 2; sp++)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(s[kb][8 * sp + j]), p1 = __builtin_amdgcn_exp2f(s[kb][8 * sp + j + 1]);
+          rs += p0; rs += p1;
+          pw[kb][sp][j >> 1] = pack2bf_pk(p0, p1);
+        }
+    l_run += rs;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int sp = 0; sp < 2; sp++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+          bf16x8 vf;
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            const int key = kb * 32 + 16 * sp + 8 * t + 4 * lh + tq;
+            const int d = n * 32 + 16 * tg + 4 * tp;
+            const bf16x4 v4 = lds_read_tr16(vs + v_off(key, d >> 3) + (d & 7));
+#pragma unroll
+            for (int e = 0; e < 4; e++) vf[4 * t + e] = v4[e];
+          }
+          o[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, *reinterpret_cast<const bf16x8*>(&pw[kb][sp]), o[n], 0, 0, 0);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wavefront's pieces of the next tile have landed ...
+    __syncthreads();                                          // ... everybody's have, and this tile's reads are done
+    buf ^= 1;
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, WAVE);
+  const float m_run = -negm[0];
+  const bool uniform = !(l_tot > 0.f);          // only real keys ever contribute: a row of blocked keys sums exact zeros
+  const float inv = uniform ? 0.f : 1.f / l_tot;
+  if (qvalid) {
+    if (lh == 0) a.lse[((int64_t)b * a.heads + h) * a.nq + qrow] = uniform ? INFINITY : m_run + log2f(l_tot);
+    u16* op = a.o + (int64_t)b * a.o_bstride + (int64_t)qrow * a.o_ld + h * DH;
+    const float* vm = a.vmean + (int64_t)b * a.heads * DH + h * DH;
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int d = n * 32 + 8 * g + 4 * lh;
+        float v0, v1, v2, v3;
+        if (uniform) { v0 = vm[d]; v1 = vm[d + 1]; v2 = vm[d + 2]; v3 = vm[d + 3]; }
+        else { v0 = o[n][4 * g] * inv; v1 = o[n][4 * g + 1] * inv; v2 = o[n][4 * g + 2] * inv; v3 = o[n][4 * g + 3] * inv; }
+        uint2 pk; pk.x = pack2bf(v0, v1); pk.y = pack2bf(v2, v3);
+        *reinterpret_cast<uint2*>(op + d) = pk;
+      }
+  }
+}
+
 int mca_attn_fwd64_launch(const mca_attn_fwd_args* a, hipStream_t stream, int dbg);          // attention_fwd64.hip
 
 extern "C" int mca_attn_fwd(const mca_attn_fwd_args* a, mca_stream_t stream) {
@@ -544,9 +759,12 @@ extern "C" int mca_attn_fwd(const mca_attn_fwd_args* a, mca_stream_t stream) {
   if ((uintptr_t)a->khot % 16) return MCA_E_ALIGN;
   // round-4 structure, taken when the caller supplies the query-block schedule: blocks of up to 256 rows, one wavefront per
   // SIMD (knob 13 = 2 forces the 128-row-tile kernel: A/B).  The engine does not supply it by default (MCA_DEBUG=fwd64=1 does).
-  if (a->qb_desc && a->khot && mca_knobs[13] == 0 && (int64_t)a->kv_ld * 64 < (1ll << 30))
+  if (a->qb_desc && a->khot && (mca_knobs[13] == 0 || mca_knobs[13] == 3) && (int64_t)a->kv_ld * 64 < (1ll << 30))
     return mca_attn_fwd64_launch(a, as_stream(stream), mca_knobs[9]);
-  if (a->khot && mca_knobs[13] != 1 && (int64_t)a->kv_ld * 64 < (1ll << 30))
+  if (a->khot && (a->flags & MCA_ATTN_LAZY_REFERENCE) && mca_knobs[13] == 0 && (int64_t)a->kv_ld * 64 < (1ll << 30))
+    hipLaunchKernelGGL(attn_fwd4l_kernel, grid, dim3(256), 0, as_stream(stream), *a, mca_knobs[9],
+                       mca_knobs[15] > 0 ? (float)(mca_knobs[15] - 1) : 12.f);
+  else if (a->khot && mca_knobs[13] != 1 && (int64_t)a->kv_ld * 64 < (1ll << 30))
     hipLaunchKernelGGL(attn_fwd4_kernel, grid, dim3(256), 0, as_stream(stream), *a, mca_knobs[9]);
   else
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, as_stream(stream), *a, mca_knobs[9] | mca_knobs[8]);

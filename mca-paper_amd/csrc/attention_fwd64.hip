@@ -52,25 +52,15 @@ MCA_TRACE_BUFFER(attn_fwd64)      // trace build, knob 8 = 8: s_memtime stamps o
 #define F64_TRACE_ARGS
 #endif
 
-#ifndef F64_ABL
-#define F64_ABL 0          // timing-only ablations (tools/ablate_fwd64.py): 1 no DMA pieces in the steps, 2 no fragment reads in the steps,
-#endif                     // 4 no lazy-maximum decision / slow path, 8 no tile sync, 16 no exponential groups, 32 no matrix instructions, 64 no maxima
 #define F64_SB() __builtin_amdgcn_sched_barrier(0)
 // register classes: what the vector unit touches (scores, P, O, -m) lives in VGPRs; what only the matrix pipe reads (Q
 // fragments for the whole kernel, K / V^T / one-hot fragments straight from LDS, the mask words) lives in the accumulator half
-#if F64_ABL & 32
-#define MFMA_INIT(D, A, B, C) do { D = C; asm volatile("" : "+v"(D) : "a"(A), "a"(B)); } while (0)
-#define MFMA_ACCV(D, A, B) asm volatile("" : "+v"(D) : "a"(A), "a"(B))
-#define MFMA_ACCA(D, A, B) asm volatile("" : "+v"(D) : "v"(A), "v"(B))
-#define MFMA_ACCM(D, A, B) asm volatile("" : "+v"(D) : "a"(A), "v"(B))
-#else
 #define MFMA_INIT(D, A, B, C) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(D) : "a"(A), "a"(B), "v"(C))
 #define MFMA_ACCV(D, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "a"(A), "a"(B))
 // (the V^T fragments, two 64-bit transposed reads glued into one operand and carried across a step boundary, are kept in
 //  VGPRs by hipcc whatever the constraint says: asking for them there saves the copies; operand class does not change the rate)
 #define MFMA_ACCA(D, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "v"(A), "v"(B))
 #define MFMA_ACCM(D, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "a"(A), "v"(B))
-#endif
 
 __device__ __forceinline__ int f64_k_off(int r, int c) { return r * 64 + ((c ^ ((r >> 1) & 7)) << 3); }
 __device__ __forceinline__ int f64_v_off(int r, int c) { return r * 64 + ((c ^ (((r >> 1) & 1) << 2)) << 3); }
@@ -107,7 +97,7 @@ __device__ __forceinline__ void f64_step(f32x16 (&o)[2][2], f32x16 (&negm)[2], f
                                          const u16* nkst, const u16* nvst, const f64_dma& job, const float thr F64_TRACE_PARAMS) {
   // ---- phase 0: block maxima of the pending scores (vector), then the first half of the pending P.V (matrix)
   float mx[2] = {0.f, 0.f};
-  if (DO_SM && !(F64_ABL & 64)) {
+  if (DO_SM) {
 #pragma unroll
     for (int qb = 0; qb < 2; qb++) {
       float m = fmaxf(fmaxf(sx[qb][0], sx[qb][1]), sx[qb][2]);
@@ -133,7 +123,7 @@ __device__ __forceinline__ void f64_step(f32x16 (&o)[2][2], f32x16 (&negm)[2], f
   bool slow = false;
   float alpha[2] = {1.f, 1.f};
   bf16x4 vlo[4];
-  if (DO_SM && (FIRST || !(F64_ABL & 4))) {
+  if (DO_SM) {
     // a row's reference only ever tracks REAL keys: blocked scores (-32768 from the mask product) underflow to exactly 0
     // against any reference a real key can set, and a reference near -32768 would cost the scores 2^-8 of absolute precision.
     // A row that has accumulated nothing yet (l == 0) takes its reference from the first real score it meets, whatever its sign.
@@ -161,7 +151,7 @@ __device__ __forceinline__ void f64_step(f32x16 (&o)[2][2], f32x16 (&negm)[2], f
   // one exponential group (2 exp, 2 add, 1 pack).  Matrix order: S(st 0) x2, PV k=2 x2, S(st 1) x2, PV k=3 x2, S(st 2) x2,
   // S(st 3) x2, mask x2.
 #define F64_EXPG(G)                                                                                              \
-  if (DO_SM && !(F64_ABL & 16)) {                                                                                \
+  if (DO_SM) {                                                                                                   \
     constexpr int qb_ = (G) >> 3, i_ = (G) & 7;                                                                  \
     const float p0_ = __builtin_amdgcn_exp2f(sx[qb_][2 * i_]), p1_ = __builtin_amdgcn_exp2f(sx[qb_][2 * i_ + 1]); \
     l[qb_] += p0_; l[qb_] += p1_;                                                                                \
@@ -173,17 +163,17 @@ __device__ __forceinline__ void f64_step(f32x16 (&o)[2][2], f32x16 (&negm)[2], f
 #define F64_S(ST, QB)                                                                              \
   if (DO_S) { if ((ST) == 0) MFMA_INIT(snew[QB], cur.kf[ST], qf[QB][ST], negm[QB]); else MFMA_ACCV(snew[QB], cur.kf[ST], qf[QB][ST]); }
 #define F64_PV(K, QB) if (DO_PV) MFMA_ACCA(o[QB][(K) & 1], cur.vf[K], pold[QB][(K) >> 1]);
-#define F64_RK(ST) if (RD_K && !(F64_ABL & 2)) nxt.kf[ST] = *reinterpret_cast<const bf16x8*>(nkst + ln.kaddr[ST] + HN * 2048);
-#define F64_RH() if (RD_K && !(F64_ABL & 2)) nxt.hf = *reinterpret_cast<const bf16x8*>(nkst + 2 * TK * DH + ln.haddr + HN * 512);
+#define F64_RK(ST) if (RD_K) nxt.kf[ST] = *reinterpret_cast<const bf16x8*>(nkst + ln.kaddr[ST] + HN * 2048);
+#define F64_RH() if (RD_K) nxt.hf = *reinterpret_cast<const bf16x8*>(nkst + 2 * TK * DH + ln.haddr + HN * 512);
   // half T (keys 8 T .. of the 16-key step KS) of V^T fragment K = 2 KS + N: elements 4 T .. 4 T + 3
 #define F64_RV(K, T)                                                                                              \
-  if (RD_V && !(F64_ABL & 2)) {                                                                                   \
+  if (RD_V) {                                                                                                     \
     const bf16x4 v4_ = lds_read_tr16(nvst + TK * DH + ln.vaddr[(K) & 1] + (HN * 32 + 16 * ((K) >> 1) + 8 * (T)) * 64); \
     if ((T) == 0) vlo[K] = v4_; else nxt.vf[K] = __builtin_shufflevector(vlo[K], v4_, 0, 1, 2, 3, 4, 5, 6, 7);     \
   }
-#define F64_DK(I) if (DMA && !(F64_ABL & 1)) { if (job.on) F64_DMA16(job.kb, job.ko[I], job.lds + (unsigned)(I) * 4096u); }
-#define F64_DV(I) if (DMA && !(F64_ABL & 1)) { if (job.on) F64_DMA16(job.vb, job.vo[I], job.lds + 8192u + (unsigned)(I) * 4096u); }
-#define F64_DH() if (DMA && !(F64_ABL & 1)) { if (job.hot) F64_DMA16(job.hb, job.ho, job.lds + 16384u); }
+#define F64_DK(I) if (DMA) { if (job.on) F64_DMA16(job.kb, job.ko[I], job.lds + (unsigned)(I) * 4096u); }
+#define F64_DV(I) if (DMA) { if (job.on) F64_DMA16(job.vb, job.vo[I], job.lds + 8192u + (unsigned)(I) * 4096u); }
+#define F64_DH() if (DMA) { if (job.hot) F64_DMA16(job.hb, job.ho, job.lds + 16384u); }
   F64_S(0, 0) F64_RV(0, 0) F64_EXPG(0)
   F64_S(0, 1) F64_RV(0, 1) F64_DK(0) F64_EXPG(1)
   F64_PV(2, 0) F64_RV(1, 0) F64_EXPG(2)
@@ -205,8 +195,8 @@ __device__ __forceinline__ void f64_step(f32x16 (&o)[2][2], f32x16 (&negm)[2], f
   F64_EXPG(15)
   // the step's own fragments stay live up to here, so that no read of the NEXT step's fragments lands in a register an
   // in-flight matrix instruction still reads (the hardware holds such a read back behind the instruction)
-  if (DO_S && !(F64_ABL & 128)) asm volatile("" :: "a"(cur.kf[0]), "a"(cur.kf[1]), "a"(cur.kf[2]), "a"(cur.kf[3]), "a"(cur.hf));
-  if (DO_PV && !(F64_ABL & 128)) asm volatile("" :: "v"(cur.vf[0]), "v"(cur.vf[1]), "v"(cur.vf[2]), "v"(cur.vf[3]));
+  if (DO_S) asm volatile("" :: "a"(cur.kf[0]), "a"(cur.kf[1]), "a"(cur.kf[2]), "a"(cur.kf[3]), "a"(cur.hf));
+  if (DO_PV) asm volatile("" :: "v"(cur.vf[0]), "v"(cur.vf[1]), "v"(cur.vf[2]), "v"(cur.vf[3]));
 #undef F64_EXPG
 #undef F64_S
 #undef F64_PV
@@ -219,7 +209,7 @@ __device__ __forceinline__ void f64_step(f32x16 (&o)[2][2], f32x16 (&negm)[2], f
   // without exponential groups nothing separates the last S instruction from the next step's first reader of its result
   if (DO_S && !DO_SM) { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); F64_SB(); }
   // ---- slow path, second half: O joins the new reference maximum (the step's P.V is complete: pad for its last result)
-  if (DO_SM && !FIRST && !(F64_ABL & 4)) {
+  if (DO_SM && !FIRST) {
     if (__builtin_expect(slow, false)) {
       asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
       F64_SB();
@@ -394,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(mca_attn_fwd_args a,
       // even step: S_e = S(it, keys 0-31) | P_e(it-1, keys 0-31).V | exponentiate S_o(it-1, keys 32-63) -> P_o
       f64_step<true, true, true, false, 1, true, true, false>(o, negm, l, se, so, po, pe, qf, qbw, ln, fa, fb, kst, vst, nojob, thr F64_TRACE_ARGS);
       F64_STAMP();
-      if (it + 1 < n_live && !(F64_ABL & 8)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); F64_STAMP(); __builtin_amdgcn_s_barrier(); }
+      if (it + 1 < n_live) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); F64_STAMP(); __builtin_amdgcn_s_barrier(); }
       F64_STAMP();
       const f64_dma job = make_job((int)(e_next & 0x7fffffffu), (it + 2) & 3, it + 2 < n_live);
       e_next = it + 3 < n_live ? __builtin_amdgcn_readfirstlane(live_s[it + 3]) : 0u;

@@ -495,9 +495,14 @@ typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 template <int N> __device__ __forceinline__ void ps_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 #define NTPS_LDS_BYTES (3 * (BM2 + BN) * 64 * 2 + 16384)
 
-// timeline probe (knob 0 = 8): workgroup 0 / wave 0 writes s_memtime stamps, read back by tools/trace_persist.py
+// timeline probe (TRACE build only: mca-paper_amd/build.py --trace; knob 0 = 8): workgroup 0 / wave 0 writes s_memtime stamps,
+// read back by tools/trace_persist.py; the product build carries neither the stamps nor the clock probe of the grouped kernel
 MCA_TRACE_BUFFER(gemm)
+#ifdef MCA_TRACE_BUILD
 #define PS_STAMP() do { if (tracing && ti < 1024) mca_trace_gemm[ti++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PS_STAMP() do { } while (0)
+#endif
 
 // MODE 0: bf16 out;  1: fp32 out;  2: fp32 out + full-row fp32 residual;  3: fused GEGLU backward (bf16 out, see
 // mca_gemm_nt_geglu_bwd: C = dh, residual = h, ldres = row stride of both, N = ip);  4: fused GEGLU forward (see
@@ -1665,12 +1670,15 @@ __global__ __launch_bounds__(512) void gemm_tn_256x256_group_kernel(tn_group g, 
   const int tile_id = tile_all - g.first_tile[p];
   const int r_begin = split_id * g.rows_per_split;
   int r_end = r_begin + g.rows_per_split; if (r_end > g.R) r_end = g.R;
-  // clock probe (knob 9 bit 8): shader cycles and 100 MHz ticks of every workgroup's lifetime (tools/ablate_tn_group.py)
+#ifdef MCA_TRACE_BUILD          // clock probe (knob 9 bit 8): shader cycles and 100 MHz ticks of every workgroup's lifetime (tools/ablate_tn_group.py)
   const bool probe = (dbg & 8) && threadIdx.x == 0 && lin0 < 512;
   const uint64_t c0 = probe ? __builtin_amdgcn_s_memtime() : 0, t0 = probe ? __builtin_amdgcn_s_memrealtime() : 0;
+#endif
   tn_256x256_tile(g.A[p], g.lda[p], g.B[p], g.ldb[p], g.C[p], g.ldc[p], g.N[p], g.K[p], tile_id / g.tiles_k[p], tile_id % g.tiles_k[p],
                   r_begin, r_end, ldst);
+#ifdef MCA_TRACE_BUILD
   if (probe) { mca_trace_gemm[2 * lin0] = __builtin_amdgcn_s_memtime() - c0; mca_trace_gemm[2 * lin0 + 1] = __builtin_amdgcn_s_memrealtime() - t0; }
+#endif
 }
 
 extern "C" int mca_gemm_tn_acc(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,

@@ -7,11 +7,11 @@
 
 // Two launches, no atomics: every block leaves its partial sum in a fixed slot, one block adds the slots in index order.  The
 // sum is then the same bits on every launch (an atomicAdd per block made the clip coefficient, and with it the weights of
-// data-parallel replicas that hold identical gradients, differ in the last bit from rank to rank).  The slots are a
-// per-process device array: one norm in flight per process (the step has exactly one).
-#define SQN_BLOCKS 1024
-__device__ float mca_sqnorm_partials[SQN_BLOCKS];
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, int64_t n4, int64_t n) {
+// data-parallel replicas that hold identical gradients, differ in the last bit from rank to rank).  The slots are words
+// 1 .. MCA_SQNORM_WORDS - 1 of the CALLER's buffer (word 0 = the norm): the library keeps no state of its own, so two norms
+// on two streams, two engines in one process or a bench A/B cannot meet in a hidden array.
+#define SQN_BLOCKS (MCA_SQNORM_WORDS - 1)
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, int64_t n4, int64_t n, float* __restrict__ mca_sqnorm_partials) {
   __shared__ float red[4];
   float acc = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
   __syncthreads();
   if (threadIdx.x == 0) mca_sqnorm_partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-__global__ __launch_bounds__(64) void sqnorm_final_kernel(int blocks, float* __restrict__ out) {
+__global__ __launch_bounds__(64) void sqnorm_final_kernel(int blocks, float* __restrict__ out, const float* __restrict__ mca_sqnorm_partials) {
   float acc = 0.f;
   for (int i = threadIdx.x; i < blocks; i += 64) acc += mca_sqnorm_partials[i];          // lane l: slots l, l + 64, ... in order
   acc = wave_sum(acc);
@@ -36,8 +36,8 @@ extern "C" int mca_grad_sqnorm(const float* g, int64_t n, float* sqnorm, mca_str
   if ((uintptr_t)g % 16) return MCA_E_ALIGN;
   const int64_t n4 = n / 4;
   int64_t blocks = (n4 + 255) / 256; if (blocks > SQN_BLOCKS) blocks = SQN_BLOCKS; if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g, n4, n);
-  hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), (int)blocks, sqnorm);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g, n4, n, sqnorm + 1);
+  hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), (int)blocks, sqnorm, sqnorm + 1);
   return launch_status();
 }
 

@@ -105,6 +105,23 @@ def setup_data(dataset_path, split=0.1, ds_frac=1.0, ds_seed=42, model=3, predro
     return dataset
 
 
+def shard_eval_batches(n: int, batch_size: int, world: int, rank: int):
+    """Index batches of rank ``rank`` for an UNSHUFFLED loader over ``n`` samples prepared by Accelerate for ``world`` processes
+    (the reference's ``eval_dl`` through ``accelerator.prepare``, train_accel_gpu.py:71,93): Accelerate's ``BatchSamplerShard``
+    with its defaults (``split_batches=False, even_batches=True``, the loader's ``drop_last=False``) deals the sequential
+    batches round-robin - rank r takes batches r, r + W, ... - and completes the last round with samples from the START of
+    the dataset, so that every rank sees the same number of FULL batches (the contrastive labels need equal local batches,
+    utils/contrastive_loss_with_temperature.py:28-31).  Restated in closed form: the sequence 0 .. n-1 followed by the first
+    min(n, W * batch_size) indices cycled, cut into ceil(ceil(n / b) / W) * W batches of b.  Checked against
+    ``accelerate.data_loader.BatchSamplerShard`` itself in tests/test_aux_cpu.py."""
+    nb = -(-n // batch_size)
+    rounds = -(-nb // world)
+    total = rounds * world * batch_size
+    base = min(n, world * batch_size)
+    virt = list(range(n)) + [j % base for j in range(total - n)]
+    return [virt[(k * world + rank) * batch_size:(k * world + rank + 1) * batch_size] for k in range(rounds)]
+
+
 class DevicePrefetcher:
     """Host batches -> device batches, one batch AHEAD of the compute stream (the input pipeline of train_accel_gpu.py:70,111:
     the reference moves every batch with a synchronous ``move_to`` in the compute stream; at b = 32 that is 59 MB = 1.6 ms of
@@ -126,7 +143,7 @@ class DevicePrefetcher:
         self.copied = [torch.cuda.Event() for _ in range(depth)]
         self.released = [None] * depth                  # recorded on the compute stream when a set's consumer is done enqueueing
         self.slot = 0
-        self.in_use = None                              # slot handed out last
+        self.in_use = None                              # (slot handed out last, the stream it was handed out on)
         self.pending = None                             # (slot or None, batch) staged ahead
         self._stage()
 
@@ -139,6 +156,12 @@ class DevicePrefetcher:
         if isinstance(b, list):
             return tuple(DevicePrefetcher._shape_sig(v) for v in b)
         raise TypeError("Invalid type for move_to")
+
+    @staticmethod
+    def _has_device_tensor(b):
+        if torch.is_tensor(b):
+            return b.device.type != "cpu"
+        return any(DevicePrefetcher._has_device_tensor(v) for v in (b.values() if isinstance(b, dict) else b))
 
     def _alloc_like(self, b):
         if torch.is_tensor(b):
@@ -166,9 +189,12 @@ class DevicePrefetcher:
         sig = self._shape_sig(host)
         if self.sets[s] is None:
             self.sets[s] = (sig, self._alloc_like(host))
+            self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))          # allocated here, first written there
         if self.sets[s][0] != sig:                      # odd-shaped batch: no double buffering for it
             self.pending = (None, host)
             return
+        if self._has_device_tensor(host):               # a device-resident source (synthetic_batch(device='cuda')): its producer
+            self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))          # runs on the current stream
         with torch.cuda.stream(self.copy_stream):
             if self.released[s] is not None:
                 self.copy_stream.wait_event(self.released[s])
@@ -183,10 +209,11 @@ class DevicePrefetcher:
 
     def __next__(self):
         cur = torch.cuda.current_stream(self.device)
-        if self.in_use is not None:                     # the consumer is back: everything reading that set has been enqueued
+        if self.in_use is not None:                     # the consumer is back: everything reading that set has been enqueued ...
+            slot, handed_on = self.in_use               # ... on the stream the set was handed out on (which need not be `cur`)
             ev = torch.cuda.Event()
-            ev.record(cur)
-            self.released[self.in_use] = ev
+            ev.record(handed_on)
+            self.released[slot] = ev
             self.in_use = None
         if self.pending is None:
             raise StopIteration
@@ -195,7 +222,7 @@ class DevicePrefetcher:
             out = _to_device(batch, self.device)
         else:
             cur.wait_event(self.copied[s])
-            out, self.in_use = batch, s
+            out, self.in_use = batch, (s, cur)
         self._stage()
         return out
 

@@ -47,8 +47,9 @@ def debug_options() -> dict:
     none of them.  overlap_wgrad=0|1 (weight-gradient GEMMs on a side stream: default by size), group_wgrad=0 (one launch per
     weight gradient instead of one per layer), mask_mfma=0 (element-wise attention mask instead of the mask product),
     dkv_keys=256 (8-wavefront key blocks in the dK/dV pass), fwd64=1 (the round-4 query-block forward attention kernel,
-    attention_fwd64.hip, instead of the 128-row-tile one: correct, measured 24 % slower).  Kernel-level knobs: include/mca_hip_debug.h (hip.knobs)."""
-    opts = {"overlap_wgrad": None, "group_wgrad": True, "mask_mfma": True, "dkv_keys": 128, "fwd64": False}
+    attention_fwd64.hip, instead of the 128-row-tile one: correct, measured 24 % slower), lazy_softmax=1
+    (MCA_ATTN_LAZY_REFERENCE: the forward attention's softmax reference moves lazily, -9 % on that kernel).  Kernel-level knobs: include/mca_hip_debug.h (hip.knobs)."""
+    opts = {"overlap_wgrad": None, "group_wgrad": True, "mask_mfma": True, "dkv_keys": 128, "fwd64": False, "lazy_softmax": False}
     for item in filter(None, os.environ.get("MCA_DEBUG", "").split(",")):
         k, _, v = item.partition("=")
         k = k.strip()
@@ -109,6 +110,8 @@ class FusionEngine:
         self.attn_flags = hip.ATTN_Q_PRESCALED                  # (the kernels take pre-scaled q only)
         self.attn_dtype = "bf16"
         self.dbg = debug_options()                               # A/B switches: ONE environment variable, MCA_DEBUG
+        if self.dbg["lazy_softmax"]:
+            self.attn_flags |= hip.ATTN_LAZY_REFERENCE
         self.nk_pad = _pad_to(self.N, 256)
         # the attention mask as a matrix product (mca_build_keyhot): needs every key group id <= 14
         self.mask_mfma = int(self.st.kgroup.max()) <= 14 and self.dbg["mask_mfma"]

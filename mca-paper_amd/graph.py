@@ -66,9 +66,9 @@ class GraphedStep:
         eng.finite_flag.zero_(); eng._flag_host.zero_(); eng._flag_event = None
 
     def _capture_segments(self):
-        """The data-parallel step as [graph, collective, graph, collective, ...] (module docstring).  The collectives also run
-        while capturing (on whatever the buffers hold: captured kernels do not execute), so every rank goes through the same
-        sequence of collective calls as in a replay."""
+        """The data-parallel step as [graph, collective, graph, collective, ...] (module docstring).  Capturing issues NO
+        collective: a capture that fails on one rank raises there with nothing in flight, and the caller can agree on a common
+        path (bench.py) or exit non-zero (train_accel_gpu.py)."""
         import gc
         torch.cuda.synchronize(); gc.collect(); torch.cuda.empty_cache()          # as torch.cuda.graph() does before a capture
         pool = torch.cuda.graph_pool_handle()
@@ -86,8 +86,9 @@ class GraphedStep:
             self.program.append(state["g"])
 
         def cut(fn):
+            # the collective is only RECORDED here: while capturing, the buffers hold nothing (captured kernels do not run), and
+            # a rank whose capture fails must not leave the others inside a half-issued sequence of collectives
             end()
-            fn()
             self.program.append(fn)
             begin()
 

@@ -69,6 +69,7 @@ class AttnFwdArgs(C.Structure):
 
 
 ATTN_Q_PRESCALED = 1
+ATTN_LAZY_REFERENCE = 2          # mca_attn_fwd: lazy softmax reference (include/mca_hip.h)
 
 
 class AttnFp8Operands(C.Structure):

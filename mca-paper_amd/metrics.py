@@ -21,6 +21,18 @@ def lunif(x: torch.Tensor, t: float = 2, norm: bool = True) -> torch.Tensor:
     return torch.pdist(x, p=2).pow(2).mul(-t).exp().mean().log()
 
 
+def _gather_cat(parts: List[torch.Tensor], group=None) -> torch.Tensor:
+    """this rank's accumulated rows, then every other rank's, rank-major: what torchmetrics does for a list state with
+    ``dist_reduce_fx="cat"`` when ``compute()`` synchronises (utils/metrics.py:40-41,60)"""
+    import torch.distributed as dist
+    local = torch.cat(parts) if parts else torch.zeros(0)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, local, group=group)
+    return torch.cat([o for o in out if o.numel()])
+
+
 class Alignment:
     def __init__(self, alpha: float = 2):
         self.alpha = alpha
@@ -33,7 +45,10 @@ class Alignment:
         self.preds.append(preds.detach().float().cpu())
         self.target.append(target.detach().float().cpu())
 
-    def compute(self, norm: bool = False) -> torch.Tensor:
+    def compute(self, norm: bool = False, sync: bool = False, group=None) -> torch.Tensor:
+        """sync: gather every rank's rows first (a collective: every rank must call it), as the reference's torchmetrics do"""
+        if sync:
+            return lalign(_gather_cat(self.preds, group), _gather_cat(self.target, group), self.alpha, norm)
         return lalign(torch.cat(self.preds), torch.cat(self.target), self.alpha, norm)
 
     def reset(self):
@@ -48,7 +63,9 @@ class Uniformity:
     def update(self, preds: torch.Tensor):
         self.preds.append(preds.detach().float().cpu())
 
-    def compute(self, norm: bool = False) -> torch.Tensor:
+    def compute(self, norm: bool = False, sync: bool = False, group=None) -> torch.Tensor:
+        if sync:
+            return lunif(_gather_cat(self.preds, group), self.t, norm)
         return lunif(torch.cat(self.preds), self.t, norm)
 
     def reset(self):

@@ -14,16 +14,18 @@ import torch
 
 from .hip import call, ptr, stream_ptr
 
+SQNORM_WORDS = 1025          # include/mca_hip.h MCA_SQNORM_WORDS: the norm + the caller-owned scratch of mca_grad_sqnorm
+
 
 def clip_grad_norm_(model, max_norm: float) -> torch.Tensor:
     """Records the clipping request and returns the total gradient L2 norm (device tensor, no sync).  The
     scaling itself is applied inside the next ``FusedAdamW.step()`` (gradients in memory stay unscaled)."""
     eng = model.engine
-    sq = eng._ws.setdefault("sqnorm", torch.zeros(1, dtype=torch.float32, device=eng.device))
-    sq.zero_()
+    sq = eng._ws.setdefault("sqnorm", torch.zeros(SQNORM_WORDS, dtype=torch.float32, device=eng.device))          # word 0 + scratch
+    sq[:1].zero_()
     call("mca_grad_sqnorm", ptr(eng.gflat), eng.n_params, ptr(sq), stream_ptr())
     eng._pending_clip = float(max_norm)
-    return sq.sqrt().reshape(())
+    return sq[0].sqrt().reshape(())
 
 
 class FusedAdamW(torch.optim.Optimizer):

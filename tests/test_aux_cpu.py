@@ -43,6 +43,25 @@ def test_metrics_match_formulas(pkg):
     assert al.preds == [] and un.preds == []
 
 
+def test_eval_sharding_is_accelerates(pkg):
+    """data.shard_eval_batches (the DP eval loader of train_accel_gpu.py) against accelerate.data_loader.BatchSamplerShard with the
+    defaults accelerator.prepare uses (split_batches=False, even_batches=True) over a sequential, drop_last=False loader"""
+    import pytest
+    acc = pytest.importorskip("accelerate.data_loader")
+    from torch.utils.data import BatchSampler, SequentialSampler
+    for n in (1, 5, 7, 8, 9, 16, 17, 31, 33, 100):
+        for b in (1, 2, 4, 8):
+            for W in (1, 2, 3, 4, 8):
+                per_rank = []
+                for r in range(W):
+                    want = list(acc.BatchSamplerShard(BatchSampler(SequentialSampler(range(n)), b, False), W, r))
+                    got = pkg.data.shard_eval_batches(n, b, W, r)
+                    assert got == want, (n, b, W, r)
+                    per_rank.append(got)
+                assert len({len(x) for x in per_rank}) == 1 and all(len(bt) == b for x in per_rank for bt in x)          # equal, full local batches
+                assert set(range(n)) <= {i for x in per_rank for bt in x for i in bt}
+
+
 def test_predrop_semantics(pkg):
     torch.manual_seed(0)
     apply = pkg.data.batch_predrop({"a": {"dropout": 1.0, "pad_token": -10000}, "b": {"dropout": 0.0}, "c": {}})

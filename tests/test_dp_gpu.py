@@ -58,21 +58,31 @@ def test_dp2_native_matches_oracle_objective(tmp_path):
     for p in params.values():
         p.requires_grad_(True)
     full = P.data.synthetic_batch(cfg, b * W, seed=21, p_drop=0.3)
-    Pr = O.Prec("fp32")
-    tokens, padding, sample_mask = O.encode_and_pack(S, sd, full, Pr)
-    pooled = O.mca_trunk(S, sd, tokens, padding, Pr)
-    tot, loss0 = 0, None
-    for r in range(W):
-        sm = {n: sample_mask[n][r * b:(r + 1) * b] for n in names}
-        l = O.pretraining_loss(S, pooled[r * b:(r + 1) * b], sm, sd["loss.loss_fn.logit_scale"], pooled_all=pooled, rank=r)["loss"]
-        loss0 = l if r == 0 else loss0
-        tot = tot + l
-    (tot / W).backward()
-    assert abs(got["loss"] - float(loss0)) < 0.03 * abs(float(loss0)) + 0.05
+    def dp_objective(mode):
+        """gradient of (1 / W) sum_r loss_r on the concatenated batch, in the oracle's precision mode `mode`"""
+        for p in params.values():
+            p.grad = None
+        Pr = O.Prec(mode)
+        tokens, padding, sample_mask = O.encode_and_pack(S, sd, full, Pr)
+        pooled = O.mca_trunk(S, sd, tokens, padding, Pr)
+        tot, loss0 = 0, None
+        for r in range(W):
+            sm = {n: sample_mask[n][r * b:(r + 1) * b] for n in names}
+            l = O.pretraining_loss(S, pooled[r * b:(r + 1) * b], sm, sd["loss.loss_fn.logit_scale"], pooled_all=pooled, rank=r)["loss"]
+            loss0 = l if r == 0 else loss0
+            tot = tot + l
+        (tot / W).backward()
+        return float(loss0), {n: p.grad.detach().clone() for n, p in params.items() if p.grad is not None}
+    loss_emu, g_emu = dp_objective("bf16emu")
+    loss0, g_ref = dp_objective("fp32")
+    assert abs(got["loss"] - loss0) < 0.03 * abs(loss0) + 0.05
+    # the single-GPU bound (tests/test_step_gpu.py): no worse than bf16 arithmetic itself, i.e. within a few x the distance of
+    # the bf16-EMULATING oracle from the fp32 one, per tensor; median 3 %  (round 3 asserted a blanket 25 % / 5 %)
     errs = []
-    for n, p in params.items():
-        if p.grad is None or p.grad.abs().max() == 0:
+    for n, gref in g_ref.items():
+        if gref.abs().max() == 0:
             continue
-        errs.append((rel_err(got["grads"][n], p.grad), n))
-    worst = max(errs)
-    assert worst[0] < 0.25 and sorted(e for e, _ in errs)[len(errs) // 2] < 0.05, (worst, sorted(e for e, _ in errs)[len(errs) // 2])
+        e, e_emu = rel_err(got["grads"][n], gref), rel_err(g_emu[n], gref)
+        assert e < 4 * e_emu + 2e-2, (n, e, e_emu)
+        errs.append((e, n))
+    assert sorted(e for e, _ in errs)[len(errs) // 2] < 0.03, (max(errs), sorted(e for e, _ in errs)[len(errs) // 2])

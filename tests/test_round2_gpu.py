@@ -296,16 +296,51 @@ def test_long_config_at_batch_128(P):
     print("long config: fp8 vs bf16 pooled rel-L2", e8, "loss", float(l8), float(l1))
     assert torch.isfinite(p8).all() and e8 < 1e-2 and abs(float(l8) - float(l1)) <= 2e-2 * abs(float(l1))
     out = model(batch)
-    opt.zero_grad(); out["loss"].backward(); optim.clip_grad_norm_(model, 2.0); opt.step()
+    opt.zero_grad(); out["loss"].backward()
     torch.cuda.synchronize()
     assert torch.isfinite(out["loss"])
     for n, p in model.named_parameters():
         assert torch.isfinite(p.grad).all(), n
         if n != "return_tokens":
             assert float(p.grad.abs().max()) > 0, n
+    g16 = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    del out
+    # ---- configs[4] names fp8 attention: the TRAINING step in fp8 at this size (the three fp8 backward kernels and the backward
+    # quantisation at b = 128: every row offset of their operands is beyond 2^31 bytes).  Stated tolerances against the bf16
+    # step on the same weights and batch: gradient norm within 3 %, every tensor within 30 %, median within 5 % (e4m3 operands
+    # in S and dP of five layers; measured: norm 0.13 %, median 2.4 %, worst 22 % on layers.0.attn.to_q.weight, the tensor the
+    # noise of all five layers reaches); two fp8 steps give the same dq | dk | dv bits in the layer the backward reaches first
+    eng.set_attention_dtype("fp8")
+    ws = eng.workspace(b)
+    assert eng.fp8_backward_on(ws, eng.N)
+    runs = []
+    for rep in range(2):
+        o8 = model(batch)
+        opt.zero_grad(); o8["loss"].backward()
+        torch.cuda.synchronize()
+        runs.append(ws["layers"][eng.L - 1]["dqkv"].clone())
+        assert abs(float(o8["loss"]) - float(l8)) <= 1e-5 * abs(float(l8))          # the fp8 forward of above, again
+        del o8
+    assert torch.equal(runs[0], runs[1]), "fp8 attention backward at b = 128 is not bitwise repeatable"
+    del runs
+    errs = []
+    for n, p in model.named_parameters():
+        assert torch.isfinite(p.grad).all(), n
+        if float(g16[n].abs().max()) == 0:
+            continue
+        errs.append((rel_err(p.grad, g16[n]), n))
+    n16 = float(torch.sqrt(sum((g.double() ** 2).sum() for g in g16.values())))
+    n8 = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters())))
+    worst, med = max(errs), sorted(e for e, _ in errs)[len(errs) // 2]
+    print("long config: fp8 vs bf16 training step: gradient norm", n8, n16, "worst tensor", worst, "median", med)
+    assert abs(n8 - n16) <= 3e-2 * n16 and worst[0] < 0.30 and med < 0.05, (n8, n16, worst, med)
+    del g16
+    optim.clip_grad_norm_(model, 2.0); opt.step()          # the optimizer step on the fp8 gradients
+    torch.cuda.synchronize()
+    model.engine.assert_finite() if eng.check_finite == "deferred" else None
+    eng.set_attention_dtype("bf16")
     # the same first two samples alone: identical pooled rows (nothing mixes samples before the loss)
     pb = p1.view(b, R, -1)[:2].clone()
-    del out
     small = {k: {kk: vv[:2].contiguous() for kk, vv in v.items()} for k, v in batch.items()}
     torch.manual_seed(43)
     m2 = P.MCA(**P.config.cmu_model_config(batch_size=2, long_seq=True)).cuda()

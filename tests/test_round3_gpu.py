@@ -68,6 +68,15 @@ def test_train_script_real_data_with_eval_loop(P, tmp_path):
     evals = [rec for rec in recs if "val_epoch_total_loss" in rec]
     steps = [rec for rec in recs if "step" in rec]
     assert [e["epoch"] for e in evals] == [0, 1] and steps[-1]["step"] == 2 * (18 // 4)          # 18 train samples, drop_last
+    # the reference logs EVERY step (train_accel_gpu.py:126-130): total_loss, the loss terms, param_norm, grad_norm, lr ...
+    assert [rec["step"] for rec in steps] == list(range(1, 9))
+    for rec in steps:
+        assert rec["param_norm"] > 0 and rec["lr"] >= 0 and 0 < rec["grad_norm"] <= rec["grad_norm_unclipped"] + 1e-6
+        assert rec["grad_norm"] <= 2.0 * (1 + 1e-5)          # read after clip_grad_norm_(2.0) in the reference: the clipped norm
+    # ... and every eval batch (:163-164): two batches per epoch here
+    vsteps = [rec for rec in recs if "val_step_total_loss" in rec]
+    assert [v["epoch"] for v in vsteps] == [0, 0, 1, 1] and all(any(k.startswith("val_step_") and k != "val_step_total_loss" for k in v) for v in vsteps)
+    assert abs(sum(v["val_step_total_loss"] for v in vsteps[2:]) / 2 - evals[-1]["val_epoch_total_loss"]) < 1e-4 * abs(evals[-1]["val_epoch_total_loss"])
     got = evals[-1]
     # ---- the same eval split, rebuilt the way the script built it (same seeds -> same predrop draws and split)
     torch.manual_seed(11)
@@ -117,6 +126,90 @@ def test_train_script_real_data_with_eval_loop(P, tmp_path):
     sb = torch.load(out / "1" / "scheduler.bin", weights_only=True)
     assert sb["last_epoch"] == 8 and abs(ob["param_groups"][0]["lr"] - sb["_last_lr"][0]) < 1e-12
     assert ob["param_groups"][0]["lr"] <= steps[-1]["lr"]          # cosine decay after the 2-step warm-up
+
+
+def test_train_script_eval_loop_under_data_parallelism(P, tmp_path):
+    """The evaluation loop with TWO ranks (gloo, both on this GPU; RCCL on a node): the reference's prepared eval loader is
+    sharded (train_accel_gpu.py:71,93 -> Accelerate's BatchSamplerShard: batches dealt round-robin, the last round completed from
+    the start of the set), every forward all-gathers the embeddings, rank 0 logs ITS losses, the torchmetrics states gather every
+    rank's rows.  Rank 0's logged val_epoch_* must equal the oracle's global-batch objective of rank 0's rows on those very
+    batches + the metric formulas over both ranks' rows (until round 3 every rank evaluated the whole set and the all-gather
+    gave each sample W - 1 duplicates as negatives: +ln W on every term)."""
+    import yaml
+    from oracle import mca_oracle as O
+    cfg = small_config("mca")
+    ds_path = str(tmp_path / "ds")
+    _ragged_dataset(ds_path, cfg, n=28)
+    mod_cfg = {name: {"type": "embedded_sequence", "pad_len": enc["max_tokens"], "embedding_size": enc["input_size"], "data_col_name": "data",
+                      "dropout": 0.0} for name, enc in cfg["encoder_configs"].items()}
+    out = tmp_path / "out"
+    y = dict(encoder_configs=cfg["encoder_configs"], modality_config=mod_cfg, hidden_size=cfg["dim"], layers=cfg["depth"], heads=cfg["heads"],
+             dim_head=cfg["dim_head"], num_fusion_tokens=cfg["num_fusion_tokens"], batch_size=2, fcl=cfg["fcl"], fcl_root=cfg["fcl_root"],
+             bimodal_contrastive=cfg["bimodal_contrastive"], non_fusion_fcl=cfg["non_fusion_fcl"], fusion_combos=cfg["fusion_combos"],
+             zorro=cfg["zorro"], eao=False, no_fusion=False, mean_pool=False, predrop=False, epochs=1, lr=1e-3, lr_scheduler_type="cosine",
+             num_warmup_steps=2, clip=2.0, seed=11, output_dir=str(out), dataset=ds_path, split=0.25, ds_seed=42, run_eval_loop=True)
+    ypath = tmp_path / "train.yaml"
+    ypath.write_text(yaml.safe_dump(y, sort_keys=False))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MCA_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "train_accel_gpu.py"), str(ypath)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    recs = [json.loads(l) for l in open(out / "log.jsonl")]
+    got = [rec for rec in recs if "val_epoch_total_loss" in rec][-1]
+    # ---- the same eval set dealt the same way: 7 test samples, batch 2 -> 4 batches -> 2 rounds; the last round's second
+    # batch is [6, 0]: completed from the start
+    torch.manual_seed(11)
+    ds = P.data.setup_data(ds_path, split=0.25, ds_frac=1.0, ds_seed=42, predrop=False, predrop_config=mod_cfg)
+    n_test = len(ds["test"])
+    shards = [P.data.shard_eval_batches(n_test, 2, 2, r) for r in range(2)]
+    assert n_test == 7 and shards[0] == [[0, 1], [4, 5]] and shards[1] == [[2, 3], [6, 0]]
+    collate = P.MultimodalCollator(mod_cfg)
+    sd = {k: (v.float() if v.is_floating_point() else v) for k, v in P.checkpoint._read(str(out)).items()}
+    S = O.Structure(copy.deepcopy(cfg))
+    names = S.modalities
+    Pr = O.Prec("fp32")
+    rows = {r: {k: [] for k in names + ["fusion"]} for r in range(2)}
+    pairs = {r: {k: ([], []) for k in names} for r in range(2)}
+    sums, logit_mag = {}, 0.0
+    for k_round in range(2):
+        batch = collate([ds["test"][i] for r in range(2) for i in shards[r][k_round]])          # rank-major global batch
+        tokens, padding, sample_mask = O.encode_and_pack(S, sd, batch, Pr)
+        pooled = O.mca_trunk(S, sd, tokens, padding, Pr)
+        pd = pooled.double()
+        logit_mag = max(logit_mag, float(torch.exp(sd["loss.loss_fn.logit_scale"].double())) *
+                        max(float((pd[:, i] @ pd[:, j].t()).abs().max()) for i in range(pd.shape[1]) for j in range(pd.shape[1])))
+        for r in range(2):
+            sm = {n: sample_mask[n][2 * r:2 * r + 2] for n in names}
+            o = O.pretraining_loss(S, pooled[2 * r:2 * r + 2], sm, sd["loss.loss_fn.logit_scale"], pooled_all=pooled, rank=r)
+            if r == 0:          # the main process logs its own losses
+                sums["total_loss"] = sums.get("total_loss", 0.0) + float(o["loss"])
+                for kk, v in o["losses"].items():
+                    sums[kk] = sums.get(kk, 0.0) + float(v)
+            for n in names:
+                rows[r][n].append(o[n][sm[n]]); pairs[r][n][0].append(o[n][sm[n]]); pairs[r][n][1].append(o["fusion"][sm[n]])
+            rows[r]["fusion"].append(o["fusion"])
+    want = {f"val_epoch_{k}": v / 2 for k, v in sums.items() if "|" not in k}
+    cat = lambda parts: torch.cat([torch.cat(parts[r]) for r in range(2)])          # rank 0's rows, then rank 1's
+    for tag, norm in (("", False), ("norm_", True)):
+        for k in names + ["fusion"]:
+            want[f"val_epoch_{tag}uniformity_{k}"] = float(P.metrics.lunif(cat({r: rows[r][k] for r in range(2)}), 2, norm))
+        for k in names:
+            want[f"val_epoch_{tag}alignment_{k}"] = float(P.metrics.lalign(cat({r: pairs[r][k][0] for r in range(2)}), cat({r: pairs[r][k][1] for r in range(2)}), 2, norm))
+    for k, w in want.items():
+        assert k in got, k
+        if w != w:
+            assert got[k] != got[k], k
+            continue
+        tol = 1e-2 * abs(w) + 1e-3
+        if "uniformity" not in k and "alignment" not in k:
+            tol = max(tol, 1e-4 * logit_mag)
+        assert abs(got[k] - w) <= tol, (k, got[k], w, tol)
+    # what the unsharded loop of round 3 would have logged is far outside that tolerance: every term carried ~ln 2 more
+    assert want["val_epoch_total_loss"] == want["val_epoch_total_loss"]
 
 
 # ------------------------------------------------------------------------------------------------ input pipeline

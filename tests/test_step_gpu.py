@@ -289,6 +289,12 @@ def test_small_step_fp8_attention_vs_fp8emu_oracle(P, variant):
     errs.sort()
     print("fp8 step", variant, "grad errs median", errs[len(errs) // 2], "max", errs[-1])
     assert errs[-1][0] <= 0.08 and errs[len(errs) // 2][0] <= 0.03, (errs[-1], errs[len(errs) // 2])
+    # ... and against the EXACT (fp32 oracle) gradients, so that a systematic loss of gradient quality from e4m3 dO / V cannot
+    # hide behind an emulation that restates it: STATED TOLERANCE per tensor 0.15, median 0.06 (the bf16 step's own
+    # distance from fp32 at this size: worst tensor a few %; measured values printed)
+    errs32 = sorted((rel_err(p.grad.cpu(), ref["grads"][n]), n) for n, p in model.named_parameters() if ref["grads"][n].abs().max() > 0)
+    print("fp8 step", variant, "grad errs vs fp32 oracle: median", errs32[len(errs32) // 2], "max", errs32[-1])
+    assert errs32[-1][0] <= 0.15 and errs32[len(errs32) // 2][0] <= 0.06, (errs32[-1], errs32[len(errs32) // 2])
     assert model.engine.fp8_backward_on(model.engine.workspace(6), model.engine.N)          # the fp8 backward really ran
 
 

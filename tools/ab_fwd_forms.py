@@ -1,6 +1,7 @@
-"""Interleaved A/B (one process, one box) of the forward attention kernels on the CMU structure: the query-block kernel (round 4:
-256-row blocks cut along the structure, one wavefront per SIMD, 64 rows each, lazy softmax reference; production) against the
-128-row-tile LDS-DMA kernel (knob 13 = 2) and the register-staged one (knob 13 = 1).  usage: ab_fwd_forms.py"""
+"""Interleaved A/B (one process, one box) of the forward attention kernels on the CMU structure: the 128-row-tile LDS-DMA kernel
+with the lazy softmax reference (MCA_ATTN_LAZY_REFERENCE), the same kernel with the textbook recurrence (production), the
+query-block kernel (round 4: 256-row blocks, one wavefront per SIMD, 64 rows each; knob 13 = 3 + the block schedule) and the
+register-staged one (knob 13 = 1).  usage: ab_fwd_forms.py"""
 import importlib, os, sys
 os.environ.setdefault("MCA_DEBUG", "fwd64=1")          # the engine offers the query-block schedule only when asked
 import torch
@@ -22,7 +23,7 @@ def setup(b, pad):
     H.call("mca_build_keyhot", ws["keyinfo"].data_ptr(), ws["khot"].data_ptr(), b, eng.nk_pad, H.stream_ptr())
     a = ws["layers"][0]
     a["qkv"].copy_(torch.randn(b * N, 3 * D, device="cuda").bfloat16()); a["qkv"][:, :D] *= 0.18
-    return lambda: eng._attn_fwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], a["lse"], eng.qmask_attn, eng.sched_attn_f, ws, b, N)
+    return eng, (lambda: eng._attn_fwd(a["qkv"].data_ptr(), N*3*D, 3*D, a["qkv"], D, 2*D, 3*D, a["o"], a["lse"], eng.qmask_attn, eng.sched_attn_f, ws, b, N))
 def t(fn, n=20):
     for _ in range(3): fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,11 +32,15 @@ def t(fn, n=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
 for b, pad in ((32, 0), (32, 1), (16, 0), (8, 0), (8, 1), (4, 0)):
-    fn = setup(b, pad)
-    r = {0: [], 1: [], 2: []}
+    eng, fn = setup(b, pad)
+    bs = eng.bsched_attn
+    r = {0: [], 1: [], 2: [], 3: []}
     for rnd in range(4):
-        for k in (0, 2, 1):
-            with H.knobs(k13=k):
+        for k in (0, 2, 3, 1):
+            eng.bsched_attn = bs if k == 3 else None          # the block schedule selects the query-block kernel
+            eng.attn_flags = H.ATTN_Q_PRESCALED | (H.ATTN_LAZY_REFERENCE if k == 0 else 0)
+            with H.knobs(k13=0 if k == 2 else k):
                 r[k].append(t(fn))
-    print(f"b={b} pad={pad}: query-block {min(r[0]):.1f} us   128-row lds-dma {min(r[2]):.1f} us   register-staged {min(r[1]):.1f} us   "
-          f"ratio {min(r[0]) / min(r[2]):.3f}", flush=True)
+    eng.bsched_attn = bs
+    print(f"b={b} pad={pad}: lazy reference {min(r[0]):.1f} us   textbook recurrence {min(r[2]):.1f} us   query-block {min(r[3]):.1f} us   "
+          f"register-staged {min(r[1]):.1f} us   lazy / textbook {min(r[0]) / min(r[2]):.3f}", flush=True)

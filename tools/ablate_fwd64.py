@@ -1,6 +1,8 @@
-"""Timing-only ablations of the query-block forward attention kernel (attention_fwd64.hip, -DF64_ABL=bits: results are wrong, only
-the launch time matters): which part of a tile's ~3,600 cycles is what.  Builds every variant library first (run here, where
-hipcc is), then times each in its own process on the GPU box.  usage: ablate_fwd64.py build | run"""
+"""Timing-only ablations of the query-block forward attention kernel (attention_fwd64.hip; results are wrong, only the launch time
+matters): which part of a tile's ~3,600 cycles is what.  The ablation switches are NOT in the product source: the overlay
+tools/overlays/attention_fwd64_abl.patch adds them (-DF64_ABL=bits) to a copy in the variant's build directory.  Builds every
+variant library first (run here, where hipcc is), then times each in its own process on the GPU box.
+usage: ablate_fwd64.py build | run"""
 import importlib, os, subprocess, sys
 os.environ.setdefault("MCA_DEBUG", "fwd64=1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +15,8 @@ if sys.argv[1] == "build":
     B = importlib.import_module("mca-paper_amd.build")
     B.build()
     for bits in VARIANTS:
-        B.build_variant(lib(bits), defines=[f"F64_ABL={bits}"], only=["attention_fwd64.hip"])
+        B.build_variant(lib(bits), defines=[f"F64_ABL={bits}"], only=["attention_fwd64.hip"],
+                        overlays={"attention_fwd64.hip": os.path.join(ROOT, "tools", "overlays", "attention_fwd64_abl.patch")})
         print("built", lib(bits))
 elif sys.argv[1] == "run":
     for bits, nm in VARIANTS.items():

@@ -1,0 +1,152 @@
+"""The replayed b = 32 CMU step under a monitor: per-100-step time beside the GPU's clocks / power / temperatures sampled every
+100 ms from sysfs (amdgpu hwmon + pp_dpm_*), to name what the 13-20 % "slow regime" of rounds 2-3 is.
+
+usage: soak_monitor.py --seconds 60 --tag fresh [--batch 32] [--workers 0]
+  --workers N: N busy host processes beside the loop (stand-ins for DataLoader workers: a collator-like numpy loop each)
+Writes gpurun_out/soak_<tag>.json: the step-time series, the sampled series, and a summary (median / p95 ms per step, sclk /
+power / temperature ranges, which sysfs files existed).  Run phases as SEPARATE processes from one shell line, e.g.
+  python tools/soak_monitor.py --tag fresh && rocprofv3 --pmc SQ_WAVES -d gpurun_out/pmc_tmp -- python3 bench.py --steps 20 \
+      --no-cpu-baseline && python tools/soak_monitor.py --tag after_pmc
+"""
+import argparse, glob, importlib, json, multiprocessing as mp, os, statistics as st, sys, threading, time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def find_sources():
+    """the sysfs files of the GPU torch uses (card with an amdgpu hwmon): {name: path}"""
+    src = {}
+    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+        dev = os.path.join(card, "device")
+        hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
+        if not hw or not os.path.exists(os.path.join(dev, "pp_dpm_sclk")):
+            continue
+        h = hw[0]
+        cand = {"sclk_levels": os.path.join(dev, "pp_dpm_sclk"), "mclk_levels": os.path.join(dev, "pp_dpm_mclk"),
+                "fclk_levels": os.path.join(dev, "pp_dpm_fclk"), "perf_level": os.path.join(dev, "power_dpm_force_performance_level"),
+                "busy": os.path.join(dev, "gpu_busy_percent"), "power_avg_uW": os.path.join(h, "power1_average"),
+                "power_in_uW": os.path.join(h, "power1_input"), "power_cap_uW": os.path.join(h, "power1_cap"),
+                "sclk_hz": os.path.join(h, "freq1_input"), "mclk_hz": os.path.join(h, "freq2_input")}
+        for t in sorted(glob.glob(os.path.join(h, "temp*_input"))):
+            lab = t.replace("_input", "_label")
+            name = open(lab).read().strip() if os.path.exists(lab) else os.path.basename(t)
+            cand["temp_" + name + "_mC"] = t
+        src = {k: v for k, v in cand.items() if os.path.exists(v)}
+        src["_card"] = card
+        break
+    return src
+
+
+def read(path):
+    try:
+        return open(path).read().strip()
+    except OSError:
+        return None
+
+
+def cur_level(txt):
+    """'0: 132Mhz\\n1: 2100Mhz *' -> 2100 (the starred level), None if unreadable"""
+    if not txt:
+        return None
+    for line in txt.splitlines():
+        if line.rstrip().endswith("*"):
+            digits = "".join(ch for ch in line.split(":", 1)[1] if ch.isdigit())
+            return int(digits) if digits else None
+    return None
+
+
+def sampler(src, stop, out, period=0.1):
+    t0 = time.perf_counter()
+    while not stop.is_set():
+        row = {"t": round(time.perf_counter() - t0, 3)}
+        for k, p in src.items():
+            if k.startswith("_"):
+                continue
+            v = read(p)
+            if k.endswith("_levels"):
+                row[k[:-7] + "_mhz"] = cur_level(v)
+            elif k == "perf_level":
+                row[k] = v
+            else:
+                try:
+                    row[k] = int(v)
+                except (TypeError, ValueError):
+                    row[k] = None
+        out.append(row)
+        time.sleep(period)
+
+
+def busy_worker(stop):
+    import numpy as np
+    rng = np.random.default_rng(os.getpid())
+    while not stop.is_set():
+        a = rng.standard_normal((1500, 74)).astype("float32")
+        np.pad(a, ((0, 0), (0, 54))).sum()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60)
+    ap.add_argument("--tag", default="run")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--workers", type=int, default=0)
+    ap.add_argument("--eager", action="store_true")
+    args = ap.parse_args()
+    import torch
+    P = importlib.import_module("mca-paper_amd"); optim = importlib.import_module("mca-paper_amd.optim"); graph = importlib.import_module("mca-paper_amd.graph")
+    src = find_sources()
+    samples, stop = [], threading.Event()
+    th = threading.Thread(target=sampler, args=(src, stop, samples), daemon=True)
+    th.start()
+    wstop = mp.Event()
+    workers = [mp.Process(target=busy_worker, args=(wstop,), daemon=True) for _ in range(args.workers)]
+    for w in workers:
+        w.start()
+    cfg = P.config.cmu_model_config(batch_size=args.batch)
+    torch.manual_seed(43)
+    model = P.build_model(cfg).cuda(); model.engine.check_finite = "deferred"
+    opt = optim.FusedAdamW(model, lr=1e-4)
+    batch = P.data.synthetic_batch(cfg, args.batch, seed=1234, device="cuda")
+    t_setup = time.perf_counter()
+    g = None if args.eager else graph.GraphedStep(model, opt, batch, clip=2.0)
+
+    def step():
+        if g is not None:
+            return g.step()
+        out = model(batch); opt.zero_grad(); out["loss"].backward(); optim.clip_grad_norm_(model, 2.0); opt.step()
+        model.engine.poll_finite()
+        return out["loss"]
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    series, t0 = [], time.perf_counter()
+    while time.perf_counter() - t0 < args.seconds:
+        ta = time.perf_counter()
+        for _ in range(100):
+            step()
+        torch.cuda.synchronize()
+        series.append({"t": round(time.perf_counter() - t0, 2), "ms_per_step": round((time.perf_counter() - ta) * 10, 4)})
+    stop.set(); wstop.set(); th.join(timeout=2)
+    ms = [r["ms_per_step"] for r in series]
+
+    def rng(key, scale=1.0):
+        v = [s[key] * scale for s in samples if s.get(key) is not None]
+        return {"min": round(min(v), 1), "median": round(st.median(v), 1), "max": round(max(v), 1), "n": len(v)} if v else None
+    summary = {"tag": args.tag, "batch": args.batch, "mode": "eager" if args.eager else "hipGraph replay", "host_workers": args.workers,
+               "steps": 100 * len(series), "ms_per_step": {"first": ms[0], "median": round(st.median(ms), 4), "min": min(ms), "max": max(ms),
+                                                             "p95": sorted(ms)[int(0.95 * (len(ms) - 1))], "last": ms[-1]},
+               "samples_per_s_median": round(args.batch / st.median(ms) * 1e3, 1),
+               "sysfs_sources": {k: v for k, v in src.items()},
+               "perf_level": sorted({s.get("perf_level") for s in samples if s.get("perf_level")}),
+               "sclk_mhz": rng("sclk_mhz"), "sclk_hwmon_mhz": rng("sclk_hz", 1e-6), "mclk_mhz": rng("mclk_mhz"), "fclk_mhz": rng("fclk_mhz"),
+               "power_W": rng("power_avg_uW", 1e-6) or rng("power_in_uW", 1e-6), "power_cap_W": rng("power_cap_uW", 1e-6),
+               "busy_percent": rng("busy"), "temps_C": {k[5:-3]: rng(k, 1e-3) for k in (samples[0] if samples else {}) if k.startswith("temp_")}}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump({"summary": summary, "steps": series, "samples": samples[::5]}, open(os.path.join(ROOT, "gpurun_out", f"soak_{args.tag}.json"), "w"))
+    print(json.dumps(summary), flush=True)
+    os._exit(0)          # (daemon worker processes: no join)
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,11 @@ schedule with warm-up, per-epoch checkpoint, final safetensors model).  What dif
 kernels of mca-paper_amd, the optimizer is the fused clip+AdamW, data parallelism is mca-paper_amd/dp.py (RCCL), and
 logging goes to stdout / <output_dir>/log.jsonl instead of wandb.  `--synthetic STEPS` trains on synthetic batches of
 the configured shapes when the HF dataset named in the YAML is not on disk.
+
+Log records (train_accel_gpu.py:126-130,163-181): every step (`--log-every N`: every N-th; each record costs a host sync, as the
+reference's `.to("cpu")` calls do) total_loss, the loss terms without '|', param_norm, grad_norm, lr; per eval batch val_step_*;
+per epoch val_epoch_*.  Under data parallelism rank 0 logs ITS values, as `accelerator.log` does, the eval set is dealt to the
+ranks as Accelerate's prepared loader deals it (data.shard_eval_batches) and the embedding metrics gather every rank's rows.
 """
 import importlib
 import json
@@ -23,6 +28,7 @@ sys.path.insert(0, REPO)
 P = importlib.import_module("mca-paper_amd")
 optim = importlib.import_module("mca-paper_amd.optim")
 dpmod = importlib.import_module("mca-paper_amd.dp")
+from utils.training import get_grad_norm, get_param_norm  # noqa: E402  (the reference's import, train_accel_gpu.py:15)
 
 
 def lr_factor(name, step, warmup, total):
@@ -59,11 +65,15 @@ def move_to(obj, device):
     raise TypeError("Invalid type for move_to")
 
 
-def run_eval(model, eval_batches, model_config, device):
+def run_eval(model, eval_batches, model_config, device, step_log=None, sync=False):
     """The reference's evaluation loop (train_accel_gpu.py:137-181) on the native model: mean of the total loss and of every loss
     term without '|' over the eval batches, Wang-Isola uniformity per modality (+ 'fusion' unless EAO) and alignment of every
     modality with the fusion embedding (samples that have the modality), raw and normalised, with the reference's log keys
-    (its 'unformity_avg' spelling included).  Returns {key: float}."""
+    (its 'unformity_avg' spelling included).  Returns {key: float}.
+    step_log: called with the reference's per-batch record {val_step_total_loss, val_step_<term>} (:163-164).
+    sync (data parallelism): `eval_batches` is this rank's share (data.shard_eval_batches) and the forward all-gathers the
+    embeddings as in training, so every loss is the global-batch loss of this rank's rows; the sums stay this rank's (the
+    reference logs from the main process only) while the metrics gather every rank's rows (torchmetrics' cat states)."""
     was_training = model.training
     model.eval()
     names = list(model_config["encoder_configs"].keys())
@@ -78,6 +88,9 @@ def run_eval(model, eval_batches, model_config, device):
             sums["total_loss"] = sums.get("total_loss", 0.0) + float(out["loss"])
             for k, v in out["losses"].items():
                 sums[k] = sums.get(k, 0.0) + float(v)
+            if step_log is not None:
+                step_log({"val_step_total_loss": float(out["loss"]),
+                          **{"val_step_" + k: float(v) for k, v in out["losses"].items() if "|" not in k}})
             for k in names:
                 sm = out["modality_sample_mask"][k]
                 uni[k].update(out[k][sm])
@@ -88,10 +101,10 @@ def run_eval(model, eval_batches, model_config, device):
     rec = {f"val_epoch_{k}": v / max(1, n) for k, v in sums.items() if "|" not in k}
     mean = lambda d: sum(d.values()) / max(1, len(d))
     for tag, norm in (("", False), ("norm_", True)):
-        u = {f"val_epoch_{tag}uniformity_{k}": float(v.compute(norm=norm)) for k, v in uni.items()}
+        u = {f"val_epoch_{tag}uniformity_{k}": float(v.compute(norm=norm, sync=sync)) for k, v in uni.items()}
         rec.update(u); rec[f"val_epoch_{tag}unformity_avg"] = mean(u)
         if has_fusion:
-            a = {f"val_epoch_{tag}alignment_{k}": float(v.compute(norm=norm)) for k, v in ali.items()}
+            a = {f"val_epoch_{tag}alignment_{k}": float(v.compute(norm=norm, sync=sync)) for k, v in ali.items()}
             rec.update(a); rec[f"val_epoch_{tag}alignment_avg"] = mean(a)
     if was_training:
         model.train()
@@ -102,11 +115,14 @@ def main():
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
     synthetic_steps = int(sys.argv[sys.argv.index("--synthetic") + 1]) if "--synthetic" in sys.argv else 0
+    log_every = max(1, int(sys.argv[sys.argv.index("--log-every") + 1])) if "--log-every" in sys.argv else 1
     world, rank, local_rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=device)
+        # RCCL ("nccl" on ROCm); MCA_DIST_BACKEND=gloo rehearses the multi-rank path on a box with one GPU (tests)
+        backend = os.environ.get("MCA_DIST_BACKEND", "nccl")
+        torch.distributed.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
     config = P.config.training_config(sys.argv[1], make_output_dir=rank == 0)
     torch.manual_seed(config.seed)
     model_config = P.config.get_model_config(config)
@@ -131,8 +147,12 @@ def main():
         sampler = DistributedSampler(ds["train"], world, rank, shuffle=True, drop_last=True) if world > 1 else None
         train_dl = DataLoader(ds["train"], collate_fn=collate, batch_size=config.batch_size, shuffle=sampler is None, sampler=sampler,
                               num_workers=8, prefetch_factor=4, drop_last=True, pin_memory=True)
-        # the reference's eval loader keeps the last partial batch (train_accel_gpu.py:71); under DP equal local batches are needed
-        eval_dl = DataLoader(ds["test"], collate_fn=collate, batch_size=config.batch_size, drop_last=world > 1)
+        # the reference's eval loader keeps the last partial batch (train_accel_gpu.py:71); prepared for W processes Accelerate
+        # deals its batches round-robin and completes the last round from the start of the set (train_accel_gpu.py:93)
+        if world > 1:
+            eval_dl = DataLoader(ds["test"], collate_fn=collate, batch_sampler=P.data.shard_eval_batches(len(ds["test"]), config.batch_size, world, rank))
+        else:
+            eval_dl = DataLoader(ds["test"], collate_fn=collate, batch_size=config.batch_size)
         steps_per_epoch = len(train_dl)
 
         def batches(epoch):
@@ -193,9 +213,16 @@ def main():
                 opt.step()
                 step += 1
                 model.engine.poll_finite()          # raises for a completed step that saw non-finite values (no host sync)
-            if rank == 0 and (idb % 10 == 0 or idb == steps_per_epoch - 1):
+            if rank == 0 and (idb % log_every == 0 or idb == steps_per_epoch - 1):
+                # train_accel_gpu.py:126-130.  grad_norm there is read AFTER clip_grad_norm_ scaled the gradients in place, i.e.
+                # the clipped norm, and (like param_norm) without the first parameter (utils/training.py): here the fused AdamW
+                # applies the clip coefficient on the fly, so the same number is norm * min(1, clip / (norm + 1e-6)) of the
+                # helper's norm; the unclipped total norm is logged beside it.
+                gn_ref = float(get_grad_norm(model))
+                g_all = float(gnorm) if gnorm is not None else None
+                coef = min(1.0, config.clip / (g_all + 1e-6)) if (config.clip and g_all is not None) else 1.0
                 rec = {"epoch": epoch, "step": step, "total_loss": float(loss), "lr": opt.param_groups[0]["lr"],
-                       "grad_norm": float(gnorm) if gnorm is not None else None,
+                       "param_norm": float(get_param_norm(model)), "grad_norm": gn_ref * coef, "grad_norm_unclipped": g_all,
                        **{k: float(v) for k, v in outputs["losses"].items() if "|" not in k}}
                 print(json.dumps(rec), flush=True)
                 log.write(json.dumps(rec) + "\n"); log.flush()
@@ -206,7 +233,10 @@ def main():
             P.checkpoint.save_state(os.path.join(config.output_dir, str(epoch)), model, opt, step, sched_stride=sched_stride, next_lr=lr_at(step))
             print(f"epoch {epoch} done in {time.time() - t_epoch:.1f}s", flush=True)
         if config.run_eval_loop and eval_batches is not None:
-            rec = run_eval(model, eval_batches, model_config, device)
+            def step_log(r):
+                if rank == 0:
+                    log.write(json.dumps({"epoch": epoch, **r}) + "\n")
+            rec = run_eval(model, eval_batches, model_config, device, step_log=step_log, sync=world > 1)
             if rank == 0:
                 rec = {"epoch": epoch, **rec}
                 print(json.dumps(rec), flush=True)

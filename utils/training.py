@@ -1,8 +1,13 @@
 """Host helpers of the reference's step loop (utils/training.py:3-70), same names and return types.
 
 ``move_to`` keeps the reference's recursion over dicts / lists and its TypeError; copies are issued ``non_blocking`` (pinned
-batches then overlap with compute; pageable ones behave as before).  The two norms read the engine's flat buffers when the model
-runs on the native engine (one reduction instead of one per tensor) and fall back to the per-parameter loop otherwise."""
+batches then overlap with compute; pageable ones behave as before).
+
+The two norms reproduce the reference's VALUES, quirk included: both fetch the device with ``next(iter(parameters))`` on the
+very generator they then loop over (utils/training.py:50-51,61-62), so the FIRST parameter of ``model.parameters()`` is in
+neither norm (checked by running the reference's functions: tests/test_host_cpu.py states the contract).  ``skip_first=False``
+gives the norm over every parameter.  ``get_param_norm`` reads the engine's flat buffer when the model runs on the native
+engine (one reduction instead of one per tensor); ``get_grad_norm`` walks ``p.grad`` (views of the flat gradient buffer)."""
 import torch
 
 
@@ -14,16 +19,6 @@ def move_to(obj, device):
     if isinstance(obj, list):
         return [move_to(v, device) for v in obj]
     raise TypeError("Invalid type for move_to")
-
-
-def copy_batch(obj):
-    if torch.is_tensor(obj):
-        return obj.detach().clone()
-    if isinstance(obj, dict):
-        return {k: copy_batch(v) for k, v in obj.items()}
-    if isinstance(obj, list):
-        return [copy_batch(v) for v in obj]
-    raise TypeError("Invalid type for copy_to")
 
 
 def count_parameters(model, print_summary=False):
@@ -46,25 +41,30 @@ def _engine_of(model):
     return getattr(m, "_engine", None)
 
 
-def get_param_norm(model, norm_type=2.0):
-    """L-p norm over every parameter, a 1-element float64 tensor on the model's device (utils/training.py:48-57)."""
+def get_param_norm(model, norm_type=2.0, skip_first=True):
+    """L-p norm over the parameters (all but the first: module docstring), a 1-element float64 tensor on the model's device
+    (utils/training.py:48-57)."""
     norm_type = float(norm_type)
+    params = list(model.parameters())
     eng = _engine_of(model)
     if eng is not None and norm_type == 2.0:
-        return eng.flat.double().pow(2).sum().sqrt().reshape(1)          # alignment padding of the flat buffer is zero
-    params = list(model.parameters())
+        sq = eng.flat.double().pow(2).sum()          # alignment padding of the flat buffer is zero
+        if skip_first and params:
+            sq = sq - params[0].detach().double().pow(2).sum()
+        return sq.clamp_min(0).sqrt().reshape(1)
     total = torch.zeros(1, dtype=torch.float64, device=params[0].device)
-    for p in params:
+    for p in params[1 if skip_first else 0:]:
         total += torch.norm(p.detach(), norm_type).double() ** norm_type
     return total ** (1.0 / norm_type)
 
 
-def get_grad_norm(model, norm_type=2.0):
-    """L-p norm over every gradient that exists, a 1-element float32 tensor (utils/training.py:59-70)."""
+def get_grad_norm(model, norm_type=2.0, skip_first=True):
+    """L-p norm over every gradient that exists (all but the first parameter's: module docstring), a 1-element float32 tensor
+    (utils/training.py:59-70)."""
     norm_type = float(norm_type)
     params = list(model.parameters())
     total = torch.zeros(1, dtype=torch.float32, device=params[0].device)
-    for p in params:
+    for p in params[1 if skip_first else 0:]:
         if p.grad is not None:
             total += torch.norm(p.grad.detach(), norm_type) ** norm_type
     return total ** (1.0 / norm_type)
