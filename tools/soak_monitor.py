@@ -14,10 +14,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def find_sources():
-    """the sysfs files of the GPU torch uses (card with an amdgpu hwmon): {name: path}"""
+def find_sources(pci_bus_id=None):
+    """the sysfs files of the GPU torch uses: the card whose PCI address is pci_bus_id ('0000:05:00.0'; a box exposes one of its
+    eight GPUs to the process, and card0 is usually another tenant's), else the first card with an amdgpu hwmon: {name: path}"""
     src = {}
-    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*"))
+    if pci_bus_id:
+        match = [c for c in cards if pci_bus_id.lower() in os.path.realpath(os.path.join(c, "device")).lower()]
+        cards = match or cards
+    for card in cards:
         dev = os.path.join(card, "device")
         hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
         if not hw or not os.path.exists(os.path.join(dev, "pp_dpm_sclk")):
@@ -95,7 +100,10 @@ def main():
     args = ap.parse_args()
     import torch
     P = importlib.import_module("mca-paper_amd"); optim = importlib.import_module("mca-paper_amd.optim"); graph = importlib.import_module("mca-paper_amd.graph")
-    src = find_sources()
+    pr = torch.cuda.get_device_properties(0)
+    pci = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)) if hasattr(pr, "pci_bus_id") else None
+    src = find_sources(pci)
+    src["_pci"] = pci
     samples, stop = [], threading.Event()
     th = threading.Thread(target=sampler, args=(src, stop, samples), daemon=True)
     th.start()
@@ -107,7 +115,7 @@ def main():
     torch.manual_seed(43)
     model = P.build_model(cfg).cuda(); model.engine.check_finite = "deferred"
     opt = optim.FusedAdamW(model, lr=1e-4)
-    batch = P.data.synthetic_batch(cfg, args.batch, seed=1234, device="cuda")
+    batch = P.data.synthetic_batch(cfg, args.batch, seed=1234, lengths="full", device="cuda")          # BASELINE configs[1]: full-length sequences
     t_setup = time.perf_counter()
     g = None if args.eager else graph.GraphedStep(model, opt, batch, clip=2.0)
 
