@@ -27,6 +27,59 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+
+class GpuStateSampler:
+    """amdgpu sysfs (shader clock, board power, junction temperature) of THIS process's GPU every 50 ms while the timed region
+    runs: the pool's boxes differ by +-6 % and every box has two sustained-load operating points (profiles/r04_slow_regime.md), so
+    a samples/s figure is only comparable with the clock it was measured at.  Read-only files; absent files give nulls."""
+
+    def __init__(self, device_index=0):
+        import glob, threading
+        self.rows, self._stop, self._thread = [], threading.Event(), None
+        self.src = {}
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            return
+        for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+            dev = os.path.join(card, "device")
+            if pci.lower() not in os.path.realpath(dev).lower():
+                continue
+            hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
+            if hw:
+                cand = {"sclk_hz": "freq1_input", "power_uW": "power1_input", "power_avg_uW": "power1_average", "junction_mC": "temp1_input"}
+                self.src = {k: os.path.join(hw[0], f) for k, f in cand.items() if os.path.exists(os.path.join(hw[0], f))}
+            break
+
+    def _run(self):
+        while not self._stop.is_set():
+            row = {}
+            for k, path in self.src.items():
+                try:
+                    row[k] = int(open(path).read().strip())
+                except (OSError, ValueError):
+                    pass
+            self.rows.append(row)
+            self._stop.wait(0.05)
+
+    def start(self):
+        import threading
+        if self.src:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=1)
+
+        def med(key, scale):
+            v = sorted(r[key] * scale for r in self.rows if key in r)
+            return round(v[len(v) // 2], 1) if v else None
+        return {"sclk_mhz_median": med("sclk_hz", 1e-6), "power_w_median": med("power_uW", 1e-6) or med("power_avg_uW", 1e-6),
+                "junction_c_median": med("junction_mC", 1e-3), "samples": len(self.rows), "source": "amdgpu sysfs hwmon, 50 ms, timed region only"}
+
 MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic GFLOP per sample per step, mask-aware, 2 flop/MAC, bwd = 2 x fwd (SURVEY.md section 8d)
 STEP_GFLOP = {"cmu_mca": 334.8, "cmu_mma": 337.4, "long_mca": 885.7}
@@ -140,6 +193,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-protocol", default="short", choices=["short", "full"])
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--step-times", action="store_true", help="print the host clock after every timed step to stderr (diagnosis)")
     ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"], help="auto: hipGraph replay (one graph on one GPU; graph segments cut at the eager collectives under data parallelism); falls back to the eager loop if the capture fails")
     ap.add_argument("--sample-every", type=int, default=20, help="record per-kernel HIP events on every n-th timed step (a sampled step runs its kernels one at a time and costs ~1.3 steps)")
     args = ap.parse_args()
@@ -291,8 +345,12 @@ def main():
     torch.cuda.synchronize()
     if kernel_timing:
         hip.profile_start(timed)
+    gpu_state = GpuStateSampler(dev.index if hasattr(dev, "index") and dev.index is not None else 0) if rank == 0 else None
+    if gpu_state is not None:
+        gpu_state.start()
     t0 = time.perf_counter()
     sampled = 0
+    host_marks = []          # --step-times: host clock after every step's launches (a sampled step ends synchronised)
     for i in range(args.steps):
         rec = kernel_timing and (i % args.sample_every) == 0
         hip.profile_enable(rec)
@@ -310,17 +368,21 @@ def main():
         if rec:
             hip.profile_collect()             # its timing events are resolved and released right away
             eng.overlap_wgrad = saved
+        host_marks.append(time.perf_counter() - t0)
     hip.profile_enable(True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gpu_state = gpu_state.stop() if gpu_state is not None else None
     prof = hip.profile_stop() if kernel_timing else {}
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+    if args.step_times and rank == 0:
+        print("bench: host ms after each step: " + " ".join(f"{m * 1e3:.1f}" for m in host_marks) + f" | synchronised end {dt * 1e3:.1f}", file=sys.stderr, flush=True)
     eng.assert_finite()                        # the device flag of the last step (blocking read, outside the timed region)
     assert bool(torch.isfinite(loss)), "non-finite loss in the timed region"
     # a step whose gradients blew up is not a measurement (a mis-ordered memset node in the captured graph once left the loss
@@ -347,6 +409,8 @@ def main():
                        "launch_choice": choice,
                        "collectives": (f"{dist.get_backend()} over {dist.get_world_size()} ranks" if world > 1 else "none")},
         }
+        if gpu_state is not None:
+            line["config"]["gpu_state_rank0"] = gpu_state
         if gf:
             line["step_tflops"] = round(value * gf / 1e3, 1)
             line["step_frac_of_mfma_peak"] = round(value * gf / 1e3 / (MFMA_BF16_PEAK_TFLOPS * world), 4)

@@ -335,10 +335,11 @@ int mca_contrastive_fwd_bwd(const float* pooled_all, const uint32_t* present_all
 /* ---------------------------------------------------------------------------------------------
  * clip_grad_norm_ + AdamW over one flat buffer (train_accel_gpu.py:116-118; torch AdamW defaults)
  * --------------------------------------------------------------------------------------------- */
-/* sqnorm[0] += sum g^2  (caller zeroes sqnorm[0]).  sqnorm points at MCA_SQNORM_WORDS floats: words 1.. are scratch for the
- * per-block partial sums, added in a fixed order (the same bits on every launch and on every data-parallel replica); the
- * library itself holds no state, calls on different buffers may overlap.                          */
-#define MCA_SQNORM_WORDS 1025
+/* sqnorm[0] = sum g^2, sqnorm[MCA_SQNORM_WORDS - 1] = its square root (the total gradient norm, train_accel_gpu.py:116).
+ * sqnorm points at MCA_SQNORM_WORDS floats: words 1 .. MCA_SQNORM_WORDS - 2 are scratch for the per-block partial sums, added
+ * in a fixed order (the same bits on every launch and on every data-parallel replica); the library itself holds no state,
+ * calls on different buffers may overlap.                                                          */
+#define MCA_SQNORM_WORDS 1026
 int mca_grad_sqnorm(const float* g, int64_t n, float* sqnorm, mca_stream_t stream);
 /* grads scaled by min(1, max_norm/(sqrt(sqnorm)+1e-6)) when max_norm > 0, then decoupled AdamW.
  * skip_flag (may be NULL): device word written by mca_nonfinite_flag; non-zero = the step is skipped,

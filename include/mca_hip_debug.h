@@ -12,7 +12,7 @@ extern "C" {
 /* knob[key] = value for key in [0, 16); returns 0.  All knobs are 0 in production.  What the library reads them for:
  *    0  persistent NT GEMMs: 8 = s_memtime stamps of workgroup 0 (tools/trace_persist.py), 32 * P = P row panels per tile group
  *    1  = 1: the 128 x 128 NT kernel for every shape;   2  bit 1: weight-gradient 128 x 128 kernel without its atomics (timing)
- *    3  > 0: number of row splits of the weight-gradient kernels;   4  = 1: no residual prefetch in the fp32 + residual NT kernel
+ *    3  > 0: number of (uniform) row splits of the weight-gradient kernels;   4  = 1: no residual prefetch in the fp32 + residual NT kernel
  *    5  weight-gradient kernel: 1 = 128 x 128, 2 = 256 x 128 where 256 x 256 would be chosen
  *    7  1 = one-tile-per-workgroup NT kernels only, 3 = persistent kernel for fp32 + residual as well;   10  = 1: 256 x 128 persistent
  *       kernel where the 256 x 256 one would be chosen;   11  = 1: one launch per member of a weight-gradient group
@@ -22,7 +22,7 @@ extern "C" {
  *   12  = 1: general LayerNorm kernels where the trunk forms would be chosen;   13  = 1: register-staged attention forward,
  *       = 2: the LDS-DMA forward (attn_fwd4_kernel) whatever the flags and schedules say, = 3: the query-block kernel
  *       (attention_fwd64.hip) whenever the caller supplies its schedule
- *   14  > 0: cap on the workgroups of the trunk LayerNorm backward (default 256)
+ *   14  > 0: cap on the workgroups of the LayerNorm backward kernels (default 256) and of mca_reduce_rows (default 512)
  *   15  = t + 1: the forward attention kernels move their lazy softmax reference when a score exceeds it by more than t
  *       log2 units (default 12; 1 = at every increase, the textbook online softmax) */
 int mca_debug_set(int key, int value);

@@ -629,19 +629,18 @@ extern "C" int mca_attn_bwd_dkv(const mca_attn_bwd2_args* a, mca_stream_t stream
 }
 
 // =====================================================================================================
-// delta[b,h,q] = sum_d dO[q,h,d] * O[q,h,d]   (dvmean: attn_dvmean_kernel below)
+// delta[b,h,q] = sum_d dO[q,h,d] * O[q,h,d]   (dvmean: attn_dvmean_block below, same launch)
 // one wavefront per (b, q) row: lane covers 8 contiguous columns of the 512-wide row -> head = lane / 8
 // =====================================================================================================
 #define PREP_ROWS 32
-__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restrict__ o, const u16* __restrict__ d_o,
-                                                             int64_t bstride, int64_t ld, float* __restrict__ delta, int heads,
-                                                             int nq) {
+__device__ __forceinline__ void attn_bwd_prep_block(const int bx, const int by, const u16* __restrict__ o, const u16* __restrict__ d_o,
+                                                    int64_t bstride, int64_t ld, float* __restrict__ delta, int heads, int nq) {
   // delta is (b, head, q): a row touches it at a stride of nq floats per head.  It crosses LDS so that the global accesses are
   // 128-byte runs along q (one row at a time they were 4-byte accesses in 8 different lines per row).
   __shared__ float del_s[8][PREP_ROWS];
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = by, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cols = heads * DH;
-  const int q_begin = blockIdx.x * PREP_ROWS;
+  const int q_begin = bx * PREP_ROWS;
   int q_end = q_begin + PREP_ROWS; if (q_end > nq) q_end = nq;
   for (int c0 = 0; c0 < cols; c0 += 512) {
     const int h0 = c0 / DH;
@@ -685,13 +684,13 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restric
 // (a kernel, not hipMemsetAsync: as a memset NODE of a single-chain captured step the zeroing was not ordered against the
 // kernels around it - the whole backward then started from a dvmean full of stale sums).
 #define DVM_MAX_LIST 4096
-__global__ __launch_bounds__(256) void attn_dvmean_kernel(const u16* __restrict__ d_o, int64_t bstride, int64_t ld,
-                                                           const float* __restrict__ lse, float* __restrict__ dvmean,
-                                                           int heads, int nq, float inv_nk) {
+__device__ __forceinline__ void attn_dvmean_block(const int bx, const int by, const u16* __restrict__ d_o, int64_t bstride, int64_t ld,
+                                                  const float* __restrict__ lse, float* __restrict__ dvmean,
+                                                  int heads, int nq, float inv_nk) {
   __shared__ int list_s[DVM_MAX_LIST];
   __shared__ int n_s;
   __shared__ float red[32][DH + 1];
-  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = bx, b = by, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* l = lse + ((int64_t)b * heads + h) * nq;
   float* out = dvmean + (int64_t)b * heads * DH + h * DH;
   {          // the common case first: no uniform row at all (one barrier)
@@ -740,15 +739,22 @@ __global__ __launch_bounds__(256) void attn_dvmean_kernel(const u16* __restrict_
     out[tid] = t * inv_nk;
   }
 }
+// delta and dvmean are independent of each other: ONE launch (a node of the replayed step costs ~4 us whatever it does); blocks
+// 0 .. n_prep - 1 of a sample compute delta, the `heads` blocks behind them dvmean
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restrict__ o, const u16* __restrict__ d_o, int64_t bstride, int64_t ld,
+                                                             const float* __restrict__ lse, float* __restrict__ delta,
+                                                             float* __restrict__ dvmean, int heads, int nq, float inv_nk, int n_prep) {
+  if ((int)blockIdx.x < n_prep) attn_bwd_prep_block((int)blockIdx.x, (int)blockIdx.y, o, d_o, bstride, ld, delta, heads, nq);
+  else attn_dvmean_block((int)blockIdx.x - n_prep, (int)blockIdx.y, d_o, bstride, ld, lse, dvmean, heads, nq, inv_nk);
+}
 extern "C" int mca_attn_bwd_prep(const uint16_t* o, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld,
                                  const float* lse, float* delta, float* dvmean, int batch, int heads, int nq, int nk,
                                  mca_stream_t stream) {
   if (!o || !d_o || !lse || !delta || !dvmean || batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0) return MCA_E_BADARG;
   if (o_ld % 8 || o_bstride % 8 || (uintptr_t)o % 16 || (uintptr_t)d_o % 16) return MCA_E_ALIGN;
   if (heads > 65535 || batch > 65535) return MCA_E_UNSUPPORTED;
-  hipLaunchKernelGGL(attn_dvmean_kernel, dim3(heads, batch), dim3(256), 0, as_stream(stream), d_o, o_bstride, o_ld, lse, dvmean, heads, nq,
-                     1.f / (float)nk);
-  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((nq + PREP_ROWS - 1) / PREP_ROWS, batch), dim3(256), 0, as_stream(stream), o, d_o,
-                     o_bstride, o_ld, delta, heads, nq);
+  const int n_prep = (nq + PREP_ROWS - 1) / PREP_ROWS;
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(n_prep + heads, batch), dim3(256), 0, as_stream(stream), o, d_o, o_bstride, o_ld, lse, delta,
+                     dvmean, heads, nq, 1.f / (float)nk, n_prep);
   return launch_status();
 }

@@ -362,7 +362,8 @@ extern "C" int mca_layernorm_bwd(const float* dy, int64_t ldy, int64_t y_bstride
     return launch_status();
   }
   int64_t blocks = (rows + 3) / 4;
-  if (blocks > 1024) blocks = 1024;          // bounds the number of atomics on dgamma/dbeta
+  const int64_t bcap = mca_knobs[14] > 0 ? mca_knobs[14] : 256;          // one workgroup per CU, as the trunk form: each ends with atomics on the same dgamma / dbeta addresses
+  if (blocks > bcap) blocks = bcap;
   if (vec)
     hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dy, ldy, y_bstride,
                        period, x, ldx, gamma, mean, rstd, rowmask, dx, lddx, dx_bf16, ld_bf16, dgamma, dbeta, rows, cols);
@@ -557,6 +558,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
   int64_t g1 = g0 + groups_per_block; if (g1 > ngroups) g1 = ngroups;
   if (c >= cols) return;
   float acc = 0.f;
+#pragma unroll 4
   for (int64_t g = g0; g < g1; g++) {
     if (g * period + prow < rows) acc += src[g * src_bstride + prow * lds + c];
   }
@@ -567,9 +569,13 @@ extern "C" int mca_reduce_rows(const float* src, int64_t lds, int64_t src_bstrid
   if (!src || !dst || rows < 0 || cols <= 0 || period <= 0) return MCA_E_BADARG;
   if (rows == 0) return MCA_OK;
   const int64_t ngroups = (rows + period - 1) / period;
-  int64_t slabs = ngroups < 1024 ? ngroups : 1024;      // enough blocks to keep HBM busy on tall column sums
-  // keep the grid reasonable when period is large
-  while (slabs > 1 && slabs * period * ((cols + 255) / 256) > 65536) slabs /= 2;
+  // Two rounds of workgroups at most: every slab ends with one atomic per (prow, column), and the slabs of one column all hit
+  // the same address (a bias gradient over 12,000 rows in 1,024 slabs: 38 us for 25 MB, all of it same-address atomics; knob 14
+  // = another number of workgroups, tools/bench_ln.py)
+  const int64_t per_slab = period * ((cols + 255) / 256);
+  const int64_t wgs = mca_knobs[14] > 0 ? mca_knobs[14] : 512;
+  int64_t slabs = wgs / per_slab > 0 ? wgs / per_slab : 1;
+  if (slabs > ngroups) slabs = ngroups;
   const int64_t gpb = (ngroups + slabs - 1) / slabs;
   if (period > 65535) return MCA_E_UNSUPPORTED;
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 255) / 256, (unsigned)period, (unsigned)slabs), dim3(256), 0,

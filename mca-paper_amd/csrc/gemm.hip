@@ -1657,25 +1657,58 @@ struct tn_group {
   int64_t lda[MCA_TN_MAX_GROUP], ldb[MCA_TN_MAX_GROUP], ldc[MCA_TN_MAX_GROUP];
   int N[MCA_TN_MAX_GROUP], K[MCA_TN_MAX_GROUP], tiles_k[MCA_TN_MAX_GROUP];
   int first_tile[MCA_TN_MAX_GROUP + 1];
-  int n, R, rows_per_split;
+  int n, R, tiles;
+  // Balanced row partition: every workgroup reduces `unit` rows of one tile's worth of work.  The first n_full * tiles
+  // workgroups take whole (tile, split) cells of `unit` rows as before (the tiles of one split next to each other on an XCD, so
+  // that an operand row block is fetched into one L2 once); the rows left over, [n_full * unit, R) of every tile, form a second,
+  // tile-major line of tiles * (R - n_full * unit) row-units that the remaining workgroups cut into equal spans of `unit`: such a
+  // workgroup finishes one tile's rest and starts the next one's (two atomic epilogues).  Any number of tiles then fills the
+  // chip's one round of workgroups: 52 tiles are 4 full splits on 208 CUs + 48 spans, not 4 splits with 48 CUs idle.
+  int unit, n_full;
 };
 __global__ __launch_bounds__(512) void gemm_tn_256x256_group_kernel(tn_group g, int dbg) {
   extern __shared__ __attribute__((aligned(16))) u16 ldst[];
-  const int lin0 = (int)(blockIdx.x + gridDim.x * blockIdx.y);
-  const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y));          // tiles of one split on one XCD
-  const int tile_all = lin % (int)gridDim.x, split_id = lin / (int)gridDim.x;
-  int p = 0;
-#pragma unroll
-  for (int i = 1; i < MCA_TN_MAX_GROUP; i++) if (i < g.n && tile_all >= g.first_tile[i]) p = i;
-  const int tile_id = tile_all - g.first_tile[p];
-  const int r_begin = split_id * g.rows_per_split;
-  int r_end = r_begin + g.rows_per_split; if (r_end > g.R) r_end = g.R;
+  const int lin0 = (int)blockIdx.x;
+  const int lin = (dbg & 16) ? lin0 : xcd_remap(lin0, (int)gridDim.x);          // tiles of one split on one XCD
 #ifdef MCA_TRACE_BUILD          // clock probe (knob 9 bit 8): shader cycles and 100 MHz ticks of every workgroup's lifetime (tools/ablate_tn_group.py)
   const bool probe = (dbg & 8) && threadIdx.x == 0 && lin0 < 512;
   const uint64_t c0 = probe ? __builtin_amdgcn_s_memtime() : 0, t0 = probe ? __builtin_amdgcn_s_memrealtime() : 0;
 #endif
-  tn_256x256_tile(g.A[p], g.lda[p], g.B[p], g.ldb[p], g.C[p], g.ldc[p], g.N[p], g.K[p], tile_id / g.tiles_k[p], tile_id % g.tiles_k[p],
-                  r_begin, r_end, ldst);
+  const int n_cells = g.n_full * g.tiles;
+  const int row0 = g.n_full * g.unit, rest = g.R - row0;          // rows [row0, R) of every tile: the tile-major line
+  // this workgroup's span [s, e) of the line (a whole cell is the degenerate case: one segment, no line arithmetic)
+  int64_t s = 0, e = 0;
+  if (lin >= n_cells) {
+    s = (int64_t)(lin - n_cells) * g.unit;
+    e = s + g.unit;
+    const int64_t line = (int64_t)g.tiles * rest;
+    if (e > line) e = line;
+  }
+  bool first = true;
+  for (;;) {
+    int tile_all, r_begin, r_end;
+    if (lin < n_cells) {
+      tile_all = lin % g.tiles;
+      r_begin = (lin / g.tiles) * g.unit; r_end = r_begin + g.unit;
+    } else {
+      if (s >= e) break;
+      tile_all = (int)(s / rest);
+      const int off = (int)(s - (int64_t)tile_all * rest);
+      int len = rest - off; if ((int64_t)len > e - s) len = (int)(e - s);
+      r_begin = row0 + off; r_end = r_begin + len;
+      s += len;
+    }
+    if (r_end > g.R) r_end = g.R;
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < MCA_TN_MAX_GROUP; i++) if (i < g.n && tile_all >= g.first_tile[i]) p = i;
+    const int tile_id = tile_all - g.first_tile[p];
+    if (!first) __syncthreads();          // the previous segment's last fragment reads, before this one's DMA lands in the ring
+    first = false;
+    tn_256x256_tile(g.A[p], g.lda[p], g.B[p], g.ldb[p], g.C[p], g.ldc[p], g.N[p], g.K[p], tile_id / g.tiles_k[p], tile_id % g.tiles_k[p],
+                    r_begin, r_end, ldst);
+    if (lin < n_cells) break;
+  }
 #ifdef MCA_TRACE_BUILD
   if (probe) { mca_trace_gemm[2 * lin0] = __builtin_amdgcn_s_memtime() - c0; mca_trace_gemm[2 * lin0 + 1] = __builtin_amdgcn_s_memrealtime() - t0; }
 #endif
@@ -1763,16 +1796,23 @@ extern "C" int mca_gemm_tn_acc_group(const mca_tn_desc* d, int n, int64_t R, mca
     return MCA_OK;
   }
   for (int i = n; i <= MCA_TN_MAX_GROUP; i++) g.first_tile[i] = tiles;
-  g.n = n; g.R = (int)R;
-  // one full round of workgroups (1 per CU): splits = CUs / tiles, at least 4 steps of 32 rows each
-  int64_t splits = num_cus() / tiles > 0 ? num_cus() / tiles : 1;
-  if (g_knob[3] > 0) splits = g_knob[3];
-  const int64_t max_splits = (R + 4 * BR2 - 1) / (4 * BR2);
-  if (splits > max_splits) splits = max_splits;
-  int64_t rps = (R + splits - 1) / splits;
-  rps = (rps + BR2 - 1) / BR2 * BR2;
-  splits = (R + rps - 1) / rps;
-  g.rows_per_split = (int)rps;
+  g.n = n; g.R = (int)R; g.tiles = tiles;
+  // one full round of workgroups (1 per CU), every one with the same `unit` rows of one tile (struct tn_group): at least 4 steps
+  // of 32 rows each.  knob 3 = s: s uniform splits and no line (the round-3 partition, A/B)
+  const int cus = num_cus();
+  int64_t unit = ((int64_t)tiles * R + cus - 1) / cus;
+  if (g_knob[3] > 0) unit = (R + g_knob[3] - 1) / g_knob[3];
+  if (unit < 4 * BR2) unit = 4 * BR2;
+  unit = (unit + BR2 - 1) / BR2 * BR2;
+  if (unit > R) unit = (R + BR2 - 1) / BR2 * BR2;
+  int64_t n_full = R / unit;                                  // whole cells per tile
+  if (g_knob[3] <= 0 && n_full * tiles > cus) n_full = cus / tiles;
+  int64_t rest = R - n_full * unit;
+  if (g_knob[3] > 0 && rest > 0) { n_full += 1; rest = 0; }          // uniform splits: the last one is short
+  const int64_t spans = rest > 0 ? ((int64_t)tiles * rest + unit - 1) / unit : 0;
+  const int64_t grid = n_full * tiles + spans;
+  if (grid <= 0 || grid > (1 << 30)) return MCA_E_UNSUPPORTED;
+  g.unit = (int)unit; g.n_full = (int)n_full;
   static bool attr_dev[64] = {false}; bool& attr = *mca_dev_flag(attr_dev);
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_256x256_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1780,7 +1820,6 @@ extern "C" int mca_gemm_tn_acc_group(const mca_tn_desc* d, int n, int64_t R, mca
       return MCA_E_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL(gemm_tn_256x256_group_kernel, dim3(tiles, (unsigned)splits), dim3(512), TN2_LDS_BYTES, as_stream(stream), g,
-                     g_knob[9]);
+  hipLaunchKernelGGL(gemm_tn_256x256_group_kernel, dim3((unsigned)grid), dim3(512), TN2_LDS_BYTES, as_stream(stream), g, g_knob[9]);
   return launch_status();
 }

@@ -10,7 +10,7 @@
 // data-parallel replicas that hold identical gradients, differ in the last bit from rank to rank).  The slots are words
 // 1 .. MCA_SQNORM_WORDS - 1 of the CALLER's buffer (word 0 = the norm): the library keeps no state of its own, so two norms
 // on two streams, two engines in one process or a bench A/B cannot meet in a hidden array.
-#define SQN_BLOCKS (MCA_SQNORM_WORDS - 1)
+#define SQN_BLOCKS (MCA_SQNORM_WORDS - 2)
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, int64_t n4, int64_t n, float* __restrict__ mca_sqnorm_partials) {
   __shared__ float red[4];
   float acc = 0.f;
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64) void sqnorm_final_kernel(int blocks, float* __r
   float acc = 0.f;
   for (int i = threadIdx.x; i < blocks; i += 64) acc += mca_sqnorm_partials[i];          // lane l: slots l, l + 64, ... in order
   acc = wave_sum(acc);
-  if (threadIdx.x == 0) *out += acc;          // accumulates into the caller's (zeroed) word, as the atomic form did
+  if (threadIdx.x == 0) { out[0] = acc; out[MCA_SQNORM_WORDS - 1] = sqrtf(acc); }          // sum g^2 and the norm itself (for logs: no sqrt launch)
 }
 
 extern "C" int mca_grad_sqnorm(const float* g, int64_t n, float* sqnorm, mca_stream_t stream) {

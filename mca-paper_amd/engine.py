@@ -149,10 +149,17 @@ class FusionEngine:
         order: List[torch.nn.Parameter] = []
         marks: List[int] = []                        # bucket boundaries (indices into `order`)
         order += [m.loss.loss_fn.logit_scale]
+        # the pooling key/value projection's gradient is reduced over all T token rows: it rides in the top layer's grouped
+        # weight-gradient launch (_backward_layers_and_encoders) and therefore belongs to that layer's bucket
+        pool_kv_late = not self.eao and self.L > 0
         if not self.eao:
-            order += [m.return_tokens, m.attn_pool.to_out.weight, m.attn_pool.to_q.weight, m.attn_pool.to_kv.weight]
+            order += [m.return_tokens, m.attn_pool.to_out.weight, m.attn_pool.to_q.weight]
+            if not pool_kv_late:
+                order += [m.attn_pool.to_kv.weight]
         order += [m.norm.gamma]
         marks.append(len(order))
+        if pool_kv_late:
+            order += [m.attn_pool.to_kv.weight]
         for i in reversed(range(self.L)):
             ly = m.layers[i]
             order += [ly.ff.feedforward[2].weight, ly.ff.feedforward[0].weight, ly.attn.to_out.weight,
@@ -783,15 +790,18 @@ class FusionEngine:
         call("mca_f32_to_bf16", ptr(ws["dqp_sum"]), D, ptr(ws["dqp_b"]), D, R, D, 1.0, stream_ptr())
         self.gemm_nt(ws["dqp_b"], self.wp["qT"], ws["drt"], R, D, D)                 # d return_tokens via to_q
         call("mca_reduce_rows", ptr(ws["drt"]), D, R * D, R, ptr(G(m.return_tokens)), D, R, D, stream_ptr())
-        on_side(lambda: (tn(ws["dqp_b"], ws["rt_b"], G(ap.to_q.weight), R, D, D),
-                         tn(ws["dkvp"], ws["t_b"], G(ap.to_kv.weight), T, 2 * D, D)))
+        on_side(lambda: tn(ws["dqp_b"], ws["rt_b"], G(ap.to_q.weight), R, D, D))
+        pool_kv = (ws["dkvp"], ws["t_b"], G(ap.to_kv.weight), 2 * D, D)
+        if not (self.L > 0 and self.group_wgrad and T >= 4096):          # else: a member of the top layer's grouped launch
+            on_side(lambda pk=pool_kv: tn(pk[0], pk[1], pk[2], T, 2 * D, D))
+            pool_kv = None
         dx, dx_other = ws["dxa"], ws["dxb"]
         self.gemm_nt(ws["dkvp"], self.wp["kvT"], dx, T, D, 2 * D)                    # d (final-normed tokens), fp32
         top = ws["layers"][self.L - 1]["dxo_b"] if self.L else ws["dx_b"]
         self.ln_bwd(dx, D, ws["x"][self.L], m.norm.gamma, ws["mf"], ws["rf"], T, D, G(m.norm.gamma), dx=dx_other, dx_bf16=top)
         dx, dx_other = dx_other, dx
         on_side(lambda: bucket_ready(0))
-        self._backward_layers_and_encoders(ws, dx, dx_other, bucket_ready, on_side)
+        self._backward_layers_and_encoders(ws, dx, dx_other, bucket_ready, on_side, extra_top=pool_kv)
 
     def _backward_part_eao(self, ws, dpool, bucket_ready, on_side):
         """EAO: d pooled (b, segments, D) -> mean-pool backward -> final norm backward -> the shared layer / encoder chain."""
@@ -805,7 +815,7 @@ class FusionEngine:
         on_side(lambda: bucket_ready(0))
         self._backward_layers_and_encoders(ws, dx, dx_other, bucket_ready, on_side)
 
-    def _backward_layers_and_encoders(self, ws, dx, dx_other, bucket_ready, on_side):
+    def _backward_layers_and_encoders(self, ws, dx, dx_other, bucket_ready, on_side, extra_top=None):
         m, D, N, H, Ip, I, R, b, T = self.model, self.D, self.N, self.H, self.Ip, self.I, self.R, ws["b"], ws["T"]
         G = self.grad_of
         tn = self.gemm_tn_acc
@@ -815,8 +825,9 @@ class FusionEngine:
             dxo, dx1, dh, dqkv = a["dxo_b"], a["dx1_b"], a["dh"], a["dqkv"]
             below = ws["layers"][i - 1]["dxo_b"] if i > 0 else ws["dx_b"]
             # x_out = g @ W2^T + x1n            (dx = d x_out fp32, dxo = its bf16 copy)
-            # The four weight gradients of the layer reduce over the same T rows: grouped into one launch after the layer's
-            # attention backward (48 tiles -> 5 row splits instead of 21 per gradient: a quarter of the fp32 atomic traffic).
+            # The five weight gradients of the layer reduce over the same T rows: grouped into one launch after the layer's
+            # attention backward (52 tiles of 256 x 256 -> 5 row splits instead of 21-32 per gradient: a quarter of the fp32 atomic
+            # traffic; the launch's balanced row partition fills all CUs for any tile count, gemm.hip struct tn_group).
             grouped = self.group_wgrad and T >= 4096
             if not grouped:
                 on_side(lambda dxo=dxo, a=a, ly=ly: tn(dxo, a["g"], G(ly.ff.feedforward[2].weight), T, D, I))
@@ -833,7 +844,8 @@ class FusionEngine:
             self.gemm_nt(dh, w["w1T"], dx_other, T, D, 2 * Ip, residual=dx)            # d x1n = dh @ W1 + dx
             self.ln_bwd(dx_other, D, a["x1"], g, a["m2"], a["r2"], T, D, G(g), dx=dx, dx_bf16=dx1)   # dx = d x1
             # x1 = o @ Wo^T + xn
-            on_side(lambda dx1=dx1, a=a, ly=ly: tn(dx1, a["o"], G(ly.attn.to_out.weight), T, D, D))
+            if not grouped:
+                on_side(lambda dx1=dx1, a=a, ly=ly: tn(dx1, a["o"], G(ly.attn.to_out.weight), T, D, D))
             self.gemm_nt(dx1, w["oT"], ws["do"], T, D, D)
             # dq | dk | dv land in dqkv as bf16, each element written once
             self._attn_bwd2(a["qkv"].data_ptr(), N * 3 * D, 3 * D, a["qkv"], D, 2 * D, 3 * D, a["o"], ws["do"], a["lse"],
@@ -843,10 +855,11 @@ class FusionEngine:
             gq = G(ly.attn.to_q.weight)
             assert G(ly.attn.to_kv.weight).data_ptr() == gq.data_ptr() + D * D * 4
             if grouped:
-                gw2 = G(ly.ff.feedforward[2].weight)
-                on_side(lambda dqkv=dqkv, dh=dh, dxo=dxo, a=a, gq=gq, gw1=gw1, gw2=gw2: self.gemm_tn_acc_group(
+                gw2, gwo = G(ly.ff.feedforward[2].weight), G(ly.attn.to_out.weight)
+                extra = [extra_top] if (bi == 0 and extra_top is not None) else []
+                on_side(lambda dqkv=dqkv, dh=dh, dxo=dxo, dx1=dx1, a=a, gq=gq, gw1=gw1, gw2=gw2, gwo=gwo, extra=extra: self.gemm_tn_acc_group(
                     [(dqkv, a["xn_b"], gq, 3 * D, D), (dh, a["x1n_b"], gw1, I, D), (dh[:, Ip:], a["x1n_b"], gw1[I:], I, D),
-                     (dxo, a["g"], gw2, D, I)], T))
+                     (dxo, a["g"], gw2, D, I), (dx1, a["o"], gwo, D, D)] + extra, T))
             else:
                 on_side(lambda dqkv=dqkv, a=a, gq=gq: tn(dqkv, a["xn_b"], gq, T, 3 * D, D))
             self.gemm_nt(dqkv, w["qkvT"], dx_other, T, D, 3 * D, residual=dx)          # d xn = dqkv @ Wqkv + d x1
@@ -911,13 +924,17 @@ class FusionEngine:
         with hip.cached_stream():
             return self._model_forward(batch, no_loss)
 
+    def can_forward_backward(self) -> bool:
+        m = self.model
+        return all(isinstance(m.encoders[n], (EmbeddedSequenceEncoder, TabularEncoder)) for n in m.modality_types)
+
     def forward_backward(self, batch):
         """forward + loss + backward WITHOUT autograd: the same kernels as ``model(batch)`` followed by ``loss.backward()``, issued
         from the calling thread (autograd runs a CUDA backward on its device thread; a stream capture that is cut into segments
         at the data-parallel collectives must begin and end its captures on one thread: graph.GraphedStep).  Every ``p.grad`` is
         the view of the flat gradient buffer.  Returns the output dict of the forward."""
         m = self.model
-        if not all(isinstance(m.encoders[n], (EmbeddedSequenceEncoder, TabularEncoder)) for n in m.modality_types):
+        if not self.can_forward_backward():
             raise NotImplementedError("forward_backward needs native encoders (a torch encoder's backward runs under autograd)")
         with hip.cached_stream(), torch.no_grad():
             self._last_direct = None
@@ -968,11 +985,11 @@ class FusionEngine:
         names = [t.name for t in m.loss_terms]
         out["losses"] = {n: terms[i] for i, n in enumerate(names)}
         if m.fcl and not m.zorro:
-            if getattr(self, "_fc_idx", None) is None:          # device index tensors, built once (a list index is an H2D copy)
-                self._fc_idx = torch.tensor([i for i, n in enumerate(names) if "fcl" in n], dtype=torch.long, device=self.device)
-                self._nf_idx = torch.tensor([i for i, n in enumerate(names) if "fcl" not in n], dtype=torch.long, device=self.device)
-            out["fcl_loss"] = torch.nan_to_num(terms.index_select(0, self._fc_idx)).mean()
-            out["no-fcl_loss"] = torch.nan_to_num(terms.index_select(0, self._nf_idx)).mean()
+            if getattr(self, "_fc_w", None) is None:          # (2, terms) averaging weights, built once: three small kernels per step
+                fc = torch.tensor([1.0 if "fcl" in n else 0.0 for n in names], dtype=torch.float32, device=self.device)
+                self._fc_w = torch.stack([fc / fc.sum().clamp(min=1), (1 - fc) / (1 - fc).sum().clamp(min=1)])
+            both = (torch.nan_to_num(terms)[None, :] * self._fc_w).sum(1)
+            out["fcl_loss"], out["no-fcl_loss"] = both[0], both[1]
         out["loss"] = loss.reshape(())
         out["modality_sample_mask"] = sample_mask
         if self.check_finite and self.check_finite != "deferred":

@@ -34,6 +34,7 @@ class GraphedStep:
     def __init__(self, model, optimizer, batch, clip: float = 2.0, dp=None, warmup: int = 3, overlap_wgrad: bool = False):
         self.model, self.opt, self.clip, self.dp = model, optimizer, float(clip), dp
         eng = model.engine
+        self.direct = eng.can_forward_backward()
         # weight-gradient GEMMs on the side stream: inside a graph the fork / join edges cost more than the overlap gains at
         # every size tried (one box, alternating processes: b = 32 21.9 ms with, 21.5 without; b = 8 7.90-8.02 with, 7.80 without)
         eng.overlap_wgrad = bool(overlap_wgrad)
@@ -114,6 +115,13 @@ class GraphedStep:
         if self.dp is not None:          # no autograd node (see _capture_segments); the same kernel chain
             out = self.model.engine.forward_backward(self.static)
             self.dp.finish_backward()
+            self.gnorm = _optim.clip_grad_norm_(self.model, self.clip) if self.clip else None
+            self.opt.step()
+            return out
+        if self.direct:
+            # one GPU, native encoders: the same direct chain (autograd's own bookkeeping around the step's single node is eight
+            # small kernels per replay: grad_output fills, the products with them, the accumulation into .grad)
+            out = self.model.engine.forward_backward(self.static)
             self.gnorm = _optim.clip_grad_norm_(self.model, self.clip) if self.clip else None
             self.opt.step()
             return out

@@ -14,7 +14,7 @@ import torch
 
 from .hip import call, ptr, stream_ptr
 
-SQNORM_WORDS = 1025          # include/mca_hip.h MCA_SQNORM_WORDS: the norm + the caller-owned scratch of mca_grad_sqnorm
+SQNORM_WORDS = 1026          # include/mca_hip.h MCA_SQNORM_WORDS: the norm + the caller-owned scratch of mca_grad_sqnorm
 
 
 def clip_grad_norm_(model, max_norm: float) -> torch.Tensor:
@@ -22,10 +22,9 @@ def clip_grad_norm_(model, max_norm: float) -> torch.Tensor:
     scaling itself is applied inside the next ``FusedAdamW.step()`` (gradients in memory stay unscaled)."""
     eng = model.engine
     sq = eng._ws.setdefault("sqnorm", torch.zeros(SQNORM_WORDS, dtype=torch.float32, device=eng.device))          # word 0 + scratch
-    sq[:1].zero_()
-    call("mca_grad_sqnorm", ptr(eng.gflat), eng.n_params, ptr(sq), stream_ptr())
+    call("mca_grad_sqnorm", ptr(eng.gflat), eng.n_params, ptr(sq), stream_ptr())          # word 0 = sum g^2, last word = the norm
     eng._pending_clip = float(max_norm)
-    return sq[0].sqrt().reshape(())
+    return sq[SQNORM_WORDS - 1].reshape(())
 
 
 class FusedAdamW(torch.optim.Optimizer):

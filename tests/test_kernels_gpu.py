@@ -92,6 +92,11 @@ def test_gemm_tn_acc(H, R, N, K, lda, ldb):
 
 @pytest.mark.parametrize("R,members", [
     (8192, [(1536, 512, 1536, 512), (1365, 512, 2816, 512), (1365, 512, 2816, 512), (512, 1365, 512, 1408)]),   # a layer's four
+    # a layer's five (with the out-projection): 52 tiles = 4 whole splits + 48 spans that end one tile's rows and begin the next's
+    (8200, [(1536, 512, 1536, 512), (1365, 512, 2816, 512), (1365, 512, 2816, 512), (512, 1365, 512, 1408), (512, 512, 512, 512)]),
+    # ... and the pooling key/value projection on top (the top layer's launch), at the b = 8 row count
+    (20304, [(1536, 512, 1536, 512), (1365, 512, 2816, 512), (1365, 512, 2816, 512), (512, 1365, 512, 1408), (512, 512, 512, 512),
+             (1024, 512, 1024, 512)]),
     (4100, [(512, 512, 512, 512), (300, 700, 304, 704), (1024, 256, 1024, 256), (256, 256, 256, 256), (515, 260, 520, 264)]),
     (5000, [(512, 512, 512, 512), (100, 512, 104, 512)]),          # a member the grouped kernel does not take -> single launches
     (300, [(512, 512, 512, 512), (512, 256, 512, 256)]),           # too few rows -> single launches
@@ -112,6 +117,15 @@ def test_gemm_tn_acc_group(H, R, members):
     torch.cuda.synchronize()
     for (A, B, Cg), ref in zip(keep, refs):
         assert rel(Cg, ref) < 2e-5
+    # uniform row splits (knob 3: the partition without the tile-major line) add the same products once more
+    H.lib().mca_debug_set(3, 3)
+    try:
+        H.call("mca_gemm_tn_acc_group", C.byref(arr), len(members), R, H.stream_ptr())
+        torch.cuda.synchronize()
+    finally:
+        H.lib().mca_debug_set(3, 0)
+    for (A, B, Cg), ref in zip(keep, refs):
+        assert rel(Cg - A[:, :Cg.shape[0]].float().t() @ B[:, :Cg.shape[1]].float(), ref) < 4e-5
 
 
 # ------------------------------------------------------------------------------------------- LayerNorm
@@ -1026,9 +1040,9 @@ def test_clip_adamw(H):
         gn = torch.nn.utils.clip_grad_norm_([p_ref], 2.0)
         opt.step()
         gd = grad.cuda()
-        sq = torch.zeros(1025, device="cuda")          # MCA_SQNORM_WORDS: the norm + the caller-owned scratch
+        sq = torch.full((1026,), 7.0, device="cuda")          # MCA_SQNORM_WORDS: sum g^2, the caller-owned scratch, the norm
         H.call("mca_grad_sqnorm", gd.data_ptr(), n, sq.data_ptr(), H.stream_ptr())
-        assert abs(float(sq[0].sqrt()) - float(gn)) < 1e-4 * float(gn)
+        assert abs(float(sq[0].sqrt()) - float(gn)) < 1e-4 * float(gn) and float(sq[1025]) == float(sq[0].sqrt())
         H.call("mca_adamw_step", p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.01,
                1 - 0.9 ** step, 1 - 0.999 ** step, 2.0, sq.data_ptr(), None, None, H.stream_ptr())
         err = (p.cpu() - p_ref.detach()).abs().max()
