@@ -330,16 +330,18 @@ def main():
             eng.overlap_wgrad = False
         step()
         eng.overlap_wgrad = saved
-    if graphed is not None and not args.no_kernel_timing:
-        # the sampled steps of a replayed loop run their body eagerly under HIP-event timing: that form is warmed up here, outside
-        # the timed region (b = 8: the first such step stalled ~90 ms inside its first fused out-projection launch, inflating
-        # a 40-step measurement from 7.2 to 9.6 ms per step)
-        hip.profile_start(("mca_gemm_nt_lnres",))
-        graphed.step(eager=True)
-        hip.profile_stop()
     timed = ("mca_attn_bwd_prep", "mca_attn_vmean_if_needed", "mca_attn_vmean", "mca_layernorm_fwd", "mca_layernorm_bwd", "mca_attn_fwd", "mca_attn_fwd_fp8", "mca_attn_quant_mxfp8", "mca_attn_bwd_dq", "mca_attn_bwd_dkv", "mca_attn_bwd_dq_fp8", "mca_attn_bwd_dkv_fp8", "mca_attn_quant_bwd_mxfp8", "mca_gemm_nt", "mca_gemm_nt_lnres", "mca_gemm_nt_geglu_fwd", "mca_gemm_nt_geglu_bwd",
              "mca_gemm_tn_acc", "mca_gemm_tn_acc_group")
     kernel_timing = not args.no_kernel_timing
+    if graphed is not None and kernel_timing:
+        # The sampled steps of a replayed loop run their body eagerly with an event pair around every launch.  That exact form is
+        # run once here, outside the timed region: in a process that is not the first on its box the first such step stalls
+        # ~90-100 ms (b = 32: 120.9 ms for the step instead of 23.2; `--step-times`), which a 20-step measurement reports as
+        # 26.1 instead of 21.1 ms per step.
+        hip.profile_start(timed)
+        torch.cuda.synchronize()
+        graphed.step(eager=True)
+        hip.profile_stop()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
