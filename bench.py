@@ -83,7 +83,7 @@ class GpuStateSampler:
 MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic GFLOP per sample per step, mask-aware, 2 flop/MAC, bwd = 2 x fwd
 STEP_GFLOP = {"cmu_mca": 334.8, "cmu_mma": 337.4, "long_mca": 885.7}
-PMC_JSON = os.path.join("profiles", "r03_hbm_traffic_pmc.json")
+PMC_JSON = os.path.join("profiles", "r04_hbm_traffic_pmc.json")
 
 
 def pmc_traffic(kernel_key: str):

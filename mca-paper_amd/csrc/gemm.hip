@@ -1650,6 +1650,7 @@ __global__ __launch_bounds__(512) void gemm_tn_256x256_kernel(const u16* __restr
 // Several weight gradients over the SAME token rows in one launch (the four of a transformer layer): the launch then has
 // 48 tiles instead of 12, so a full round of workgroups needs 5 row splits instead of 21 and the fp32 atomic traffic (every
 // split adds the whole gradient once; a quarter to a third of the single launches' time) drops four-fold.
+#define TN_SPAN_RELIEF 1536       // rows a two-tile workgroup is relieved of (mca_gemm_tn_acc_group; measured: tools/bench_tn_group.py)
 struct tn_group {
   const u16* A[MCA_TN_MAX_GROUP];
   const u16* B[MCA_TN_MAX_GROUP];
@@ -1661,10 +1662,10 @@ struct tn_group {
   // Balanced row partition: every workgroup reduces `unit` rows of one tile's worth of work.  The first n_full * tiles
   // workgroups take whole (tile, split) cells of `unit` rows as before (the tiles of one split next to each other on an XCD, so
   // that an operand row block is fetched into one L2 once); the rows left over, [n_full * unit, R) of every tile, form a second,
-  // tile-major line of tiles * (R - n_full * unit) row-units that the remaining workgroups cut into equal spans of `unit`: such a
+  // tile-major line of tiles * (R - n_full * unit) row-units that the remaining workgroups cut into equal spans of `span` rows (a little less than `unit`): such a
   // workgroup finishes one tile's rest and starts the next one's (two atomic epilogues).  Any number of tiles then fills the
   // chip's one round of workgroups: 52 tiles are 4 full splits on 208 CUs + 48 spans, not 4 splits with 48 CUs idle.
-  int unit, n_full;
+  int unit, n_full, span;          // rows of a whole cell, cells per tile, rows of a span of the line
 };
 __global__ __launch_bounds__(512) void gemm_tn_256x256_group_kernel(tn_group g, int dbg) {
   extern __shared__ __attribute__((aligned(16))) u16 ldst[];
@@ -1679,8 +1680,8 @@ __global__ __launch_bounds__(512) void gemm_tn_256x256_group_kernel(tn_group g, 
   // this workgroup's span [s, e) of the line (a whole cell is the degenerate case: one segment, no line arithmetic)
   int64_t s = 0, e = 0;
   if (lin >= n_cells) {
-    s = (int64_t)(lin - n_cells) * g.unit;
-    e = s + g.unit;
+    s = (int64_t)(lin - n_cells) * g.span;
+    e = s + g.span;
     const int64_t line = (int64_t)g.tiles * rest;
     if (e > line) e = line;
   }
@@ -1797,21 +1798,38 @@ extern "C" int mca_gemm_tn_acc_group(const mca_tn_desc* d, int n, int64_t R, mca
   }
   for (int i = n; i <= MCA_TN_MAX_GROUP; i++) g.first_tile[i] = tiles;
   g.n = n; g.R = (int)R; g.tiles = tiles;
-  // one full round of workgroups (1 per CU), every one with the same `unit` rows of one tile (struct tn_group): at least 4 steps
-  // of 32 rows each.  knob 3 = s: s uniform splits and no line (the round-3 partition, A/B)
+  // One full round of workgroups (1 per CU).  n_full whole splits of `unit` rows per tile + `spans` workgroups on the tile-major
+  // line of the rows left over (struct tn_group).  A span workgroup pays two pipeline fills and two atomic epilogues, so it gets
+  // `relief` rows less than a cell: unit = (tiles * R + spans * relief) / CUs.  At least 4 steps of 32 rows per workgroup.
+  // knob 3 = s: s uniform splits and no line (the round-3 partition, A/B); knob 6 = r + 1: relief of 32 r rows
   const int cus = num_cus();
-  int64_t unit = ((int64_t)tiles * R + cus - 1) / cus;
-  if (g_knob[3] > 0) unit = (R + g_knob[3] - 1) / g_knob[3];
-  if (unit < 4 * BR2) unit = 4 * BR2;
-  unit = (unit + BR2 - 1) / BR2 * BR2;
-  if (unit > R) unit = (R + BR2 - 1) / BR2 * BR2;
-  int64_t n_full = R / unit;                                  // whole cells per tile
-  if (g_knob[3] <= 0 && n_full * tiles > cus) n_full = cus / tiles;
-  int64_t rest = R - n_full * unit;
-  if (g_knob[3] > 0 && rest > 0) { n_full += 1; rest = 0; }          // uniform splits: the last one is short
-  const int64_t spans = rest > 0 ? ((int64_t)tiles * rest + unit - 1) / unit : 0;
+  const int64_t relief = g_knob[6] > 0 ? 32 * (int64_t)(g_knob[6] - 1) : TN_SPAN_RELIEF;
+  int64_t n_full = cus / tiles, unit, rest, span = 0, spans = 0;
+  if (g_knob[3] > 0) {
+    unit = ((R + g_knob[3] - 1) / g_knob[3] + BR2 - 1) / BR2 * BR2;
+    n_full = (R + unit - 1) / unit; rest = 0;                 // uniform splits: the last one is short
+  } else {
+    for (;;) {
+      const int64_t sp = cus - n_full * tiles;                // workgroups left for the line
+      unit = ((int64_t)tiles * R + sp * relief + cus - 1) / cus;
+      if (unit < 4 * BR2) unit = 4 * BR2;
+      unit = (unit + BR2 - 1) / BR2 * BR2;
+      rest = R - n_full * unit;
+      if (rest >= 0 || n_full == 0) break;
+      n_full--;                                               // (tiny R: fewer whole splits)
+    }
+    if (n_full == 0) { rest = R; }
+    if (rest > 0) {
+      const int64_t sp = cus - n_full * tiles > 0 ? cus - n_full * tiles : cus;
+      span = ((int64_t)tiles * rest + sp - 1) / sp;
+      if (span < 4 * BR2) span = 4 * BR2;
+      span = (span + BR2 - 1) / BR2 * BR2;
+      spans = ((int64_t)tiles * rest + span - 1) / span;
+    }
+  }
   const int64_t grid = n_full * tiles + spans;
   if (grid <= 0 || grid > (1 << 30)) return MCA_E_UNSUPPORTED;
+  g.span = (int)span;
   g.unit = (int)unit; g.n_full = (int)n_full;
   static bool attr_dev[64] = {false}; bool& attr = *mca_dev_flag(attr_dev);
   if (!attr) {
