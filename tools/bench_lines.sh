@@ -5,16 +5,16 @@ set -o pipefail
 OUT="${1:-gpurun_out/lines}"; mkdir -p "$OUT"
 run() { local tag="$1"; shift; echo "== $tag: $*"; timeout -k 10 500 "$@" > "$OUT/$tag.json" 2> "$OUT/$tag.err" || { echo "FAILED $tag"; tail -3 "$OUT/$tag.err"; return 1; }; cut -c1-170 "$OUT/$tag.json" | tail -1; }
 run b32_default python bench.py &&
-run b32_nosample python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-kernel-timing &&
-run b32_host python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-kernel-timing --inputs host &&
-run b32_ragged python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-kernel-timing --lengths uniform --p-drop 0.2 &&
-run b8_nosample python bench.py --batch 8 --steps 60 --warmup 5 --no-cpu-baseline --no-kernel-timing &&
-run b8_mma python bench.py --batch 8 --variant mma --p-drop 0.4 --steps 60 --warmup 5 --no-cpu-baseline --no-kernel-timing &&
-run eao_b8 python bench.py --variant eao --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-timing &&
-run long_bf16 python bench.py --workload long --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing &&
-run long_fp8 python bench.py --workload long --attn fp8 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing &&
-run long_bf16_again python bench.py --workload long --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing &&
-run long_fp8_again python bench.py --workload long --attn fp8 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing
+run b32_nosample python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-kernel-timing --sustain-seconds 0 &&
+run b32_host python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-kernel-timing --sustain-seconds 0 --inputs host &&
+run b32_ragged python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-kernel-timing --sustain-seconds 0 --lengths uniform --p-drop 0.2 &&
+run b8_nosample python bench.py --batch 8 --steps 60 --warmup 5 --no-cpu-baseline --no-kernel-timing --sustain-seconds 0 &&
+run b8_mma python bench.py --batch 8 --variant mma --p-drop 0.4 --steps 60 --warmup 5 --no-cpu-baseline --no-kernel-timing --sustain-seconds 0 &&
+run eao_b8 python bench.py --variant eao --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-timing --sustain-seconds 0 &&
+run long_bf16 python bench.py --workload long --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --sustain-seconds 0 &&
+run long_fp8 python bench.py --workload long --attn fp8 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --sustain-seconds 0 &&
+run long_bf16_again python bench.py --workload long --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --sustain-seconds 0 &&
+run long_fp8_again python bench.py --workload long --attn fp8 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --sustain-seconds 0
 python3 - "$OUT" <<'PY'
 import glob, json, os, sys
 out = []
