@@ -47,3 +47,31 @@ def test_bench_two_ranks_reports_its_launch_choice_and_collectives():
         assert cfg["launch"] == "eager" and ch["guard_ms_per_step"]["replay"] > 1.05 * ch["guard_ms_per_step"]["eager"]
     # value = samples of ALL ranks / the slowest rank's time
     assert abs(rec["value"] - 16 * 3 / (rec["ms_per_step"] * 3e-3)) <= 1e-2 * rec["value"]
+
+
+def test_bench_single_gpu_line_follows_the_contract():
+    """`python bench.py --steps 4 --warmup 2` on one GPU (small batch, no CPU baseline: the contract's other fields): ONE JSON
+    line with BASELINE's metric and unit, whole-job value consistent with ms_per_step, `roofline` of the dominant launch class
+    (achieved / peak = frac, live HIP events of the one eager sampled step), the workload named in `config`, the clock the figure was
+    measured at, and the steady-state rate beside - never instead of - `value`."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--batch", "4", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                        "--sustain-seconds", "3"], capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["metric"].startswith("training samples/sec") and rec["unit"] == "samples/s" and rec["higher_is_better"] is True
+    assert rec["n_gpus"] == 1 and rec["steps"] == 4 and rec["warmup"] == 2 and rec["scaling"] == "weak" and rec["vs_baseline"] is None
+    assert rec["dtype"] == "bf16" and rec["data"] == "synthetic" and "model" not in rec["config"] and "workload" in rec["config"]
+    assert abs(rec["value"] - 4 * 4 / (rec["ms_per_step"] * 4e-3)) <= 1e-2 * rec["value"]
+    rf = rec["roofline"]
+    assert rf["bound"] in ("mfma", "hbm") and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1 and rf["avg_launch_us"] > 0 and rf["sampled_steps"] == 1
+    assert rec["config"]["launch_choice"]["chosen"] == "graph" and "hipGraph replay" in rec["config"]["launch"]
+    gs = rec["config"]["gpu_state_rank0"]
+    assert gs["samples"] >= 1 and (gs["sclk_mhz_median"] is None or 100 < gs["sclk_mhz_median"] < 3000)
+    su = rec["config"]["sustained"]
+    assert su["samples_per_s"] > 0 and su["steps"] >= 50 and "not `value`" in su["note"]
+    assert "cpu_baseline" not in rec and rec["kernels"]["mca_attn_bwd_dkv/layer"]["launches_per_step"] == 5
