@@ -105,6 +105,21 @@ encoders_dict: Dict[str, type] = {
 # ------------------------------------------------------------------------------------------------------
 # collators (host side; run in DataLoader workers)
 # ------------------------------------------------------------------------------------------------------
+def _batch_buffer(shape, fill, dtype):
+    """The output buffer of a collator, filled with ``fill``.  Inside a DataLoader worker it is allocated in shared memory, as
+    torch's default_collate does: a batch built in ordinary memory is copied into shared memory again when the worker hands it
+    to the loop (58 MB per CMU batch of 32: 46 ms per batch with 8 workers against 12 ms, the difference between a loader-bound
+    and a GPU-bound training loop, profiles/r04_slow_regime.md).  Same values either way."""
+    if torch.utils.data.get_worker_info() is None:
+        return torch.full(shape, fill, dtype=dtype)
+    proto = torch.empty(0, dtype=dtype)
+    numel = 1
+    for d in shape:
+        numel *= int(d)
+    storage = proto._typed_storage()._new_shared(numel, device="cpu")
+    return proto.new(storage).resize_(*shape).fill_(fill)
+
+
 class SequenceCollator:
     """1-D sequences / dense tables padded (or cropped) to ``pad_len`` with ``pad_token``; ``attention_mask`` is int64 with
     1 where the padded value equals pad_token (encoders.py:286-311).  A missing sample (None) becomes an all-pad row.
@@ -122,7 +137,7 @@ class SequenceCollator:
         for x in rows:
             d = x.dtype if x is not None else torch.float32
             dtype = d if dtype is None else torch.promote_types(dtype, d)
-        out = torch.full((len(rows), self.pad_len), fill, dtype=dtype or torch.float32)
+        out = _batch_buffer((len(rows), self.pad_len), fill, dtype or torch.float32)
         for i, x in enumerate(rows):
             if x is not None and x.numel():
                 n = min(x.shape[-1], self.pad_len)          # longer rows are cropped (the reference's negative F.pad does that)
@@ -150,8 +165,8 @@ class EmbeddedSequenceCollator:
         first = next((x for x in seqs if x is not None), None)
         width = first.shape[-1] if first is not None else self.embedding_size
         dtype = first.dtype if first is not None else torch.float32
-        tokens = torch.full((len(seqs), self.pad_len, width), self.fill_value, dtype=dtype)
-        mask = torch.ones(len(seqs), self.pad_len, dtype=torch.bool)
+        tokens = _batch_buffer((len(seqs), self.pad_len, width), self.fill_value, dtype)
+        mask = _batch_buffer((len(seqs), self.pad_len), True, torch.bool)
         for i, x in enumerate(seqs):
             if x is None:
                 continue

@@ -210,3 +210,38 @@ def test_every_reference_training_yaml_is_accepted(pkg, golden_dir, tmp_path):
     assert n_built >= 9 and n_eao >= 1 and len(refused) >= 1
     unrunnable = json.load(open(os.path.join(golden_dir, "ref_unrunnable.json")))
     assert unrunnable["MCA(mean_pool=True).forward"]["type"] == "RuntimeError"
+
+
+class _RaggedSamples(torch.utils.data.Dataset):
+    """{modality: {"data": (len, emb)}} samples with ragged lengths and a missing modality now and then (module level: workers pickle it)"""
+
+    def __init__(self, n=12):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(100 + i)
+        a = torch.randn(int(torch.randint(1, 40, (1,), generator=g)), 7, generator=g)
+        b = None if i % 5 == 3 else torch.randn(int(torch.randint(1, 9, (1,), generator=g)), 3, generator=g)
+        return {"audio": {"data": a}, "video": {"data": b}}
+
+
+def test_collators_in_loader_workers_build_the_same_batch_in_shared_memory(pkg):
+    """Inside a DataLoader worker the collators fill buffers allocated in shared memory (as torch's default_collate does), so the
+    batch is not copied a second time on its way to the training loop; the values are those of the in-process call."""
+    from torch.utils.data import DataLoader
+    mod_cfg = {"audio": {"type": "embedded_sequence", "pad_len": 32, "embedding_size": 7, "data_col_name": "data"},
+               "video": {"type": "embedded_sequence", "pad_len": 8, "embedding_size": 3, "data_col_name": "data"}}
+    col = pkg.MultimodalCollator(mod_cfg)
+    ds = _RaggedSamples()
+    here = list(DataLoader(ds, collate_fn=col, batch_size=4, num_workers=0))
+    there = list(DataLoader(ds, collate_fn=col, batch_size=4, num_workers=2))
+    assert len(here) == len(there) == 3
+    for a, b in zip(here, there):
+        for m in mod_cfg:
+            for k in ("tokens", "attention_mask"):
+                assert a[m][k].dtype == b[m][k].dtype and torch.equal(a[m][k], b[m][k])
+                assert b[m][k].is_shared() and not a[m][k].is_shared()
+    assert bool(here[0]["video"]["attention_mask"][3].all()) and float(here[0]["video"]["tokens"][3].abs().max()) == 0.0          # the missing sample: an all-pad row
