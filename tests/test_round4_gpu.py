@@ -75,3 +75,31 @@ def test_bench_single_gpu_line_follows_the_contract():
     su = rec["config"]["sustained"]
     assert su["samples_per_s"] > 0 and su["steps"] >= 50 and "not `value`" in su["note"]
     assert "cpu_baseline" not in rec and rec["kernels"]["mca_attn_bwd_dkv/layer"]["launches_per_step"] == 5
+
+
+def test_logged_norms_from_the_flat_buffers_equal_the_per_tensor_walk(pkg):
+    P = pkg
+    """utils.training.get_grad_norm / get_param_norm (logged every step, train_accel_gpu.py:126-130) read the engine's flat
+    buffers after a native backward: same values as the reference's walk over the tensors (first parameter skipped, its quirk),
+    and the full norm equals what clip_grad_norm_ reports."""
+    import importlib
+    from util_small import small_config, to_device
+    from utils.training import get_grad_norm, get_param_norm
+    optim = importlib.import_module("mca-paper_amd.optim")
+    cfg = small_config("mca")
+    model = P.build_model(cfg).cuda()
+    batch = to_device(P.data.synthetic_batch(cfg, 6, seed=5, p_drop=0.3), "cuda")
+    out = model(batch)
+    optim.FusedAdamW(model, lr=1e-3).zero_grad()
+    out["loss"].backward()
+    total = float(optim.clip_grad_norm_(model, 2.0))
+    params = list(model.parameters())
+    assert all(p.grad.data_ptr() == model.engine.grad_of(p).data_ptr() for p in params)          # the flat path is the one taken
+    walk = lambda ts: float(sum(float(t.double().pow(2).sum()) for t in ts) ** 0.5)
+    g_all, g_rest = walk([p.grad for p in params]), walk([p.grad for p in params[1:]])
+    assert abs(float(get_grad_norm(model)) - g_rest) <= 1e-5 * g_rest and abs(float(get_grad_norm(model, skip_first=False)) - g_all) <= 1e-5 * g_all
+    assert abs(total - g_all) <= 1e-5 * g_all and get_grad_norm(model).dtype == torch.float32 and get_grad_norm(model).shape == (1,)
+    p_rest = walk([p.detach() for p in params[1:]])
+    assert abs(float(get_param_norm(model)) - p_rest) <= 1e-6 * p_rest
+    params[3].grad = params[3].grad.clone()          # a gradient that is not the flat view: the walk is taken, same value
+    assert abs(float(get_grad_norm(model)) - g_rest) <= 1e-5 * g_rest

@@ -7,7 +7,8 @@ The two norms reproduce the reference's VALUES, quirk included: both fetch the d
 very generator they then loop over (utils/training.py:50-51,61-62), so the FIRST parameter of ``model.parameters()`` is in
 neither norm (checked by running the reference's functions: tests/test_host_cpu.py states the contract).  ``skip_first=False``
 gives the norm over every parameter.  ``get_param_norm`` reads the engine's flat buffer when the model runs on the native
-engine (one reduction instead of one per tensor); ``get_grad_norm`` walks ``p.grad`` (views of the flat gradient buffer)."""
+engine (one reduction instead of one per tensor), and so does ``get_grad_norm`` when every ``p.grad`` is its view of the flat
+gradient buffer (always, after a native backward); otherwise it walks ``p.grad``."""
 import torch
 
 
@@ -63,6 +64,15 @@ def get_grad_norm(model, norm_type=2.0, skip_first=True):
     (utils/training.py:59-70)."""
     norm_type = float(norm_type)
     params = list(model.parameters())
+    eng = _engine_of(model)
+    if eng is not None and norm_type == 2.0 and params and all(
+            p.grad is not None and p.grad.data_ptr() == eng.grad_of(p).data_ptr() for p in params):
+        # after a native backward every p.grad is its view of the flat gradient buffer: one reduction instead of three small
+        # kernels per tensor (the loop logs this every step, train_accel_gpu.py:126-130)
+        sq = eng.gflat.double().pow(2).sum()          # alignment padding of the flat buffer stays zero
+        if skip_first:
+            sq = sq - params[0].grad.detach().double().pow(2).sum()
+        return sq.clamp_min(0).sqrt().float().reshape(1)
     total = torch.zeros(1, dtype=torch.float32, device=params[0].device)
     for p in params[1 if skip_first else 0:]:
         if p.grad is not None:
