@@ -13,7 +13,8 @@ extern "C" {
  *    0  persistent NT GEMMs: 8 = s_memtime stamps of workgroup 0 (tools/trace_persist.py), 32 * P = P row panels per tile group
  *    1  = 1: the 128 x 128 NT kernel for every shape;   2  bit 1: weight-gradient 128 x 128 kernel without its atomics (timing)
  *    3  > 0: number of (uniform) row splits of the weight-gradient kernels;   4  = 1: no residual prefetch in the fp32 + residual NT kernel
- *    6  = r + 1: the grouped weight-gradient launch gives its two-tile workgroups 32 r rows less than the others
+ *    6  = r + 1: the grouped weight-gradient launch gives its two-tile workgroups 32 r rows less than the others; -(r + 1): the
+ *       same with a purely tile-major line (no owner segments)
  *    5  weight-gradient kernel: 1 = 128 x 128, 2 = 256 x 128 where 256 x 256 would be chosen
  *    7  1 = one-tile-per-workgroup NT kernels only, 3 = persistent kernel for fp32 + residual as well;   10  = 1: 256 x 128 persistent
  *       kernel where the 256 x 256 one would be chosen;   11  = 1: one launch per member of a weight-gradient group

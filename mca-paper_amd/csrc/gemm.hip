@@ -1664,8 +1664,13 @@ struct tn_group {
   // that an operand row block is fetched into one L2 once); the rows left over, [n_full * unit, R) of every tile, form a second,
   // tile-major line of tiles * (R - n_full * unit) row-units that the remaining workgroups cut into equal spans of `span` rows (a little less than `unit`): such a
   // workgroup finishes one tile's rest and starts the next one's (two atomic epilogues).  Any number of tiles then fills the
-  // chip's one round of workgroups: 52 tiles are 4 full splits on 208 CUs + 48 spans, not 4 splits with 48 CUs idle.
+  // chip's one round of workgroups: 52 tiles are 4 full splits on 208 CUs + 48 spans, not 4 splits with 48 CUs idle (worth 7 % at
+  // b = 32, not 19 %: the launch is bound by the shared L2 -> LDS and atomic paths, tools/bench_tn_group.py).
   int unit, n_full, span;          // rows of a whole cell, cells per tile, rows of a span of the line
+  // own > 0 (when the line's workgroups are at least half as many as the tiles): the first `own` of them each take the whole
+  // rest of "their" tile first - rows [n_full * unit, R) of tiles 0 .. own - 1, the SAME rows at the same time, so these segments
+  // share operand rows through L2 like the cells do - and only tiles own .. tiles - 1 form the line (spans of `span` rows)
+  int own;
 };
 __global__ __launch_bounds__(512) void gemm_tn_256x256_group_kernel(tn_group g, int dbg) {
   extern __shared__ __attribute__((aligned(16))) u16 ldst[];
@@ -1676,13 +1681,18 @@ __global__ __launch_bounds__(512) void gemm_tn_256x256_group_kernel(tn_group g, 
   const uint64_t c0 = probe ? __builtin_amdgcn_s_memtime() : 0, t0 = probe ? __builtin_amdgcn_s_memrealtime() : 0;
 #endif
   const int n_cells = g.n_full * g.tiles;
-  const int row0 = g.n_full * g.unit, rest = g.R - row0;          // rows [row0, R) of every tile: the tile-major line
-  // this workgroup's span [s, e) of the line (a whole cell is the degenerate case: one segment, no line arithmetic)
+  const int row0 = g.n_full * g.unit, rest = g.R - row0;          // rows [row0, R) of every tile
+  // this workgroup's span [s, e) of the tile-major line over tiles line0 .. tiles - 1 (a whole cell is the degenerate case: one
+  // segment, no line arithmetic)
+  const int line0 = g.own;
   int64_t s = 0, e = 0;
+  bool own_pending = false;
   if (lin >= n_cells) {
-    s = (int64_t)(lin - n_cells) * g.span;
+    const int j = lin - n_cells;
+    own_pending = j < g.own;
+    s = (int64_t)j * g.span;
     e = s + g.span;
-    const int64_t line = (int64_t)g.tiles * rest;
+    const int64_t line = (int64_t)(g.tiles - line0) * rest;
     if (e > line) e = line;
   }
   bool first = true;
@@ -1691,10 +1701,15 @@ __global__ __launch_bounds__(512) void gemm_tn_256x256_group_kernel(tn_group g, 
     if (lin < n_cells) {
       tile_all = lin % g.tiles;
       r_begin = (lin / g.tiles) * g.unit; r_end = r_begin + g.unit;
+    } else if (own_pending) {
+      own_pending = false;
+      tile_all = lin - n_cells;
+      r_begin = row0; r_end = g.R;
     } else {
       if (s >= e) break;
-      tile_all = (int)(s / rest);
-      const int off = (int)(s - (int64_t)tile_all * rest);
+      const int t = (int)(s / rest);
+      tile_all = line0 + t;
+      const int off = (int)(s - (int64_t)t * rest);
       int len = rest - off; if ((int64_t)len > e - s) len = (int)(e - s);
       r_begin = row0 + off; r_end = r_begin + len;
       s += len;
@@ -1801,35 +1816,54 @@ extern "C" int mca_gemm_tn_acc_group(const mca_tn_desc* d, int n, int64_t R, mca
   // One full round of workgroups (1 per CU).  n_full whole splits of `unit` rows per tile + `spans` workgroups on the tile-major
   // line of the rows left over (struct tn_group).  A span workgroup pays two pipeline fills and two atomic epilogues, so it gets
   // `relief` rows less than a cell: unit = (tiles * R + spans * relief) / CUs.  At least 4 steps of 32 rows per workgroup.
-  // knob 3 = s: s uniform splits and no line (the round-3 partition, A/B); knob 6 = r + 1: relief of 32 r rows
+  // knob 3 = s: s uniform splits and no line (the round-3 partition, A/B); knob 6 = r + 1: relief of 32 r rows, -(r + 1): the same without owner segments
   const int cus = num_cus();
-  const int64_t relief = g_knob[6] > 0 ? 32 * (int64_t)(g_knob[6] - 1) : TN_SPAN_RELIEF;
-  int64_t n_full = cus / tiles, unit, rest, span = 0, spans = 0;
+  const int k6 = g_knob[6];
+  const int64_t relief = k6 != 0 ? 32 * (int64_t)((k6 < 0 ? -k6 : k6) - 1) : TN_SPAN_RELIEF;
+  int64_t n_full = cus / tiles, unit, rest, span = 0, spans = 0, own = 0;
   if (g_knob[3] > 0) {
     unit = ((R + g_knob[3] - 1) / g_knob[3] + BR2 - 1) / BR2 * BR2;
     n_full = (R + unit - 1) / unit; rest = 0;                 // uniform splits: the last one is short
   } else {
-    for (;;) {
-      const int64_t sp = cus - n_full * tiles;                // workgroups left for the line
-      unit = ((int64_t)tiles * R + sp * relief + cus - 1) / cus;
+    const int64_t sp0 = cus - n_full * tiles, left = tiles - sp0;          // line workgroups; tiles without an owner among them
+    const bool owners = k6 >= 0 && n_full > 0 && sp0 > 0 && left > 0 && left <= sp0;
+    if (owners) {
+      // a line workgroup reduces rest + left * rest / sp0 rows, a cell `unit` = that + relief:  rest * f + relief = unit,
+      // rest = R - n_full * unit,  f = 1 + left / sp0
+      const double f = 1.0 + (double)left / (double)sp0;
+      unit = (int64_t)(((double)R * f + (double)relief) / ((double)n_full * f + 1.0));
       if (unit < 4 * BR2) unit = 4 * BR2;
       unit = (unit + BR2 - 1) / BR2 * BR2;
       rest = R - n_full * unit;
-      if (rest >= 0 || n_full == 0) break;
-      n_full--;                                               // (tiny R: fewer whole splits)
     }
-    if (n_full == 0) { rest = R; }
-    if (rest > 0) {
-      const int64_t sp = cus - n_full * tiles > 0 ? cus - n_full * tiles : cus;
-      span = ((int64_t)tiles * rest + sp - 1) / sp;
-      if (span < 4 * BR2) span = 4 * BR2;
+    if (owners && rest >= BR2) {
+      own = sp0;
+      span = (left * rest + sp0 - 1) / sp0;
       span = (span + BR2 - 1) / BR2 * BR2;
-      spans = ((int64_t)tiles * rest + span - 1) / span;
+      spans = sp0;
+    } else {
+      for (;;) {
+        const int64_t sp = cus - n_full * tiles;                // workgroups left for the line
+        unit = ((int64_t)tiles * R + sp * relief + cus - 1) / cus;
+        if (unit < 4 * BR2) unit = 4 * BR2;
+        unit = (unit + BR2 - 1) / BR2 * BR2;
+        rest = R - n_full * unit;
+        if (rest >= 0 || n_full == 0) break;
+        n_full--;                                               // (tiny R: fewer whole splits)
+      }
+      if (n_full == 0) { rest = R; }
+      if (rest > 0) {
+        const int64_t sp = cus - n_full * tiles > 0 ? cus - n_full * tiles : cus;
+        span = ((int64_t)tiles * rest + sp - 1) / sp;
+        if (span < 4 * BR2) span = 4 * BR2;
+        span = (span + BR2 - 1) / BR2 * BR2;
+        spans = ((int64_t)tiles * rest + span - 1) / span;
+      }
     }
   }
   const int64_t grid = n_full * tiles + spans;
   if (grid <= 0 || grid > (1 << 30)) return MCA_E_UNSUPPORTED;
-  g.span = (int)span;
+  g.span = (int)span; g.own = (int)own;
   g.unit = (int)unit; g.n_full = (int)n_full;
   static bool attr_dev[64] = {false}; bool& attr = *mca_dev_flag(attr_dev);
   if (!attr) {

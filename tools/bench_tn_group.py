@@ -1,6 +1,6 @@
 """The grouped weight-gradient launch on the exact members of a CMU layer (with the out-projection; the top layer's also with the
 pooling key / value projection), per row partition: uniform splits (knob 3) against the balanced partition with a relief of r rows
-for the workgroups that finish one tile and begin the next (knob 6).  usage: bench_tn_group.py [batch ...]"""
+for the workgroups that take more than one tile (knob 6 = r / 32 + 1; negative: without owner segments, a purely tile-major line).  usage: bench_tn_group.py [batch ...]"""
 import ctypes as C, importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 H = importlib.import_module("mca-paper_amd.hip"); H.lib()
@@ -29,7 +29,7 @@ for b in [int(a) for a in sys.argv[1:]] or [8, 32]:
         run = lambda: H.call("mca_gemm_tn_acc_group", C.byref(arr), len(members), R, H.stream_ptr())
         row = f"b={b:3d} {label:36s}"
         for rnd in range(2):
-            for k3, k6, nm in ((4, 0, "4 splits"), (5, 0, "5 splits"), (0, 1, "bal r=0"), (0, 9, "r=256"), (0, 17, "r=512"), (0, 25, "r=768"), (0, 33, "r=1024"), (0, 49, "r=1536")):
+            for k3, k6, nm in ((4, 0, "4 splits"), (5, 0, "5 splits"), (0, -49, "line r=1536"), (0, 1, "own r=0"), (0, 17, "r=512"), (0, 33, "r=1024"), (0, 49, "r=1536"), (0, 65, "r=2048")):
                 H.lib().mca_debug_set(3, k3); H.lib().mca_debug_set(6, k6)
                 us = timeit(run)
                 row += f" | {nm} {us:6.1f}"
