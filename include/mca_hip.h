@@ -97,12 +97,14 @@ int mca_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const flo
 
 /* Backward of the above.  dy is read with the same (period, ldy, y_bstride) row mapping as y was
  * written; masked rows have zero gradient.  dx / dx_bf16 optional.  dgamma/dbeta (fp32[cols]) are
- * ACCUMULATED (atomics).                                                                         */
+ * ACCUMULATED (atomics).  dxsum (fp32[cols], may be NULL): += the column sums of dx, i.e. the bias
+ * gradient of the nn.Linear whose output this norm takes (encoders.py:189-192: Linear -> LayerNorm),
+ * without a second pass over dx.                                                                 */
 int mca_layernorm_bwd(const float* dy, int64_t ldy, int64_t y_bstride, int64_t period,
                       const float* x, int64_t ldx, const float* gamma,
                       const float* mean, const float* rstd, const uint8_t* rowmask,
                       float* dx, int64_t lddx, uint16_t* dx_bf16, int64_t ld_bf16,
-                      float* dgamma, float* dbeta, int64_t rows, int cols, mca_stream_t stream);
+                      float* dgamma, float* dbeta, float* dxsum, int64_t rows, int cols, mca_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * GEGLU (model.py:35-38): h = [a | gate] (two halves of width ip, ld 2*ip) -> g = gelu(gate)*a

@@ -187,14 +187,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in, const uint8_t* __restrict__ rowmask,
     float* __restrict__ dx, int64_t lddx, u16* __restrict__ dx_bf16, int64_t ld_bf16,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int cols) {
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dxsum, int64_t rows, int cols) {
   constexpr int NI = 16 / VEC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float dg[NI][VEC], db[NI][VEC];
+  float dg[NI][VEC], db[NI][VEC], ds[NI][VEC];
 #pragma unroll
   for (int i = 0; i < NI; i++)
 #pragma unroll
-    for (int j = 0; j < VEC; j++) { dg[i][j] = 0.f; db[i][j] = 0.f; }
+    for (int j = 0; j < VEC; j++) { dg[i][j] = 0.f; db[i][j] = 0.f; ds[i][j] = 0.f; }
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     const bool masked = rowmask && rowmask[row];
     const float* xr = x + row * ldx;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       if (c < cols) {
         float o[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; j++) o[j] = masked ? 0.f : rstd * (g[i][j] - s1 - xh[i][j] * s2);
+        for (int j = 0; j < VEC; j++) { o[j] = masked ? 0.f : rstd * (g[i][j] - s1 - xh[i][j] * s2); ds[i][j] += o[j]; }
         if (dxr) {
           if (VEC == 4) *reinterpret_cast<float4*>(dxr + c) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
           else dxr[c] = o[0];
@@ -251,15 +251,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   }
   // block reduction of the parameter-gradient partials through LDS, then one atomic per column
   __shared__ float red[4][1024];
-  for (int pass = 0; pass < 2; pass++) {
-    float* target = pass == 0 ? dgamma : dbeta;
+  for (int pass = 0; pass < 3; pass++) {
+    float* target = pass == 0 ? dgamma : (pass == 1 ? dbeta : dxsum);
     if (!target) continue;
 #pragma unroll
     for (int i = 0; i < NI; i++) {
       const int c = (lane + 64 * i) * VEC;
 #pragma unroll
       for (int j = 0; j < VEC; j++)
-        if (c + j < 1024) red[wave][c + j] = pass == 0 ? dg[i][j] : db[i][j];
+        if (c + j < 1024) red[wave][c + j] = pass == 0 ? dg[i][j] : (pass == 1 ? db[i][j] : ds[i][j]);
     }
     __syncthreads();
     for (int c = threadIdx.x; c < cols; c += 256) {
@@ -338,17 +338,53 @@ __global__ __launch_bounds__(256) void ln_bwd_trunk_kernel(const float* __restri
   }
 }
 
+// Parameter gradients only (no dx wanted: an encoder's input norm, encoders.py:189).  dgamma / dbeta are column sums over the
+// rows: thread = column, a slab of rows per workgroup (coalesced along the columns, no wavefront reductions; the row form above
+// spent 33 us on 12,000 x 74 values).
+__global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ dy, int64_t ldy, int64_t y_bstride, int64_t period,
+                                                             const float* __restrict__ x, int64_t ldx, const float* __restrict__ mean_in,
+                                                             const float* __restrict__ rstd_in, const uint8_t* __restrict__ rowmask,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int cols,
+                                                             int64_t rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  int64_t r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
+  if (c >= cols) return;
+  float dg = 0.f, db = 0.f;
+#pragma unroll 4
+  for (int64_t row = r0; row < r1; row++) {
+    if (rowmask && rowmask[row]) continue;
+    const float* dyr = period > 0 ? dy + (row / period) * y_bstride + (row % period) * ldy : dy + row * ldy;
+    const float d = dyr[c], xh = (x[row * ldx + c] - mean_in[row]) * rstd_in[row];
+    dg += d * xh;
+    db += d;
+  }
+  if (dgamma && dg != 0.f) atomicAdd(dgamma + c, dg);
+  if (dbeta && db != 0.f) atomicAdd(dbeta + c, db);
+}
+
 extern "C" int mca_layernorm_bwd(const float* dy, int64_t ldy, int64_t y_bstride, int64_t period,
                                  const float* x, int64_t ldx, const float* gamma,
                                  const float* mean, const float* rstd, const uint8_t* rowmask,
                                  float* dx, int64_t lddx, uint16_t* dx_bf16, int64_t ld_bf16,
-                                 float* dgamma, float* dbeta, int64_t rows, int cols, mca_stream_t stream) {
+                                 float* dgamma, float* dbeta, float* dxsum, int64_t rows, int cols, mca_stream_t stream) {
   if (!dy || !x || !gamma || !mean || !rstd || rows < 0 || cols <= 0 || cols > 1024) return MCA_E_BADARG;
   if (rows == 0) return MCA_OK;
+  if (!dx && !dx_bf16 && !dxsum && mca_knobs[12] != 1) {          // parameter gradients only
+    if (!dgamma && !dbeta) return MCA_OK;
+    const int chunks = (cols + 255) / 256;
+    int64_t slabs = 512 / chunks;          // two rounds of workgroups at most (each ends with one atomic per column)
+    if (slabs > (rows + 15) / 16) slabs = (rows + 15) / 16;
+    if (slabs < 1) slabs = 1;
+    const int64_t rpb = (rows + slabs - 1) / slabs;
+    hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(chunks, (unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, as_stream(stream), dy, ldy, y_bstride,
+                       period, x, ldx, mean, rstd, rowmask, dgamma, dbeta, rows, cols, rpb);
+    return launch_status();
+  }
   const bool vec = (cols % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (y_bstride % 4 == 0) &&
                    (!dx || lddx % 4 == 0) && (!dx_bf16 || ld_bf16 % 4 == 0) &&
                    ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && (!dx || (uintptr_t)dx % 16 == 0);
-  if (vec && !rowmask && period <= 0 && !dbeta && dgamma && (cols == 256 || cols == 512 || cols == 1024) &&
+  if (vec && !rowmask && period <= 0 && !dbeta && !dxsum && dgamma && (cols == 256 || cols == 512 || cols == 1024) &&
       (uintptr_t)gamma % 16 == 0 && mca_knobs[12] != 1) {          // knob 12 = 1: general kernel (A/B)
     // one workgroup per CU at most: every workgroup ends with one atomic per column on dgamma, and 1024 of them on the same
     // 512 addresses cost more than the extra loads in flight bring (b = 8: 40.8 -> 28.5 us, b = 32: 108.7 -> 104.0 us;
@@ -366,10 +402,10 @@ extern "C" int mca_layernorm_bwd(const float* dy, int64_t ldy, int64_t y_bstride
   if (blocks > bcap) blocks = bcap;
   if (vec)
     hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dy, ldy, y_bstride,
-                       period, x, ldx, gamma, mean, rstd, rowmask, dx, lddx, dx_bf16, ld_bf16, dgamma, dbeta, rows, cols);
+                       period, x, ldx, gamma, mean, rstd, rowmask, dx, lddx, dx_bf16, ld_bf16, dgamma, dbeta, dxsum, rows, cols);
   else
     hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dy, ldy, y_bstride,
-                       period, x, ldx, gamma, mean, rstd, rowmask, dx, lddx, dx_bf16, ld_bf16, dgamma, dbeta, rows, cols);
+                       period, x, ldx, gamma, mean, rstd, rowmask, dx, lddx, dx_bf16, ld_bf16, dgamma, dbeta, dxsum, rows, cols);
   return launch_status();
 }
 

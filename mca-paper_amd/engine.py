@@ -459,10 +459,10 @@ class FusionEngine:
 
     @staticmethod
     def ln_bwd(dy, ldy, x, gamma, mean, rstd, rows, cols, dgamma, dbeta=None, rowmask=None, dx=None, dx_bf16=None,
-               y_bstride=0, period=0):
+               y_bstride=0, period=0, dxsum=None):
         call("mca_layernorm_bwd", ptr(dy), ldy, y_bstride, period, ptr(x), x.stride(0), ptr(gamma), ptr(mean), ptr(rstd),
              ptr(rowmask), ptr(dx), dx.stride(0) if dx is not None else 0, ptr(dx_bf16),
-             dx_bf16.stride(0) if dx_bf16 is not None else 0, ptr(dgamma), ptr(dbeta), rows, cols, stream_ptr())
+             dx_bf16.stride(0) if dx_bf16 is not None else 0, ptr(dgamma), ptr(dbeta), ptr(dxsum), rows, cols, stream_ptr())
 
     def _attn_fwd(self, q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, lse, qmask, sched, ws, b, nq, layer=0):
         N = self.N
@@ -879,9 +879,9 @@ class FusionEngine:
             if isinstance(enc, EmbeddedSequenceEncoder):
                 e, te = ws["enc"][name], enc.token_encoder
                 kp = self.we[name]["kp"]
+                # (the Linear's bias gradient = column sums of this norm's dx: same launch)
                 self.ln_bwd(dx[off:], D, e["y"], te[2].weight, e["m2"], e["r2"], rows, D, G(te[2].weight), dbeta=G(te[2].bias),
-                            rowmask=e["mask"], dx=e["dy"], dx_bf16=e["dy_b"], y_bstride=N * D, period=n)
-                call("mca_reduce_rows", ptr(e["dy"]), D, D, 1, ptr(G(te[1].bias)), D, rows, D, stream_ptr())
+                            rowmask=e["mask"], dx=e["dy"], dx_bf16=e["dy_b"], y_bstride=N * D, period=n, dxsum=G(te[1].bias))
                 on_side(lambda e=e, te=te, rows=rows, enc=enc: tn(e["dy_b"], e["xin_b"], G(te[1].weight), rows, D, enc.input_size))
                 self.gemm_nt(e["dy_b"], self.we[name]["wT"], e["dxin"], rows, kp, D)
                 t2 = e["tokens"].view(rows, enc.input_size)
@@ -910,8 +910,7 @@ class FusionEngine:
         call("mca_reduce_rows", dx.data_ptr() + off * D * 4, D, N * D, n, ptr(gemb), D, rows, D, stream_ptr())
         gemb[n - 1].zero_()
         self.ln_bwd(dx[off:], D, e["y"], ve.norm.weight, e["m2"], e["r2"], rows, D, G(ve.norm.weight), dbeta=G(ve.norm.bias),
-                    rowmask=e["mask"], dx=e["dy"], dx_bf16=e["dy_b"], y_bstride=N * D, period=n)
-        call("mca_reduce_rows", ptr(e["dy"]), D, D, 1, ptr(G(ve.linear2.bias)), D, rows, D, stream_ptr())
+                    rowmask=e["mask"], dx=e["dy"], dx_bf16=e["dy_b"], y_bstride=N * D, period=n, dxsum=G(ve.linear2.bias))
         self._on_side(lambda: self.gemm_tn_acc(e["dy_b"], e["h1_b"], G(ve.linear2.weight), rows, D, D), 200 + mi, ws)
         self.gemm_nt(e["dy_b"], self.we[name]["w2T"], e["dh1"], rows, D, D)
         call("mca_tab_value_bwd", ptr(e["dh1"]), D, ptr(e["h1_b"]), ptr(e["values"]), ptr(G(ve.linear1.weight)),

@@ -116,7 +116,7 @@ SIGNATURES = {
     "mca_gemm_tn_acc": (_I, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P]),
     "mca_gemm_tn_acc_group": (_I, [_P, _I, _I64, _P]),
     "mca_layernorm_fwd": (_I, [_P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _I, _P, _P, _I64, _I, _F, _P]),
-    "mca_layernorm_bwd": (_I, [_P, _I64, _I64, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I, _P]),
+    "mca_layernorm_bwd": (_I, [_P, _I64, _I64, _I64, _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _I64, _I, _P]),
     "mca_geglu_fwd": (_I, [_P, _P, _I64, _I, _P]),
     "mca_geglu_bwd": (_I, [_P, _P, _P, _I64, _I, _P]),
     "mca_cast_pad_bf16": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I, _P]),

@@ -199,14 +199,26 @@ def test_layernorm_fwd_bwd(H, rows, cols, affine, masked):
     dgamma = torch.zeros(cols, device="cuda")
     dbeta = torch.zeros(cols, device="cuda") if affine else None
     dyptr = dy_full.data_ptr() + (5 * cols * 4 if period else 0)
+    dxsum = torch.randn(cols, device="cuda", generator=g) if affine else None          # (accumulated into: not zero)
+    dxsum0 = dxsum.clone() if affine else None
     H.call("mca_layernorm_bwd", dyptr, cols, NTOT * cols, period, x.data_ptr(), cols, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-           H.ptr(mm), dx.data_ptr(), cols, dxb.data_ptr(), cols_pad, dgamma.data_ptr(), H.ptr(dbeta), rows, cols, H.stream_ptr())
+           H.ptr(mm), dx.data_ptr(), cols, dxb.data_ptr(), cols_pad, dgamma.data_ptr(), H.ptr(dbeta), H.ptr(dxsum), rows, cols, H.stream_ptr())
     gx = xr.grad
     assert rel(dx, gx) < 2e-5
     assert rel(dxb[:, :cols].float(), gx) < 4e-3
     assert rel(dgamma, gr.grad) < 2e-5
     if affine:
         assert rel(dbeta, br.grad) < 2e-5
+        # the column sums of dx (bias gradient of the Linear in front of the norm), same launch.  dx sums to ~0 along a row, not along a column
+        assert (dxsum - dxsum0 - gx.sum(0)).abs().max() < 2e-4 * gx.abs().sum(0).max()
+    # parameter gradients only (no dx asked for: an encoder's input norm): the column-parallel kernel
+    dgamma2 = torch.zeros(cols, device="cuda")
+    dbeta2 = torch.zeros(cols, device="cuda") if affine else None
+    H.call("mca_layernorm_bwd", dyptr, cols, NTOT * cols, period, x.data_ptr(), cols, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+           H.ptr(mm), None, 0, None, 0, dgamma2.data_ptr(), H.ptr(dbeta2), None, rows, cols, H.stream_ptr())
+    assert rel(dgamma2, gr.grad) < 2e-5
+    if affine:
+        assert rel(dbeta2, br.grad) < 2e-5
 
 
 # ----------------------------------------------------------------------------------------------- GEGLU
