@@ -12,6 +12,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                  algorithmic flops per launch / average launch duration (DESIGN.md section "Measurement").
   cpu_baseline : the oracle (CPU restatement of the reference, oracle/mca_oracle.py) timed on this host on a
                  bounded sample of the same workload (N=1, rank 0 only).
+and, inside `config`: launch_choice (what --launch auto chose and why; the two-step replay-vs-eager guard under data parallelism),
+gpu_state_rank0 (shader clock / board power over the timed region, sysfs) and - single GPU, replayed step - sustained: the rate of
+the same replayed step after 30 s of unbroken load, measured AFTER the timed region and never used for `value` (every process
+starts in the slower of the chip's two sustained-load operating points, profiles/r04_slow_regime.md; --sustain-seconds 0: off).
+--step-times prints the host clock after every timed step (the sampled step's cost is visible there).
 The step timed is the one train_accel_gpu.py runs: finite checks ON (device flag, polled without a host sync; the
 fused AdamW skips a flagged step), inputs resident in HBM (same batch every step).
 """

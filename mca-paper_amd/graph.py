@@ -19,7 +19,9 @@ flag MAX | clip + AdamW.  Per step the host issues ~9 ``hipGraphLaunch`` and ~9 
 the bucket all-reduces run on the process group's stream beside the following backward segments exactly as in the eager loop.
 No RCCL call is ever inside a captured region, so nothing depends on RCCL's own capture support.  The segmented body runs the
 backward through ``engine.forward_backward`` (no autograd node): a capture has to end on the thread that began it, and autograd
-runs a CUDA backward on its own device thread.
+runs a CUDA backward on its own device thread.  The single-GPU body takes the same direct chain when every encoder is native
+(autograd's bookkeeping around the step's one node is eight small kernels per replay); a model with a foreign torch encoder is
+captured through autograd as before.
 
 Reference loop being replaced: train_accel_gpu.py:108-119 (model(batch); zero_grad; backward; clip_grad_norm_; optimizer.step).
 """
