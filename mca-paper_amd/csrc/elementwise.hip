@@ -145,6 +145,54 @@ __global__ __launch_bounds__(256) void ln_fwd_trunk_kernel(const float* __restri
   }
 }
 
+// Narrow rows (an encoder's input norm: 35 ... 713 features, bf16 output padded to the GEMM's K, no fp32 output): SIXTEEN lanes
+// per row, four rows per wavefront.  With a wavefront per row a 74-column row keeps 74 of 1,024 lane slots of the general kernel
+// busy and the loop is bound by its per-row latency (48,000 x 74: 32 us for 14 MB).
+__global__ __launch_bounds__(256) void ln_fwd_narrow_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const uint8_t* __restrict__ rowmask,
+                                                             u16* __restrict__ y_bf16, int64_t ld_bf16, int cols_pad,
+                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t rows,
+                                                             int cols, float eps) {
+  const int sub = threadIdx.x & 15, rloc = threadIdx.x >> 4;
+  for (int64_t row = (int64_t)blockIdx.x * 16 + rloc; row < rows; row += (int64_t)gridDim.x * 16) {
+    const bool masked = rowmask && rowmask[row];
+    const float* xr = x + row * ldx;
+    float v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int c = sub + 16 * k;
+      v[k] = (c < cols && !masked) ? xr[c] : 0.f;
+      s += v[k];
+    }
+    s += __shfl_xor(s, 8, WAVE); s += __shfl_xor(s, 4, WAVE); s += __shfl_xor(s, 2, WAVE); s += __shfl_xor(s, 1, WAVE);
+    const float mean = s / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const float d = v[k] - mean;
+      if (sub + 16 * k < cols) q += d * d;
+    }
+    q += __shfl_xor(q, 8, WAVE); q += __shfl_xor(q, 4, WAVE); q += __shfl_xor(q, 2, WAVE); q += __shfl_xor(q, 1, WAVE);
+    const float rstd = rsqrtf(q / (float)cols + eps);
+    if (sub == 0) {
+      if (mean_out) mean_out[row] = masked ? 0.f : mean;
+      if (rstd_out) rstd_out[row] = masked ? 0.f : rstd;
+    }
+    u16* br = y_bf16 + row * ld_bf16;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int c = sub + 16 * k;
+      if (c < cols) {
+        float t = (v[k] - mean) * rstd * gamma[c];
+        if (beta) t += beta[c];
+        br[c] = f2bf(masked ? 0.f : t);
+      }
+    }
+    for (int c = cols + sub; c < cols_pad; c += 16) br[c] = 0;
+  }
+}
+
 extern "C" int mca_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
                                  const uint8_t* rowmask, const float* add, int64_t period,
                                  float* y, int64_t ldy, int64_t y_bstride,
@@ -153,6 +201,12 @@ extern "C" int mca_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
                                  mca_stream_t stream) {
   if (!x || !gamma || rows < 0 || cols <= 0 || cols > 1024) return MCA_E_BADARG;
   if (rows == 0) return MCA_OK;
+  if (!y && y_bf16 && !add && cols <= 256 && mca_knobs[12] != 1) {          // narrow rows, bf16 output only (knob 12 = 1: general kernel)
+    int64_t nb = (rows + 15) / 16; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(ln_fwd_narrow_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), x, ldx, gamma, beta, rowmask, y_bf16, ld_bf16,
+                       cols_pad, mean, rstd, rows, cols, eps);
+    return launch_status();
+  }
   const bool vec = (cols % 4 == 0) && (ldx % 4 == 0) && (!y || (ldy % 4 == 0 && y_bstride % 4 == 0)) &&
                    (!y_bf16 || ld_bf16 % 4 == 0) &&
                    ((uintptr_t)x % 16 == 0) && (!y || (uintptr_t)y % 16 == 0) && (!add || (uintptr_t)add % 16 == 0);
@@ -339,26 +393,41 @@ __global__ __launch_bounds__(256) void ln_bwd_trunk_kernel(const float* __restri
 }
 
 // Parameter gradients only (no dx wanted: an encoder's input norm, encoders.py:189).  dgamma / dbeta are column sums over the
-// rows: thread = column, a slab of rows per workgroup (coalesced along the columns, no wavefront reductions; the row form above
-// spent 33 us on 12,000 x 74 values).
+// rows: a thread owns a column and every (256 / CW)-th row of its workgroup's slab (CW = 64 / 128 / 256 columns per
+// workgroup: a 74-column norm keeps 2 x 74 of 256 threads busy instead of 74), coalesced along the columns, no wavefront
+// reductions; the row sub-lanes are added through LDS, then one atomic per column (the row form spent 33 us on 12,000 x 74 values).
+template <int CW>
 __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ dy, int64_t ldy, int64_t y_bstride, int64_t period,
                                                              const float* __restrict__ x, int64_t ldx, const float* __restrict__ mean_in,
                                                              const float* __restrict__ rstd_in, const uint8_t* __restrict__ rowmask,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int cols,
                                                              int64_t rows_per_block) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  constexpr int RY = 256 / CW;
+  __shared__ float red[2][RY][CW];
+  const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
+  const int c = blockIdx.x * CW + tx;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   int64_t r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
-  if (c >= cols) return;
   float dg = 0.f, db = 0.f;
+  if (c < cols) {
 #pragma unroll 4
-  for (int64_t row = r0; row < r1; row++) {
-    if (rowmask && rowmask[row]) continue;
-    const float* dyr = period > 0 ? dy + (row / period) * y_bstride + (row % period) * ldy : dy + row * ldy;
-    const float d = dyr[c], xh = (x[row * ldx + c] - mean_in[row]) * rstd_in[row];
-    dg += d * xh;
-    db += d;
+    for (int64_t row = r0 + ty; row < r1; row += RY) {          // (no branch on the mask: the loads of four rows stay in flight together)
+      const float keep = (rowmask && rowmask[row]) ? 0.f : 1.f;
+      const float* dyr = period > 0 ? dy + (row / period) * y_bstride + (row % period) * ldy : dy + row * ldy;
+      const float d = dyr[c] * keep, xh = (x[row * ldx + c] - mean_in[row]) * rstd_in[row];
+      dg += d * xh;
+      db += d;
+    }
   }
+  if (RY > 1) {
+    red[0][ty][tx] = dg; red[1][ty][tx] = db;
+    __syncthreads();
+    if (ty != 0) return;
+    dg = 0.f; db = 0.f;
+#pragma unroll
+    for (int k = 0; k < RY; k++) { dg += red[0][k][tx]; db += red[1][k][tx]; }          // fixed order
+  }
+  if (c >= cols) return;
   if (dgamma && dg != 0.f) atomicAdd(dgamma + c, dg);
   if (dbeta && db != 0.f) atomicAdd(dbeta + c, db);
 }
@@ -372,13 +441,17 @@ extern "C" int mca_layernorm_bwd(const float* dy, int64_t ldy, int64_t y_bstride
   if (rows == 0) return MCA_OK;
   if (!dx && !dx_bf16 && !dxsum && mca_knobs[12] != 1) {          // parameter gradients only
     if (!dgamma && !dbeta) return MCA_OK;
-    const int chunks = (cols + 255) / 256;
-    int64_t slabs = 512 / chunks;          // two rounds of workgroups at most (each ends with one atomic per column)
-    if (slabs > (rows + 15) / 16) slabs = (rows + 15) / 16;
+    const int cw = cols <= 64 ? 64 : (cols <= 128 ? 128 : 256);
+    const int chunks = (cols + cw - 1) / cw;
+    int64_t slabs = 1024 / chunks;          // four rounds of workgroups at most (each ends with one atomic per column)
+    if (slabs > (rows + 31) / 32) slabs = (rows + 31) / 32;
     if (slabs < 1) slabs = 1;
     const int64_t rpb = (rows + slabs - 1) / slabs;
-    hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(chunks, (unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, as_stream(stream), dy, ldy, y_bstride,
-                       period, x, ldx, mean, rstd, rowmask, dgamma, dbeta, rows, cols, rpb);
+    const dim3 grid(chunks, (unsigned)((rows + rpb - 1) / rpb));
+#define LNP_LAUNCH(CW) hipLaunchKernelGGL(ln_bwd_params_kernel<CW>, grid, dim3(256), 0, as_stream(stream), dy, ldy, y_bstride, period, x, ldx, mean, rstd, \
+                                          rowmask, dgamma, dbeta, rows, cols, rpb)
+    if (cw == 64) LNP_LAUNCH(64); else if (cw == 128) LNP_LAUNCH(128); else LNP_LAUNCH(256);
+#undef LNP_LAUNCH
     return launch_status();
   }
   const bool vec = (cols % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (y_bstride % 4 == 0) &&

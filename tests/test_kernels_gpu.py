@@ -152,6 +152,35 @@ def test_layernorm_fwd_trunk_form(H, rows, cols):
     assert rel(outs[0][0].float(), outs[1][0].float()) < 1e-3 and rel(outs[0][1], outs[1][1]) < 1e-6 and rel(outs[0][2], outs[1][2]) < 1e-6
 
 
+@pytest.mark.parametrize("rows,cols", [(4099, 74), (1000, 35), (333, 256), (50, 20), (7, 1)])
+def test_layernorm_fwd_narrow_rows(H, rows, cols):
+    """An encoder's input norm (encoders.py:189): affine, pad mask, bf16 output padded to the GEMM's K, no fp32 output: the
+    sixteen-lanes-per-row kernel against torch and against the general kernel (knob 12)."""
+    g = torch.Generator(device="cuda").manual_seed(37)
+    x = torch.randn(rows, cols, device="cuda", generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(cols, device="cuda", generator=g), torch.randn(cols, device="cuda", generator=g)
+    mask = torch.rand(rows, device="cuda", generator=g) < 0.3
+    mm = mask.to(torch.uint8)
+    cols_pad = (cols + 7) // 8 * 8 + 8
+    outs = []
+    for general in (0, 1):
+        H.lib().mca_debug_set(12, general)
+        yb = torch.full((rows, cols_pad), 7.0, device="cuda", dtype=torch.bfloat16)
+        mean, rstd = torch.full((rows,), 3.0, device="cuda"), torch.full((rows,), 3.0, device="cuda")
+        H.call("mca_layernorm_fwd", x.data_ptr(), cols, gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), None, 0, None, 0, 0, yb.data_ptr(), cols_pad,
+               cols_pad, mean.data_ptr(), rstd.data_ptr(), rows, cols, 1e-5, H.stream_ptr())
+        torch.cuda.synchronize()
+        outs.append((yb, mean, rstd))
+    H.lib().mca_debug_set(12, 0)
+    ref = torch.nn.functional.layer_norm(x, (cols,), gamma, beta, 1e-5).masked_fill(mask[:, None], 0.0)
+    yb, mean, rstd = outs[0]
+    assert rel(yb[:, :cols].float(), ref) < 4e-3 and (yb[:, cols:] == 0).all()
+    keep = ~mask
+    assert (mean[mask] == 0).all() and (rstd[mask] == 0).all()
+    assert rel(mean[keep], x[keep].mean(1)) < 1e-5 and rel(rstd[keep], (x[keep].var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+    assert rel(yb.float(), outs[1][0].float()) < 1e-3 and rel(mean, outs[1][1]) < 1e-6 and rel(rstd, outs[1][2]) < 1e-6
+
+
 @pytest.mark.parametrize("rows,cols,affine,masked", [(1000, 512, False, False), (333, 74, True, True), (64, 713, True, True),
                                                       (90, 128, True, True), (4099, 512, False, False), (777, 256, False, False),
                                                       (33, 1024, False, False)])
