@@ -412,9 +412,10 @@ __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restr
   if (c < cols) {
 #pragma unroll 4
     for (int64_t row = r0 + ty; row < r1; row += RY) {          // (no branch on the mask: the loads of four rows stay in flight together)
-      const float keep = (rowmask && rowmask[row]) ? 0.f : 1.f;
+      const bool masked = rowmask && rowmask[row];          // selects, not products: a non-finite value in a padded row adds an exact 0
       const float* dyr = period > 0 ? dy + (row / period) * y_bstride + (row % period) * ldy : dy + row * ldy;
-      const float d = dyr[c] * keep, xh = (x[row * ldx + c] - mean_in[row]) * rstd_in[row];
+      const float dv_ = dyr[c], xv_ = (x[row * ldx + c] - mean_in[row]) * rstd_in[row];
+      const float d = masked ? 0.f : dv_, xh = masked ? 0.f : xv_;
       dg += d * xh;
       db += d;
     }

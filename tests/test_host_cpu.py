@@ -212,6 +212,12 @@ def test_training_helpers_match_their_reference_contract(pkg):
     import pytest
     with pytest.raises(TypeError):
         move_to({"a": 3}, "cpu")
+    from utils.training import copy_batch          # (utils/training.py:19-33 of the reference)
+    src = {"a": {"x": torch.ones(2, 3, requires_grad=True)}, "l": [torch.zeros(1)]}
+    cp = copy_batch(src)
+    assert torch.equal(cp["a"]["x"], src["a"]["x"]) and cp["a"]["x"].data_ptr() != src["a"]["x"].data_ptr() and not cp["a"]["x"].requires_grad
+    with pytest.raises(TypeError):
+        copy_batch({"a": 3})
     net = torch.nn.ModuleDict({"embedding": torch.nn.Embedding(5, 4), "lin": torch.nn.Linear(4, 2)})
     assert count_parameters(net) == (20, 10)
     ps = list(net.parameters())

@@ -22,6 +22,18 @@ def move_to(obj, device):
     raise TypeError("Invalid type for move_to")
 
 
+def copy_batch(obj):
+    """Detached deep copy of a (nested) batch, the reference's helper of the same name (utils/training.py:19-33): tensors are
+    cloned, dicts and lists rebuilt, anything else is a TypeError."""
+    if torch.is_tensor(obj):
+        return obj.detach().clone()
+    if isinstance(obj, dict):
+        return {k: copy_batch(v) for k, v in obj.items()}
+    if isinstance(obj, list):
+        return [copy_batch(v) for v in obj]
+    raise TypeError("Invalid type for copy_to")
+
+
 def count_parameters(model, print_summary=False):
     """(embedding parameters, other parameters): a parameter counts as 'embedding' when its name contains that word."""
     emb = other = 0
