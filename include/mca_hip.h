@@ -315,6 +315,42 @@ int mca_attn_bwd_dkv(const mca_attn_bwd2_args* args, mca_stream_t stream);
 int mca_attn_bwd_dq_fp8(const mca_attn_bwd2_args* args, const mca_attn_fp8_bwd_operands* f, mca_stream_t stream);
 int mca_attn_bwd_dkv_fp8(const mca_attn_bwd2_args* args, const mca_attn_fp8_bwd_operands* f, mca_stream_t stream);
 
+/* ONE-PASS backward of the fusion self-attention (autograd of model.py:87-99 as called by MCALayer.forward :119), the five
+ * matrix products the gradient needs instead of the two passes' seven, still without atomics: ONE workgroup owns a whole
+ * (sample, head), walks its key blocks (<= 256 keys: dK / dV in registers) in order and inside a block the query tiles
+ * (<= 64 rows) the structure allows; dQ of a tile is summed over its key blocks by a private fp32 read-modify-write in dq_acc
+ * (first visit starts from zero, last visit writes bf16 dq): fixed order, bitwise reproducible.  Needs the mask product
+ * operands (khot / qblk: at most 15 key groups), MCA_ATTN_Q_PRESCALED, nq == nk == n.  Tables (structure.build_onepass_schedule):
+ *   qt_desc[n_qtiles]  = {first row, rows (1..64)}                       query tiles, a partition of 0..n-1
+ *   kb_desc[n_kblocks] = {first key, keys (1..256), first entry, entries} key blocks, a partition of 0..n-1, 16-byte aligned
+ *   kb_qt[]            = per key block its query tiles | (every pair structurally allowed << 31), ascending
+ *   visit[n_kblocks][n_qtiles] = 1 where the block lists the tile;  max_list = longest list (<= 256)
+ * rowc (b, heads, n_qtiles, 2, 64) fp32: -lse | -delta of the tile's rows (mca_attn_bwd_prep_onepass; positions past a tile's
+ * rows hold -inf | 0, written once by the caller).  dq_acc: workspace of batch * heads * n_qtiles * 4096 floats, contents
+ * irrelevant on entry.  dq, dk, dv bf16, every element written.  n_qtiles <= 256, n_kblocks <= 64, else MCA_E_UNSUPPORTED
+ * (the caller keeps the two-pass form).                                                                                  */
+typedef struct {
+  const uint16_t* q; int64_t q_bstride; int64_t q_ld;
+  const uint16_t* k; const uint16_t* v; int64_t kv_bstride; int64_t kv_ld;
+  const uint16_t* d_o; int64_t o_bstride; int64_t o_ld;
+  const float* rowc; const float* dvmean;
+  uint16_t* dq; int64_t dq_bstride; int64_t dq_ld;
+  uint16_t* dk; uint16_t* dv; int64_t dkv_bstride; int64_t dkv_ld;
+  float* dq_acc;
+  const uint8_t* keyinfo; const uint8_t* ktile_flags; const uint16_t* khot; const uint16_t* qblk;
+  const int32_t* qt_desc; const int32_t* kb_desc; const uint32_t* kb_qt; const uint8_t* visit;
+  int n_qtiles, n_kblocks, max_list;
+  int batch, heads, n, nk_pad, n_ktiles64;
+  float scale;
+  int flags;
+} mca_attn_bwd1_args;
+int mca_attn_bwd_onepass(const mca_attn_bwd1_args* args, mca_stream_t stream);
+/* mca_attn_bwd_prep for the one-pass form: rowc in tile order (row_slot[q] = tile * 64 + position) instead of delta; dvmean as
+ * mca_attn_bwd_prep                                                                                                      */
+int mca_attn_bwd_prep_onepass(const uint16_t* o, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld, const float* lse,
+                              const int32_t* row_slot, float* rowc, float* dvmean, int batch, int heads, int n, int n_qtiles,
+                              mca_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * All-pairs contrastive loss with temperature
  * (model.py:175-233 + torchmultimodal ContrastiveLossWithTemperature, formula per

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmca_hip.so")
-SOURCES = ["elementwise.hip", "gemm.hip", "attention_fwd.hip", "attention_fwd64.hip", "attention_bwd2.hip", "attention_fp8.hip", "loss.hip", "optim.hip"]
+SOURCES = ["elementwise.hip", "gemm.hip", "attention_fwd.hip", "attention_fwd64.hip", "attention_bwd2.hip", "attention_bwd1.hip", "attention_fp8.hip", "loss.hip", "optim.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++20", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 # per-file extras: keep the attention accumulators in VGPRs (the softmax VALU works on them in place; the default
 # AGPR form costs 256 v_accvgpr moves per key tile)

@@ -1,0 +1,375 @@
+// Block-masked fused attention, backward in ONE pass without atomics (autograd of model.py:73-105 as called by MCALayer :119).
+//
+// The two-pass backward (attention_bwd2.hip) pays for its atomic-free dQ with S and dP computed twice: 7 matrix products for
+// the 5 the gradient needs.  Here ONE workgroup owns a whole (sample, head): it walks that pair's key blocks in order (256
+// keys: 4 wavefronts x 64 keys, dK^T / dV^T and the K / V operand fragments in registers, ONE wavefront per SIMD on the whole
+// 512-entry register file) and, inside a key block, the query tiles the structure allows (<= 64 rows per step).  Per step:
+//   S^T-lse, dP^T-delta (key on the lane: the accumulators ARE the B operands of the next two products), P, dS,
+//   dV^T += dO^T P, dK^T += Q^T dS, and dS crosses LDS once ([key][query] image) for dQ^T += K^T dS^T: five products.
+// dQ of a query tile is summed over the key blocks that visit it.  Those visits all happen in THIS workgroup, one after the
+// other, so the sum is a plain private read-modify-write of an fp32 tile (the first visit starts from zero, the last one
+// writes bf16 to dq): no atomics (1.3 TB/s chip-wide on this part: the 0.9 GB of adds per layer put a 690 us floor under the
+// round-1 kernel), no hand-off between workgroups, no fence, and the order of the sum is fixed: bitwise reproducible.  A lane
+// reads back exactly the 16-byte pieces it wrote itself (dq_acc is laid out [tile][wavefront][register group][lane][4]), so
+// the read-after-write is program order of one work-item.
+// Tiles follow the structure (structure.build_onepass_schedule): query tiles and key blocks are cut along the modality
+// boundaries, described by {first row, rows} tables; a step whose every pair is allowed and whose keys are all valid skips
+// the mask product.
+#include "common.h"
+
+#define DH 64
+#define TQ 64                     // query rows per step (at most)
+#define TKB 256                   // keys per block (at most): 4 wavefronts x 64
+#define B1_NST 2                  // Q / dO / row-constant / mask-operand stages
+#define B1_STAGE_U16 (TQ * DH * 2 + 256 + TQ * 16)          // u16 per stage: Q | dO | rowc (128 floats) | qblk = 18,944 bytes
+#define B1_MAX_QT 256
+#define B1_MAX_KB 64
+#define B1_MAX_LIST 256
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+// [rows][64] bf16 image (128-byte rows) serving ds_read_b128 row reads AND ds_read_b64_tr_b16 transposed reads (as attention_bwd2.hip)
+__device__ __forceinline__ int b1_off(int r, int c) {
+  const int s = ((r >> 1) & 7) ^ (((r >> 1) & 1) << 2);
+  return r * 64 + ((c ^ s) << 3);
+}
+__device__ __forceinline__ int b1_swz(int r) { return ((r >> 1) & 7) ^ (((r >> 1) & 1) << 2); }
+
+#define B1_DMA(SRC, DST, BYTES) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), (__attribute__((address_space(3))) void*)(DST), BYTES, 0, 0)
+
+__global__ __launch_bounds__(256, 1) void attn_bwd1_kernel(mca_attn_bwd1_args a, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) u16 lds[];
+  u16* stage_s = lds;                                             // B1_NST stages
+  u16* kimg = stage_s + B1_NST * B1_STAGE_U16;                    // [256 keys][64 d]: A operand of the dQ product (transposed reads)
+  u16* dsimg = kimg + TKB * DH;                                   // 2 x [256 keys][64 queries]: dS^T of a step
+  uint32_t* list_s = reinterpret_cast<uint32_t*>(dsimg + 2 * TKB * TQ);   // the key block's query tiles
+  uint8_t* first_s = reinterpret_cast<uint8_t*>(list_s + B1_MAX_LIST);    // per query tile: first / last LIVE key block that visits it
+  uint8_t* last_s = first_s + B1_MAX_QT;
+  uint8_t* live_s = last_s + B1_MAX_QT;                           // per key block: has a valid key in this sample
+  float* dvm_s = reinterpret_cast<float*>(live_s + B1_MAX_KB);
+
+  const int lin = (dbg & 16) ? (int)blockIdx.x : xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int h = lin % a.heads, b = lin / a.heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  const int64_t bh = (int64_t)b * a.heads + h;
+
+  const u16* qbase = a.q + (int64_t)b * a.q_bstride + h * DH;
+  const u16* obase = a.d_o + (int64_t)b * a.o_bstride + h * DH;
+  const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
+  const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
+  const float* rowc_g = a.rowc + bh * (int64_t)a.n_qtiles * 128;
+  float* acc_g = a.dq_acc + bh * (int64_t)a.n_qtiles * (TQ * DH);
+  const uint8_t* kinfo_g = a.keyinfo + (int64_t)b * a.nk_pad;
+  const u16* khot_g = a.khot + (int64_t)b * a.nk_pad * 16;
+
+  // ---- which key blocks hold a valid key in this sample (64-key tile flags of mca_build_keyinfo: conservative at block edges),
+  // and per query tile the first / last of them that visits it
+  if (tid < a.n_kblocks) {
+    const int4 d = reinterpret_cast<const int4*>(a.kb_desc)[tid];
+    const uint8_t* fl = a.ktile_flags + (int64_t)b * a.n_ktiles64;
+    int live = 0;
+    for (int t = d.x >> 6; t <= (d.x + d.y - 1) >> 6; t++) live |= fl[t];
+    live_s[tid] = live ? 1 : 0;
+  }
+  if (tid < DH) dvm_s[tid] = a.dvmean[(int64_t)b * a.heads * DH + h * DH + tid];
+  __syncthreads();
+  for (int qt = tid; qt < a.n_qtiles; qt += 256) {
+    int first = 255, last = 255;
+    for (int kb = 0; kb < a.n_kblocks; kb++)
+      if (live_s[kb] && a.visit[kb * a.n_qtiles + qt]) { if (first == 255) first = kb; last = kb; }
+    first_s[qt] = (uint8_t)first; last_s[qt] = (uint8_t)last;
+  }
+  __syncthreads();
+  // query tiles nobody visits (every key they may see is padded in this sample): dq = 0
+  for (int qt = 0; qt < a.n_qtiles; qt++) {
+    if (first_s[qt] != 255) continue;
+    const int2 qd = reinterpret_cast<const int2*>(a.qt_desc)[qt];
+    for (int i = tid; i < qd.y * 8; i += 256)
+      *reinterpret_cast<uint4*>(a.dq + (int64_t)b * a.dq_bstride + (int64_t)(qd.x + (i >> 3)) * a.dq_ld + h * DH + (i & 7) * 8) = make_uint4(0, 0, 0, 0);
+  }
+
+  // loop-invariant LDS offsets (u16 units)
+  int rowfrag[4];          // row fragment (row l31, k-step st) of a 32-row block of a [rows][64] image
+#pragma unroll
+  for (int st = 0; st < 4; st++) rowfrag[st] = b1_off(l31, 2 * st + lh);
+  const float dk_scale = 0.6931471805599453f;          // q carries scale * log2 e: dK^T carries that factor
+
+  for (int kbi = 0; kbi < a.n_kblocks; kbi++) {
+    if (!live_s[kbi]) continue;          // (uniform over the workgroup)
+    const int4 kd = reinterpret_cast<const int4*>(a.kb_desc)[kbi];
+    const int key_start = __builtin_amdgcn_readfirstlane(kd.x), n_keys = __builtin_amdgcn_readfirstlane(kd.y);
+    const int e_begin = __builtin_amdgcn_readfirstlane(kd.z), n_ent = __builtin_amdgcn_readfirstlane(kd.w);
+    for (int i = tid; i < n_ent; i += 256) list_s[i] = a.kb_qt[e_begin + i];
+
+    // ---- this lane's two keys (slots wave * 64 + kb * 32 + l31): operand fragments for the whole block
+    bf16x8 kf[2][4], vf[2][4], khf[2];
+    bool ok[2];
+    int keyrow[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      const int slot = wave * 64 + kb * 32 + l31;
+      const bool valid = slot < n_keys;
+      const int key = key_start + (valid ? slot : n_keys - 1);
+      keyrow[kb] = valid ? key : -1;
+      ok[kb] = valid && kinfo_g[key] != 31;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        kf[kb][s] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * a.kv_ld + 16 * s + 8 * lh);
+        vf[kb][s] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * a.kv_ld + 16 * s + 8 * lh);
+      }
+      khf[kb] = *reinterpret_cast<const bf16x8*>(khot_g + (int64_t)key * 16 + 8 * lh);
+      if (!valid) {          // a slot past the block: one-hot of the pad group (15), blocked for every query
+#pragma unroll
+        for (int j = 0; j < 8; j++) khf[kb][j] = 0;
+        if (lh) khf[kb][7] = (short)0x3F80;
+      }
+    }
+    const bool wave_ok[2] = {__all(ok[0]) != 0, __all(ok[1]) != 0};
+    const bool wave_dead = !__any(ok[0] || ok[1]);
+    // ---- K image: wavefront w moves the rows of its own 64 slots (8 pieces of 1 KiB; swizzle on the source chunk)
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+      const int r = wave * 64 + p * 8 + (lane >> 3);
+      const int key = key_start + (r < n_keys ? r : n_keys - 1);
+      B1_DMA(kbase + (int64_t)key * a.kv_ld + (((lane & 7) ^ b1_swz(r)) << 3), kimg + (wave * 8 + p) * 512, 16);
+    }
+    f32x16 dk[2][2], dv[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { dk[kb][n][r] = 0.f; dv[kb][n][r] = 0.f; }
+    if (wave_dead) {          // its 64 rows of both dS^T images stay zero for the whole block
+      for (int i = lane; i < 2 * 64 * 8; i += 64) {
+        const int buf = i >> 9, r = (i >> 3) & 63, c = i & 7;
+        *reinterpret_cast<uint4*>(dsimg + buf * (TKB * TQ) + (wave * 64 + r) * 64 + c * 8) = make_uint4(0, 0, 0, 0);
+      }
+    }
+
+    // ---- staging of one step: Q / dO tiles (8 pieces each, two per wavefront), row constants (wavefront 0), mask operand (1, 2)
+    auto issue = [&](uint32_t ent, int st) {
+      const int qt = (int)(ent & 0x7fffffffu);
+      const int2 qd = reinterpret_cast<const int2*>(a.qt_desc)[qt];
+      const int row0 = __builtin_amdgcn_readfirstlane(qd.x), nrows = __builtin_amdgcn_readfirstlane(qd.y);
+      u16* sb = stage_s + st * B1_STAGE_U16;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int p = wave * 2 + u, r = p * 8 + (lane >> 3);
+        const int row = row0 + (r < nrows ? r : nrows - 1);
+        const int sw = ((lane & 7) ^ b1_swz(r)) << 3;
+        B1_DMA(qbase + (int64_t)row * a.q_ld + sw, sb + p * 512, 16);
+        B1_DMA(obase + (int64_t)row * a.o_ld + sw, sb + TQ * DH + p * 512, 16);
+      }
+      if (wave == 0) {
+        B1_DMA(rowc_g + (int64_t)qt * 128 + lane, sb + 2 * TQ * DH, 4);
+        B1_DMA(rowc_g + (int64_t)qt * 128 + 64 + lane, sb + 2 * TQ * DH + 128, 4);
+      } else if (wave < 3) {
+        const int r = (wave - 1) * 32 + (lane >> 1);
+        const int row = row0 + (r < nrows ? r : nrows - 1);
+        B1_DMA(a.qblk + (int64_t)row * 16 + (lane & 1) * 8, sb + 2 * TQ * DH + 256 + (wave - 1) * 512, 16);
+      }
+    };
+    __syncthreads();          // list_s visible; every wavefront is past the previous block's last reads of the stages
+    if (n_ent > 0) issue(list_s[0], 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int it = 0; it < n_ent; it++) {
+      const uint32_t ent = __builtin_amdgcn_readfirstlane(list_s[it]);
+      const int qt = (int)(ent & 0x7fffffffu);
+      const bool full = (ent >> 31) != 0;
+      const int st = it & 1;
+      if (it + 1 < n_ent) issue(__builtin_amdgcn_readfirstlane(list_s[it + 1]), st ^ 1);
+      const u16* Qs = stage_s + st * B1_STAGE_U16;
+      const u16* Os = Qs + TQ * DH;
+      const float* rc = reinterpret_cast<const float*>(Qs + 2 * TQ * DH);
+      const u16* qblk_s = Qs + 2 * TQ * DH + 256;
+      u16* dsw = dsimg + (it & 1) * (TKB * TQ);
+
+      if (!wave_dead) {
+#pragma unroll
+        for (int qb = 0; qb < 2; qb++) {
+          // S^T - lse and dP^T - delta: the row constants are the accumulators' start values
+          f32x16 s[2], dp[2];
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const f32x4 cl = *reinterpret_cast<const f32x4*>(rc + qb * 32 + 8 * g + 4 * lh);
+            const f32x4 cd = *reinterpret_cast<const f32x4*>(rc + 64 + qb * 32 + 8 * g + 4 * lh);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { s[0][4 * g + e] = cl[e]; s[1][4 * g + e] = cl[e]; dp[0][4 * g + e] = cd[e]; dp[1][4 * g + e] = cd[e]; }
+          }
+#pragma unroll
+          for (int ks = 0; ks < 4; ks++) {
+            const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + qb * 32 * DH + rowfrag[ks]);
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(Os + qb * 32 * DH + rowfrag[ks]);
+            s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[0][ks], s[0], 0, 0, 0);
+            s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[1][ks], s[1], 0, 0, 0);
+            dp[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vf[0][ks], dp[0], 0, 0, 0);
+            dp[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vf[1][ks], dp[1], 0, 0, 0);
+          }
+          // blocked (query, key) pairs: -32768 on top of the score, exp2 is exactly 0 (the mask as a matrix product)
+          if (!(full && wave_ok[0] && wave_ok[1])) {
+            const bf16x8 qbf = *reinterpret_cast<const bf16x8*>(qblk_s + (qb * 32 + l31) * 16 + 8 * lh);
+            s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qbf, khf[0], s[0], 0, 0, 0);
+            s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qbf, khf[1], s[1], 0, 0, 0);
+          }
+          u32x4v pbw[2][2], sbw[2][2];
+#pragma unroll
+          for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              const float p0 = __builtin_amdgcn_exp2f(s[kb][r]), p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
+              pbw[kb][r >> 3][(r & 7) >> 1] = pack2bf_pk(p0, p1);
+              sbw[kb][r >> 3][(r & 7) >> 1] = pack2bf_pk(p0 * dp[kb][r], p1 * dp[kb][r + 1]);
+            }
+          // dV^T += dO^T P ; dK^T += Q^T dS   (element j of k-step sp carries query 16 sp + 8 (j >> 2) + 4 lh + (j & 3))
+#pragma unroll
+          for (int sp = 0; sp < 2; sp++)
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+              bf16x8 ot, qtf;
+#pragma unroll
+              for (int t = 0; t < 2; t++) {
+                const int qr = qb * 32 + 16 * sp + 8 * t + 4 * lh + tq;
+                const int d = n * 32 + 16 * tg + 4 * tp;
+                const bf16x4 o4 = lds_read_tr16(Os + b1_off(qr, d >> 3) + (d & 7));
+                const bf16x4 q4 = lds_read_tr16(Qs + b1_off(qr, d >> 3) + (d & 7));
+#pragma unroll
+                for (int e = 0; e < 4; e++) { ot[4 * t + e] = o4[e]; qtf[4 * t + e] = q4[e]; }
+              }
+#pragma unroll
+              for (int kb = 0; kb < 2; kb++) {
+                dv[kb][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot, *reinterpret_cast<const bf16x8*>(&pbw[kb][sp]), dv[kb][n], 0, 0, 0);
+                dk[kb][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, *reinterpret_cast<const bf16x8*>(&sbw[kb][sp]), dk[kb][n], 0, 0, 0);
+              }
+            }
+          // dS^T -> [key][query] image: this lane's key row, four consecutive queries per 8-byte store
+#pragma unroll
+          for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int sp = 0; sp < 2; sp++)
+#pragma unroll
+              for (int t = 0; t < 2; t++) {
+                const int q0 = qb * 32 + 16 * sp + 8 * t + 4 * lh;
+                *reinterpret_cast<uint2*>(dsw + b1_off(wave * 64 + kb * 32 + l31, q0 >> 3) + (q0 & 7)) = make_uint2(sbw[kb][sp][2 * t], sbw[kb][sp][2 * t + 1]);
+              }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wavefront's pieces of the next stage have landed
+      __syncthreads();                                           // dS^T of the step complete; next stage visible
+
+      // ---- dQ^T[d][q] (+)= K^T[d][key] dS^T[key][q] over the block's 256 keys: wavefront w owns the 32 x 32 block
+      // (queries 32 (w >> 1) .., d 32 (w & 1) ..) of the 64 x 64 tile
+      {
+        const int qbw = wave >> 1, nw = wave & 1;
+        const bool first = first_s[qt] == kbi, last = last_s[qt] == kbi;
+        float* accp = acc_g + (int64_t)qt * (TQ * DH) + wave * 1024 + lane * 4;
+        f32x16 dq;
+        if (first) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) dq[r] = 0.f;
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(accp + g * 256);
+#pragma unroll
+            for (int e = 0; e < 4; e++) dq[4 * g + e] = v[e];
+          }
+        }
+        const u16* dsr = dsimg + (it & 1) * (TKB * TQ);
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+          bf16x8 af, bfr;
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            const int key = 16 * kk + 8 * lh + 4 * t + tq;
+            const int d = nw * 32 + 16 * tg + 4 * tp, qc = qbw * 32 + 16 * tg + 4 * tp;
+            const bf16x4 k4 = lds_read_tr16(kimg + b1_off(key, d >> 3) + (d & 7));
+            const bf16x4 s4 = lds_read_tr16(dsr + b1_off(key, qc >> 3) + (qc & 7));
+#pragma unroll
+            for (int e = 0; e < 4; e++) { af[4 * t + e] = k4[e]; bfr[4 * t + e] = s4[e]; }
+          }
+          dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, dq, 0, 0, 0);
+        }
+        if (last) {
+          const int2 qd = reinterpret_cast<const int2*>(a.qt_desc)[qt];
+          const int r = qbw * 32 + l31;
+          if (r < qd.y) {
+            u16* p = a.dq + (int64_t)b * a.dq_bstride + (int64_t)(qd.x + r) * a.dq_ld + h * DH + nw * 32 + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+              uint2 pk;
+              pk.x = pack2bf(dq[4 * g] * a.scale, dq[4 * g + 1] * a.scale);
+              pk.y = pack2bf(dq[4 * g + 2] * a.scale, dq[4 * g + 3] * a.scale);
+              *reinterpret_cast<uint2*>(p + 8 * g) = pk;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; g++) *reinterpret_cast<f32x4*>(accp + g * 256) = f32x4{dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]};
+        }
+      }
+    }
+
+    // ---- the block's dK = ln 2 * dK^T, dV = dV^T + dvmean (uniform rows spread over every key)
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      if (keyrow[kb] < 0) continue;
+      u16* dkp = a.dk + (int64_t)b * a.dkv_bstride + (int64_t)keyrow[kb] * a.dkv_ld + h * DH;
+      u16* dvp = a.dv + (int64_t)b * a.dkv_bstride + (int64_t)keyrow[kb] * a.dkv_ld + h * DH;
+#pragma unroll
+      for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int d = n * 32 + 8 * g + 4 * lh;
+          uint2 pk;
+          pk.x = pack2bf(dk[kb][n][4 * g] * dk_scale, dk[kb][n][4 * g + 1] * dk_scale);
+          pk.y = pack2bf(dk[kb][n][4 * g + 2] * dk_scale, dk[kb][n][4 * g + 3] * dk_scale);
+          *reinterpret_cast<uint2*>(dkp + d) = pk;
+          const f32x4 dvm = *reinterpret_cast<const f32x4*>(dvm_s + d);
+          pk.x = pack2bf(dv[kb][n][4 * g] + dvm[0], dv[kb][n][4 * g + 1] + dvm[1]);
+          pk.y = pack2bf(dv[kb][n][4 * g + 2] + dvm[2], dv[kb][n][4 * g + 3] + dvm[3]);
+          *reinterpret_cast<uint2*>(dvp + d) = pk;
+        }
+    }
+    __syncthreads();          // every wavefront is done with the K image, the list and the stages before the next block's prologue
+  }
+  // key blocks without a valid key in this sample sweep nothing: dK = 0, dV = dvmean
+  for (int kbi = 0; kbi < a.n_kblocks; kbi++) {
+    if (live_s[kbi]) continue;
+    const int4 kd = reinterpret_cast<const int4*>(a.kb_desc)[kbi];
+    for (int i = tid; i < kd.y * 8; i += 256) {
+      const int key = kd.x + (i >> 3), c = i & 7;
+      *reinterpret_cast<uint4*>(a.dk + (int64_t)b * a.dkv_bstride + (int64_t)key * a.dkv_ld + h * DH + c * 8) = make_uint4(0, 0, 0, 0);
+      uint4 pv;
+      pv.x = pack2bf(dvm_s[c * 8], dvm_s[c * 8 + 1]); pv.y = pack2bf(dvm_s[c * 8 + 2], dvm_s[c * 8 + 3]);
+      pv.z = pack2bf(dvm_s[c * 8 + 4], dvm_s[c * 8 + 5]); pv.w = pack2bf(dvm_s[c * 8 + 6], dvm_s[c * 8 + 7]);
+      *reinterpret_cast<uint4*>(a.dv + (int64_t)b * a.dkv_bstride + (int64_t)key * a.dkv_ld + h * DH + c * 8) = pv;
+    }
+  }
+}
+#define B1_LDS_BYTES ((B1_NST * B1_STAGE_U16 + TKB * DH + 2 * TKB * TQ) * 2 + B1_MAX_LIST * 4 + 2 * B1_MAX_QT + B1_MAX_KB + DH * 4)
+
+extern "C" int mca_attn_bwd_onepass(const mca_attn_bwd1_args* a, mca_stream_t stream) {
+  if (!a || !a->q || !a->k || !a->v || !a->d_o || !a->rowc || !a->dvmean || !a->dq || !a->dk || !a->dv || !a->dq_acc) return MCA_E_BADARG;
+  if (!a->keyinfo || !a->ktile_flags || !a->khot || !a->qblk || !a->qt_desc || !a->kb_desc || !a->kb_qt || !a->visit) return MCA_E_BADARG;
+  if (a->batch <= 0 || a->heads <= 0 || a->n <= 0 || a->n_qtiles <= 0 || a->n_kblocks <= 0) return MCA_E_BADARG;
+  if (a->n_qtiles > B1_MAX_QT || a->n_kblocks > B1_MAX_KB || a->max_list > B1_MAX_LIST) return MCA_E_UNSUPPORTED;
+  if (a->q_ld % 8 || a->kv_ld % 8 || a->o_ld % 8 || a->q_bstride % 8 || a->kv_bstride % 8 || a->o_bstride % 8) return MCA_E_ALIGN;
+  if ((uintptr_t)a->q % 16 || (uintptr_t)a->k % 16 || (uintptr_t)a->v % 16 || (uintptr_t)a->d_o % 16 || (uintptr_t)a->khot % 16 || (uintptr_t)a->qblk % 16) return MCA_E_ALIGN;
+  if (a->dq_ld % 8 || a->dq_bstride % 8 || (uintptr_t)a->dq % 16 || a->dkv_ld % 8 || a->dkv_bstride % 8 || (uintptr_t)a->dk % 16 || (uintptr_t)a->dv % 16) return MCA_E_ALIGN;
+  if ((uintptr_t)a->dq_acc % 16 || (uintptr_t)a->rowc % 4 || (uintptr_t)a->kb_desc % 16 || (uintptr_t)a->qt_desc % 8) return MCA_E_ALIGN;
+  if (a->nk_pad < a->n || a->n_ktiles64 != (a->n + 63) / 64) return MCA_E_BADARG;
+  if (!(a->flags & MCA_ATTN_Q_PRESCALED)) return MCA_E_UNSUPPORTED;
+  if ((int64_t)a->batch * a->heads > 0x7fffffff) return MCA_E_UNSUPPORTED;
+  static bool attr_set[64] = {false};
+  bool* done = mca_dev_flag(attr_set);
+  if (!*done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS_BYTES) != hipSuccess) return MCA_E_LAUNCH;
+    *done = true;
+  }
+  hipLaunchKernelGGL(attn_bwd1_kernel, dim3(a->batch * a->heads), dim3(256), B1_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
+  return launch_status();
+}

@@ -633,8 +633,13 @@ extern "C" int mca_attn_bwd_dkv(const mca_attn_bwd2_args* a, mca_stream_t stream
 // one wavefront per (b, q) row: lane covers 8 contiguous columns of the 512-wide row -> head = lane / 8
 // =====================================================================================================
 #define PREP_ROWS 32
+// row_slot != NULL (one-pass backward, attention_bwd1.hip): the row constants go out NEGATED and in that kernel's tile order
+// instead: rowc[b, h, tile, 0, pos] = -lse[b, h, q], rowc[b, h, tile, 1, pos] = -delta, row_slot[q] = tile * 64 + pos; positions
+// past a tile's rows keep what the caller initialised them with (-inf | 0: a row that contributes nothing)
 __device__ __forceinline__ void attn_bwd_prep_block(const int bx, const int by, const u16* __restrict__ o, const u16* __restrict__ d_o,
-                                                    int64_t bstride, int64_t ld, float* __restrict__ delta, int heads, int nq) {
+                                                    int64_t bstride, int64_t ld, float* __restrict__ delta, int heads, int nq,
+                                                    const float* __restrict__ lse, const int32_t* __restrict__ row_slot,
+                                                    float* __restrict__ rowc, int n_qtiles) {
   // delta is (b, head, q): a row touches it at a stride of nq floats per head.  It crosses LDS so that the global accesses are
   // 128-byte runs along q (one row at a time they were 4-byte accesses in 8 different lines per row).
   __shared__ float del_s[8][PREP_ROWS];
@@ -671,7 +676,15 @@ __device__ __forceinline__ void attn_bwd_prep_block(const int bx, const int by, 
     __syncthreads();
     {
       const int hh = tid / PREP_ROWS, r = tid % PREP_ROWS;          // 8 heads x 32 rows = 256 threads
-      if (h0 + hh < heads && q_begin + r < q_end) delta[((int64_t)b * heads + h0 + hh) * nq + q_begin + r] = del_s[hh][r];
+      if (h0 + hh < heads && q_begin + r < q_end) {
+        if (!row_slot) delta[((int64_t)b * heads + h0 + hh) * nq + q_begin + r] = del_s[hh][r];
+        else {
+          const int q = q_begin + r, slot = row_slot[q];
+          float* dst = rowc + (((int64_t)b * heads + h0 + hh) * n_qtiles + (slot >> 6)) * 128 + (slot & 63);
+          dst[0] = -lse[((int64_t)b * heads + h0 + hh) * nq + q];
+          dst[64] = -del_s[hh][r];
+        }
+      }
     }
     __syncthreads();
   }
@@ -743,8 +756,9 @@ __device__ __forceinline__ void attn_dvmean_block(const int bx, const int by, co
 // 0 .. n_prep - 1 of a sample compute delta, the `heads` blocks behind them dvmean
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restrict__ o, const u16* __restrict__ d_o, int64_t bstride, int64_t ld,
                                                              const float* __restrict__ lse, float* __restrict__ delta,
-                                                             float* __restrict__ dvmean, int heads, int nq, float inv_nk, int n_prep) {
-  if ((int)blockIdx.x < n_prep) attn_bwd_prep_block((int)blockIdx.x, (int)blockIdx.y, o, d_o, bstride, ld, delta, heads, nq);
+                                                             float* __restrict__ dvmean, int heads, int nq, float inv_nk, int n_prep,
+                                                             const int32_t* __restrict__ row_slot, float* __restrict__ rowc, int n_qtiles) {
+  if ((int)blockIdx.x < n_prep) attn_bwd_prep_block((int)blockIdx.x, (int)blockIdx.y, o, d_o, bstride, ld, delta, heads, nq, lse, row_slot, rowc, n_qtiles);
   else attn_dvmean_block((int)blockIdx.x - n_prep, (int)blockIdx.y, d_o, bstride, ld, lse, dvmean, heads, nq, inv_nk);
 }
 extern "C" int mca_attn_bwd_prep(const uint16_t* o, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld,
@@ -755,6 +769,17 @@ extern "C" int mca_attn_bwd_prep(const uint16_t* o, const uint16_t* d_o, int64_t
   if (heads > 65535 || batch > 65535) return MCA_E_UNSUPPORTED;
   const int n_prep = (nq + PREP_ROWS - 1) / PREP_ROWS;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(n_prep + heads, batch), dim3(256), 0, as_stream(stream), o, d_o, o_bstride, o_ld, lse, delta,
-                     dvmean, heads, nq, 1.f / (float)nk, n_prep);
+                     dvmean, heads, nq, 1.f / (float)nk, n_prep, (const int32_t*)nullptr, (float*)nullptr, 0);
+  return launch_status();
+}
+extern "C" int mca_attn_bwd_prep_onepass(const uint16_t* o, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld, const float* lse,
+                                         const int32_t* row_slot, float* rowc, float* dvmean, int batch, int heads, int n, int n_qtiles,
+                                         mca_stream_t stream) {
+  if (!o || !d_o || !lse || !row_slot || !rowc || !dvmean || batch <= 0 || heads <= 0 || n <= 0 || n_qtiles <= 0) return MCA_E_BADARG;
+  if (o_ld % 8 || o_bstride % 8 || (uintptr_t)o % 16 || (uintptr_t)d_o % 16) return MCA_E_ALIGN;
+  if (heads > 65535 || batch > 65535) return MCA_E_UNSUPPORTED;
+  const int n_prep = (n + PREP_ROWS - 1) / PREP_ROWS;
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(n_prep + heads, batch), dim3(256), 0, as_stream(stream), o, d_o, o_bstride, o_ld, lse, (float*)nullptr,
+                     dvmean, heads, n, 1.f / (float)n, n_prep, row_slot, rowc, n_qtiles);
   return launch_status();
 }

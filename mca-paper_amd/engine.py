@@ -27,7 +27,7 @@ import torch
 
 from . import hip
 from .encoders import EmbeddedSequenceEncoder, TabularEncoder
-from .hip import AttnBwd2Args, AttnFp8BwdOperands, AttnFp8Operands, AttnFwdArgs, LossTerm, call, ptr, stream_ptr
+from .hip import AttnBwd1Args, AttnBwd2Args, AttnFp8BwdOperands, AttnFp8Operands, AttnFwdArgs, LossTerm, call, ptr, stream_ptr
 
 LN_EPS = 1e-5
 FWD_BQ, FWD_BK = 128, 64
@@ -49,7 +49,8 @@ def debug_options() -> dict:
     dkv_keys=256 (8-wavefront key blocks in the dK/dV pass), fwd64=1 (the round-4 query-block forward attention kernel,
     attention_fwd64.hip, instead of the 128-row-tile one: correct, measured 24 % slower), lazy_softmax=1
     (MCA_ATTN_LAZY_REFERENCE: the forward attention's softmax reference moves lazily, -9 % on that kernel).  Kernel-level knobs: include/mca_hip_debug.h (hip.knobs)."""
-    opts = {"overlap_wgrad": None, "group_wgrad": True, "mask_mfma": True, "dkv_keys": 128, "fwd64": False, "lazy_softmax": False}
+    opts = {"overlap_wgrad": None, "group_wgrad": True, "mask_mfma": True, "dkv_keys": 128, "fwd64": False, "lazy_softmax": False,
+            "onepass": None}          # onepass=0|1: the one-pass attention backward (attention_bwd1.hip); default: by size
     for item in filter(None, os.environ.get("MCA_DEBUG", "").split(",")):
         k, _, v = item.partition("=")
         k = k.strip()
@@ -74,6 +75,18 @@ class _Sched:
             lo, hi = int(s.k_ptr[kb]), int(s.k_ptr[kb + 1])
             wg[i] = (kb, lo, hi - lo, int(s.k_qt[lo]) if hi > lo else 0)
         self.k_wg = _dev(wg, device)
+
+
+class _OnePassSched:
+    """device copies of a structure.OnePassSchedule (mca_attn_bwd_onepass)"""
+
+    def __init__(self, s, device):
+        self.s = s
+        self.qt_desc, self.kb_desc = _dev(s.qt_desc.astype(np.int32), device), _dev(s.kb_desc.astype(np.int32), device)
+        self.kb_qt = _dev(s.kb_qt.astype(np.uint32).view(np.int32), device)
+        self.visit, self.row_slot = _dev(s.visit.astype(np.uint8), device), _dev(s.row_slot.astype(np.int32), device)
+        self.n_qt, self.n_kb, self.max_list = len(s.qt_desc), len(s.kb_desc), int(s.kb_desc[:, 3].max())
+        self.fits = self.n_qt <= 256 and self.n_kb <= 64 and self.max_list <= 256          # the kernel's LDS tables
 
 
 class _BlockSched:
@@ -219,6 +232,11 @@ class FusionEngine:
         dkv_keys = self.dbg["dkv_keys"]
         self.dkv_keys = dkv_keys
         self.sched_attn_b2 = _Sched(st.attn_schedule(BWD_BQ, dkv_keys), dev)
+        # one-pass backward of the layer attention: needs the mask product and tables that fit the kernel's LDS
+        self.sched_onepass = None
+        if self.mask_mfma and self.dbg["onepass"] is not False:
+            sc = _OnePassSched(st.attn_onepass_schedule(aligned=True), dev)
+            self.sched_onepass = sc if sc.fits else None
         if self.eao:
             self.seg_start = _dev(st.seg_start, dev)
         else:
@@ -499,8 +517,12 @@ class FusionEngine:
 
     def _attn_bwd2(self, q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, d_o, lse, delta, dq_ptr, dq_bstride, dq_ld, dq_f32, dkv,
                    dk_off, dv_off, dkv_ld, qmask, sched_f, sched_b, ws, b, nq, layer=0):
-        """two-pass backward (attention_bwd2.hip): dq (bf16 or fp32) is WRITTEN, not accumulated."""
+        """two-pass backward (attention_bwd2.hip): dq (bf16 or fp32) is WRITTEN, not accumulated.  The layer attention at a
+        batch that gives every CU a (sample, head) takes the one-pass form (attention_bwd1.hip) instead."""
         N, esz = self.N, 2
+        if self.use_onepass(ws, b, nq, dq_f32):
+            return self._attn_bwd1(q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, d_o, lse, dq_ptr, dq_bstride, dq_ld, dkv, dk_off, dv_off,
+                                   dkv_ld, ws, b)
         call("mca_attn_bwd_prep", o.data_ptr(), d_o.data_ptr(), nq * o.stride(0), o.stride(0), lse.data_ptr(),
              delta.data_ptr(), ws["dvmean"].data_ptr(), b, self.H, nq, N, stream_ptr())
         a = AttnBwd2Args()
@@ -533,6 +555,43 @@ class FusionEngine:
         else:
             call("mca_attn_bwd_dkv", C.byref(a), stream_ptr(), flops=8.0 * 64 * pairs * self.H * b * 0.6)
             call("mca_attn_bwd_dq", C.byref(a), stream_ptr(), flops=8.0 * 64 * pairs * self.H * b * 0.4)
+        hip.set_tag("")
+
+    ONEPASS_MIN_WG = 192          # (sample, head) pairs from which the one-pass backward is the default: one workgroup per CU
+
+    def use_onepass(self, ws, b, nq, dq_f32=False) -> bool:
+        if self.sched_onepass is None or nq != self.N or dq_f32 or ws.get("khot") is None or self.fp8_backward_on(ws, nq):
+            return False
+        want = self.dbg["onepass"]
+        return bool(want) if want is not None else b * self.H >= self.ONEPASS_MIN_WG
+
+    def _attn_bwd1(self, q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, d_o, lse, dq_ptr, dq_bstride, dq_ld, dkv, dk_off, dv_off, dkv_ld, ws, b):
+        """one-pass backward of the layer attention (attention_bwd1.hip): dq, dk, dv bf16, every element written"""
+        N, esz, sc = self.N, 2, self.sched_onepass
+        if "rowc" not in ws:          # positions past a tile's rows: -inf | 0 (written once; the prep kernel only touches real rows)
+            rc = torch.empty(b, self.H, sc.n_qt, 2, 64, dtype=torch.float32, device=self.device)
+            rc[:, :, :, 0] = float("-inf"); rc[:, :, :, 1] = 0.0
+            ws["rowc"] = rc
+            ws["dq_acc"] = torch.empty(b * self.H * sc.n_qt * 4096, dtype=torch.float32, device=self.device)
+        call("mca_attn_bwd_prep_onepass", o.data_ptr(), d_o.data_ptr(), N * o.stride(0), o.stride(0), lse.data_ptr(), sc.row_slot.data_ptr(),
+             ws["rowc"].data_ptr(), ws["dvmean"].data_ptr(), b, self.H, N, sc.n_qt, stream_ptr())
+        a = AttnBwd1Args()
+        a.q, a.q_bstride, a.q_ld = q, q_bstride, q_ld
+        a.k, a.v = kv.data_ptr() + k_off * esz, kv.data_ptr() + v_off * esz
+        a.kv_bstride, a.kv_ld = N * kv_ld, kv_ld
+        a.d_o, a.o_bstride, a.o_ld = d_o.data_ptr(), N * d_o.stride(0), d_o.stride(0)
+        a.rowc, a.dvmean = ws["rowc"].data_ptr(), ws["dvmean"].data_ptr()
+        a.dq, a.dq_bstride, a.dq_ld = dq_ptr, dq_bstride, dq_ld
+        a.dk, a.dv = dkv.data_ptr() + dk_off * esz, dkv.data_ptr() + dv_off * esz
+        a.dkv_bstride, a.dkv_ld = N * dkv_ld, dkv_ld
+        a.dq_acc = ws["dq_acc"].data_ptr()
+        a.keyinfo, a.ktile_flags, a.khot, a.qblk = ws["keyinfo"].data_ptr(), ws["kflags"].data_ptr(), ws["khot"].data_ptr(), self.qblk_attn.data_ptr()
+        a.qt_desc, a.kb_desc, a.kb_qt, a.visit = sc.qt_desc.data_ptr(), sc.kb_desc.data_ptr(), sc.kb_qt.data_ptr(), sc.visit.data_ptr()
+        a.n_qtiles, a.n_kblocks, a.max_list = sc.n_qt, sc.n_kb, sc.max_list
+        a.batch, a.heads, a.n, a.nk_pad, a.n_ktiles64 = b, self.H, N, self.nk_pad, (N + 63) // 64
+        a.scale, a.flags = self.scale, self.attn_flags
+        hip.set_tag("layer")
+        call("mca_attn_bwd_onepass", C.byref(a), stream_ptr(), flops=8.0 * 64 * sc.s.allowed_pairs * self.H * b)
         hip.set_tag("")
 
     # ------------------------------------------------------------------------------------------------

@@ -99,6 +99,23 @@ class AttnBwd2Args(C.Structure):
     ]
 
 
+class AttnBwd1Args(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("q_bstride", C.c_int64), ("q_ld", C.c_int64),
+        ("k", C.c_void_p), ("v", C.c_void_p), ("kv_bstride", C.c_int64), ("kv_ld", C.c_int64),
+        ("d_o", C.c_void_p), ("o_bstride", C.c_int64), ("o_ld", C.c_int64),
+        ("rowc", C.c_void_p), ("dvmean", C.c_void_p),
+        ("dq", C.c_void_p), ("dq_bstride", C.c_int64), ("dq_ld", C.c_int64),
+        ("dk", C.c_void_p), ("dv", C.c_void_p), ("dkv_bstride", C.c_int64), ("dkv_ld", C.c_int64),
+        ("dq_acc", C.c_void_p),
+        ("keyinfo", C.c_void_p), ("ktile_flags", C.c_void_p), ("khot", C.c_void_p), ("qblk", C.c_void_p),
+        ("qt_desc", C.c_void_p), ("kb_desc", C.c_void_p), ("kb_qt", C.c_void_p), ("visit", C.c_void_p),
+        ("n_qtiles", C.c_int), ("n_kblocks", C.c_int), ("max_list", C.c_int),
+        ("batch", C.c_int), ("heads", C.c_int), ("n", C.c_int), ("nk_pad", C.c_int), ("n_ktiles64", C.c_int),
+        ("scale", C.c_float), ("flags", C.c_int),
+    ]
+
+
 _P, _I64, _I, _F = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
 # name -> (restype, argtypes).  Must list EVERY symbol include/mca_hip.h declares (tests check this).
@@ -135,6 +152,8 @@ SIGNATURES = {
     "mca_attn_quant_mxfp8": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, C.POINTER(AttnFp8Operands), _I, _I, _I, _P]),
     "mca_attn_fwd_fp8": (_I, [C.POINTER(AttnFwdArgs), C.POINTER(AttnFp8Operands), _P]),
     "mca_attn_bwd_prep": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "mca_attn_bwd_onepass": (_I, [C.POINTER(AttnBwd1Args), _P]),
+    "mca_attn_bwd_prep_onepass": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mca_attn_bwd_dq": (_I, [C.POINTER(AttnBwd2Args), _P]),
     "mca_attn_bwd_dkv": (_I, [C.POINTER(AttnBwd2Args), _P]),
     "mca_attn_quant_bwd_mxfp8": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _P, _I64, _I64, C.POINTER(AttnFp8BwdOperands), _I, _I, _I, _I, _P]),

@@ -162,6 +162,80 @@ def build_block_schedule(qmask: np.ndarray, kgroup: np.ndarray, rows: int = 256,
 
 
 @dataclass
+class OnePassSchedule:
+    """Work list of the one-pass attention backward (mca_attn_bwd_onepass, attention_bwd1.hip): ONE workgroup owns a whole
+    (sample, head), walks the key blocks in order and, inside a key block, the query tiles the structure allows."""
+    tq: int
+    tk: int
+    qt_desc: np.ndarray     # (nQ, 2) int32 {first row, rows <= tq}
+    kb_desc: np.ndarray     # (nK, 4) int32 {first key, keys <= tk, first list entry, entries}
+    kb_qt: np.ndarray       # (nnz,) uint32 query tile | (every pair of the tile structurally allowed << 31)
+    visit: np.ndarray       # (nK, nQ) uint8: the key block lists the query tile
+    row_slot: np.ndarray    # (n,) int32: tile * tq + position of the row inside its tile
+    allowed_pairs: int
+    visited_pairs: int      # tq * tk per list entry (executed work of a full-width step)
+
+
+def _cut_runs(runs, cap: int):
+    """Cut [(start, length)] runs of equal structure into pieces of at most ``cap`` rows: a run of at least cap / 2 rows is
+    split evenly into pieces of its own, shorter neighbours are merged up to ``cap``."""
+    pieces, pend = [], None
+    for r0, ln in runs:
+        if ln >= cap // 2:
+            if pend:
+                pieces.append(tuple(pend)); pend = None
+            nch = -(-ln // cap)
+            base, rem, at = ln // nch, ln % nch, r0
+            for c in range(nch):
+                sz = base + (1 if c < rem else 0)
+                pieces.append((at, sz)); at += sz
+        elif pend and pend[1] + ln <= cap and pend[0] + pend[1] == r0:
+            pend[1] += ln
+        else:
+            if pend:
+                pieces.append(tuple(pend))
+            pend = [r0, ln]
+    if pend:
+        pieces.append(tuple(pend))
+    return pieces
+
+
+def build_onepass_schedule(qmask: np.ndarray, kgroup: np.ndarray, tq: int = 64, tk: int = 256, aligned: bool = True) -> OnePassSchedule:
+    """Query tiles of at most ``tq`` rows and key blocks of at most ``tk`` keys.  aligned: both are cut ALONG the structure (a
+    modality's 1,500 tokens become 24 query tiles of 62-63 rows and 6 key blocks of 250 keys: no tile straddles two modalities,
+    CMU: 193 steps of 64 x 256 per (sample, head) against 210 on the plain grid); else the plain grid."""
+    n = len(qmask)
+    assert len(kgroup) == n, "self-attention only"
+    if aligned:
+        runs, start = [], 0
+        for i in range(1, n + 1):
+            if i == n or qmask[i] != qmask[start] or kgroup[i] != kgroup[start]:
+                runs.append((start, i - start)); start = i
+        qts, kbs = _cut_runs(runs, tq), _cut_runs(runs, tk)
+    else:
+        qts = [(r, min(tq, n - r)) for r in range(0, n, tq)]
+        kbs = [(r, min(tk, n - r)) for r in range(0, n, tk)]
+    assert sum(x[1] for x in qts) == n and sum(x[1] for x in kbs) == n
+    allowed = ((qmask[:, None].astype(np.uint32) >> kgroup[None, :].astype(np.uint32)) & 1).astype(bool)
+    visit = np.zeros((len(kbs), len(qts)), np.uint8)
+    kb_desc, kb_qt = [], []
+    for ki, (k0, kn) in enumerate(kbs):
+        first = len(kb_qt)
+        for qi, (q0, qn) in enumerate(qts):
+            blk = allowed[q0:q0 + qn, k0:k0 + kn]
+            if blk.any():
+                visit[ki, qi] = 1
+                kb_qt.append(np.uint32(qi) | (np.uint32(1 << 31) if blk.all() else np.uint32(0)))
+        kb_desc.append((k0, kn, first, len(kb_qt) - first))
+    row_slot = np.zeros(n, np.int32)
+    for qi, (q0, qn) in enumerate(qts):
+        row_slot[q0:q0 + qn] = qi * tq + np.arange(qn)
+    return OnePassSchedule(tq=tq, tk=tk, qt_desc=np.asarray(qts, np.int32).reshape(-1, 2), kb_desc=np.asarray(kb_desc, np.int32).reshape(-1, 4),
+                           kb_qt=np.asarray(kb_qt, np.uint32), visit=visit, row_slot=row_slot,
+                           allowed_pairs=int(allowed.sum()), visited_pairs=len(kb_qt) * tq * tk)
+
+
+@dataclass
 class FusionStructure:
     """Everything the reference's ``MCA.__init__`` derives from the config (model.py:305-372)."""
     token_dims: List[int]
@@ -285,6 +359,9 @@ class FusionStructure:
 
     def attn_block_schedule(self, rows: int = 256, bk: int = 64) -> BlockSchedule:
         return build_block_schedule(self.qmask_attn, self.kgroup, rows, bk)
+
+    def attn_onepass_schedule(self, aligned: bool = True) -> OnePassSchedule:
+        return build_onepass_schedule(self.qmask_attn, self.kgroup, 64, 256, aligned)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -619,6 +619,69 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first, prescaled=True, spi
             torch.cuda.synchronize()
             assert torch.equal(dq2, dq4) and torch.equal(dkv2, dkv4)
 
+    # ---- backward in ONE pass (attention_bwd1.hip): five products, dQ summed over the key blocks by a private read-modify-write.
+    # Against the dense fp64 gradients (the two-pass bound), against the two-pass results, bitwise repeatable, and the same on the
+    # structure-aligned tables and on the plain 64 x 256 grid
+    if not pool and prescaled and int(st.kgroup.max()) <= 14:
+        S_ = importlib.import_module("mca-paper_amd.structure")
+        ref2 = (dq2.float(), dkv2[:, :, D:2 * D].float(), dkv2[:, :, 2 * D:].float())          # (the fp32-dq form of the loop's last turn)
+        outs = []
+        for aligned in (True, False):
+            got = _run_onepass(H, S_.build_onepass_schedule(qmask_np, st.kgroup, 64, 256, aligned), b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean,
+                               keyinfo, kflags, khot, qblk)
+            for rep in got:
+                e_q, e_k, e_v = rel(rep[0].float(), rdq), rel(rep[1][:, :, D:2 * D].float(), rdk), rel(rep[1][:, :, 2 * D:].float(), rdv)
+                assert e_q < 1.5e-2 and e_k < 1.5e-2 and e_v < 1.5e-2, f"one-pass backward rel err dq {e_q} dk {e_k} dv {e_v} (aligned={aligned})"
+                assert (rep[1][:, :, :D] == 0).all()
+            assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])          # a second launch: the same bits
+            d_q, d_k, d_v = rel(got[0][0].float(), ref2[0]), rel(got[0][1][:, :, D:2 * D].float(), ref2[1]), rel(got[0][1][:, :, 2 * D:].float(), ref2[2])
+            assert d_q < 6e-3 and d_k < 6e-3 and d_v < 6e-3, f"one-pass vs two-pass: dq {d_q} dk {d_k} dv {d_v} (aligned={aligned})"
+            outs.append(got[0])
+        assert rel(outs[0][0].float(), outs[1][0].float()) < 6e-3
+
+
+def _run_onepass(H, sc, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean_ref, keyinfo, kflags, khot, qblk):
+    """mca_attn_bwd_prep_onepass + mca_attn_bwd_onepass on the tables `sc`, twice; returns [(dq, dkv), (dq, dkv)]"""
+    dev, D = "cuda", heads * 64
+    i32 = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int32) if x.dtype == np.uint32 else np.ascontiguousarray(x)).to(dev)
+    qt_desc, kb_desc, kb_qt, visit, row_slot = i32(sc.qt_desc), i32(sc.kb_desc), i32(sc.kb_qt), i32(sc.visit), i32(sc.row_slot)
+    nqt, nkb = len(sc.qt_desc), len(sc.kb_desc)
+    rowc = torch.empty(b, heads, nqt, 2, 64, device=dev)
+    rowc[:, :, :, 0] = float("-inf"); rowc[:, :, :, 1] = 0.0
+    dvmean = torch.full_like(dvmean_ref, 3.0)
+    H.call("mca_attn_bwd_prep_onepass", o.data_ptr(), d_o.data_ptr(), N * D, D, lse.data_ptr(), row_slot.data_ptr(), rowc.data_ptr(),
+           dvmean.data_ptr(), b, heads, N, nqt, H.stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(dvmean, dvmean_ref)
+    # the row constants, tile by tile
+    delta_ref = (d_o.float() * o.float().view(b, N, D)).view(b, N, heads, 64).sum(-1).permute(0, 2, 1)          # (b, h, N)
+    for t, (r0, rn) in enumerate(sc.qt_desc.tolist()):
+        assert torch.equal(rowc[:, :, t, 0, :rn], -lse[:, :, r0:r0 + rn])
+        assert (rowc[:, :, t, 1, :rn] + delta_ref[:, :, r0:r0 + rn]).abs().max() < 1e-3 * (1 + float(delta_ref.abs().max()))
+        assert torch.isinf(rowc[:, :, t, 0, rn:]).all() and (rowc[:, :, t, 1, rn:] == 0).all()
+    acc = torch.full((b * heads * nqt * 4096,), float("nan"), device=dev)          # contents irrelevant on entry
+    out = []
+    for _ in range(2):
+        dq = torch.full((b, N, D), 7.0, device=dev, dtype=torch.bfloat16)
+        dkv = torch.zeros(b, N, 3 * D, dtype=torch.bfloat16, device=dev)
+        a1 = H.AttnBwd1Args()
+        a1.q, a1.q_bstride, a1.q_ld = qkv.data_ptr(), N * 3 * D, 3 * D
+        a1.k, a1.v, a1.kv_bstride, a1.kv_ld = qkv.data_ptr() + D * 2, qkv.data_ptr() + 2 * D * 2, N * 3 * D, 3 * D
+        a1.d_o, a1.o_bstride, a1.o_ld = d_o.data_ptr(), N * D, D
+        a1.rowc, a1.dvmean = rowc.data_ptr(), dvmean.data_ptr()
+        a1.dq, a1.dq_bstride, a1.dq_ld = dq.data_ptr(), N * D, D
+        a1.dk, a1.dv, a1.dkv_bstride, a1.dkv_ld = dkv.data_ptr() + D * 2, dkv.data_ptr() + 2 * D * 2, N * 3 * D, 3 * D
+        a1.dq_acc = acc.data_ptr()
+        a1.keyinfo, a1.ktile_flags, a1.khot, a1.qblk = keyinfo.data_ptr(), kflags.data_ptr(), khot.data_ptr(), qblk.data_ptr()
+        a1.qt_desc, a1.kb_desc, a1.kb_qt, a1.visit = qt_desc.data_ptr(), kb_desc.data_ptr(), kb_qt.data_ptr(), visit.data_ptr()
+        a1.n_qtiles, a1.n_kblocks, a1.max_list = nqt, nkb, int(sc.kb_desc[:, 3].max())
+        a1.batch, a1.heads, a1.n, a1.nk_pad, a1.n_ktiles64 = b, heads, N, nk_pad, (N + 63) // 64
+        a1.scale, a1.flags = 0.125, H.ATTN_Q_PRESCALED
+        H.call("mca_attn_bwd_onepass", C.byref(a1), H.stream_ptr())
+        torch.cuda.synchronize()
+        out.append((dq, dkv))
+    return out
+
 
 @pytest.mark.parametrize("variant,pool,drop", [("mca", False, False), ("mca", False, True), ("zorro", False, True),
                                                ("mca", True, True), ("zorro", True, False)])

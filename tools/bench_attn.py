@@ -31,14 +31,17 @@ def bwd():
 def timeit(fn, n=10):
     for _ in range(3): fn()
     torch.cuda.synchronize()
-    H.profile_start(("mca_attn_fwd", "mca_attn_fwd_fp8", "mca_attn_quant_mxfp8", "mca_attn_bwd_dq", "mca_attn_bwd_dkv", "mca_attn_bwd_dq_fp8", "mca_attn_bwd_dkv_fp8", "mca_attn_quant_bwd_mxfp8"))
+    H.profile_start(("mca_attn_fwd", "mca_attn_fwd_fp8", "mca_attn_quant_mxfp8", "mca_attn_bwd_onepass", "mca_attn_bwd_dq", "mca_attn_bwd_dkv", "mca_attn_bwd_dq_fp8", "mca_attn_bwd_dkv_fp8", "mca_attn_quant_bwd_mxfp8"))
     for _ in range(n): fn()
     return H.profile_stop()
 def fwd8():
     eng.set_attention_dtype("fp8"); fwd(); eng.set_attention_dtype("bf16")
 def bwd8():
     eng.set_attention_dtype("fp8"); bwd(); eng.set_attention_dtype("bf16")
-cases = [("fwd", fwd, {}), ("fwd register-staged (3 wavefronts per SIMD)", fwd, {13: 1}), ("fwd fp8", fwd8, {}), ("fwd fp8 register-staged", fwd8, {9: 32}), ("bwd", bwd, {}), ("bwd fp8", bwd8, {})]
+def bwd1():
+    eng.dbg["onepass"] = True; bwd(); eng.dbg["onepass"] = False
+eng.dbg["onepass"] = False          # "bwd" = the two-pass form; "bwd one-pass" = attention_bwd1.hip
+cases = [("fwd", fwd, {}), ("fwd register-staged (3 wavefronts per SIMD)", fwd, {13: 1}), ("fwd fp8", fwd8, {}), ("fwd fp8 register-staged", fwd8, {9: 32}), ("bwd", bwd, {}), ("bwd one-pass", bwd1, {}), ("bwd fp8", bwd8, {})]
 if os.environ.get("MCA_BENCH_ATTN_ONLY"):
     cases = [c for c in cases if c[0] == os.environ["MCA_BENCH_ATTN_ONLY"]]
 if os.environ.get("MCA_BENCH_ATTN_EXTRA"):
