@@ -16,7 +16,9 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++20", "-fPIC", "-munsafe-fp-ato
 EXTRA = {"attention_fwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attention_bwd2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
          "attention_fp8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
          # hand-placed issue order: the SLP vectoriser packs adjacent f32 adds into v_pk_add_f32 and moves whole groups with them
-         "attention_fwd64.hip": ["-fno-slp-vectorize"]}
+         "attention_fwd64.hip": ["-fno-slp-vectorize"],
+         # generated issue order (attention_bwd1_sched.inc): keep single-instruction multiplies single
+         "attention_bwd1.hip": ["-fno-slp-vectorize"]}
 
 
 def needs_build() -> bool:

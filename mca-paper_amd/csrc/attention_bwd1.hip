@@ -26,6 +26,7 @@
 #define B1_MAX_KB 64
 #define B1_MAX_LIST 256
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 
 // [rows][64] bf16 image (128-byte rows) serving ds_read_b128 row reads AND ds_read_b64_tr_b16 transposed reads (as attention_bwd2.hip)
 __device__ __forceinline__ int b1_off(int r, int c) {
@@ -350,6 +351,456 @@ __global__ __launch_bounds__(256, 1) void attn_bwd1_kernel(mca_attn_bwd1_args a,
     }
   }
 }
+// =====================================================================================================
+// The production form of the kernel above: the same work decomposition, as a SOFTWARE PIPELINE whose issue order is generated
+// (tools/gen_bwd1_schedule.py -> attention_bwd1_sched.inc: one slot = one MFMA and the single-issue work in its shadow).
+//   * register classes by hand (every MFMA is inline asm): dK^T / dV^T accumulators, the K / V operand fragments and the Q / dO
+//     row fragments live in the accumulator half for the whole key block; scores, packed P / dS, row constants, transposed
+//     fragments and dQ in the vector half.  (Left to hipcc, the plain form moves 730 registers between the halves per step.)
+//   * the loop is rotated: iteration X computes the scores of blocks 0..3 of step X, and finishes step X-1 (block 3's vector work
+//     fills the shadow of A0; the dV / dK products of its blocks 2 and 3; its dQ product behind the iteration's ONE barrier); Q / dO / row-constant /
+//     mask-operand tiles arrive by LDS-DMA two steps ahead (three stages), the dQ partial of the next tile is requested a
+//     whole iteration ahead; waits are counted (vmcnt by the number of younger operations).
+//   * an inline-asm MFMA gets no hazard padding from hipcc: the schedule keeps LAG slots between a matrix instruction and the
+//     first vector reader of its result; the two places outside the schedule (dQ store, block epilogue) pad by hand.
+// =====================================================================================================
+#define B1P_NST 3
+#define B1_SB() __builtin_amdgcn_sched_barrier(0)
+// (PAD: "s_nop 1" ahead of the MFMA inside the statement - two wait states between a compiler-placed register copy or select
+//  and the MFMA that reads it.  The first and the drain iteration of a key block are padded (hipcc copies the zeroed accumulators
+//  and the carried state into place just ahead of their first reader there: tools/audit_bwd1_isa.py found them 0-1 states
+//  ahead); the steady-state loop is not, and the audit checks every build of it.)
+#define MF_INIT_VV(D, A, B, C) do { if (STEADY) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(D) : "v"(A), "v"(B), "v"(C)); \
+                                    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(D) : "v"(A), "v"(B), "v"(C)); } while (0)
+#define MF_INIT_AA(D, A, B, C) do { if (STEADY) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(D) : "a"(A), "a"(B), "v"(C)); \
+                                    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(D) : "a"(A), "a"(B), "v"(C)); } while (0)
+#define MF_ACC_AA(D, A, B) do { if (STEADY) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "a"(A), "a"(B)); \
+                                else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "a"(A), "a"(B)); } while (0)
+#define MF_ACCA_VV(D, A, B) do { if (STEADY) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(D) : "v"(A), "v"(B)); \
+                                 else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(D) : "v"(A), "v"(B)); } while (0)
+#define MF_ACC_VV(D, A, B) do { if (STEADY) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "v"(A), "v"(B)); \
+                                else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "v"(A), "v"(B)); } while (0)
+// LDS accesses by 32-bit byte address = per-lane base register + compile-time immediate (pointer arithmetic on u16* made hipcc
+// keep one address register per constant offset and spill them)
+#define LDS_P(T, ADDR) reinterpret_cast<__attribute__((address_space(3))) T*>(static_cast<uintptr_t>(ADDR))
+#define LDS_R8(ADDR) (*LDS_P(const bf16x8, ADDR))
+#define LDS_RF4(ADDR) (*LDS_P(const f32x4, ADDR))
+#define LDS_TR(ADDR) __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_P(bf16x4, ADDR))
+
+// (the body is a __device__ function: the host pass of hipcc checks the register constraints of inline asm in a __global__ body
+//  against the host's register classes)
+__device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, const int dbg, u16* lds) {
+  u16* stage_s = lds;                                             // B1P_NST stages
+  u16* kimg = stage_s + B1P_NST * B1_STAGE_U16;
+  u16* dsimg = kimg + TKB * DH;
+  uint32_t* list_s = reinterpret_cast<uint32_t*>(dsimg + 2 * TKB * TQ);
+  int2* qtd_s = reinterpret_cast<int2*>(list_s + B1_MAX_LIST);            // query tile table {first row, rows}
+  uint8_t* first_s = reinterpret_cast<uint8_t*>(qtd_s + B1_MAX_QT);
+  uint8_t* last_s = first_s + B1_MAX_QT;
+  uint8_t* live_s = last_s + B1_MAX_QT;
+  float* dvm_s = reinterpret_cast<float*>(live_s + B1_MAX_KB);
+
+  const int lin = (dbg & 16) ? (int)blockIdx.x : xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int h = lin % a.heads, b = lin / a.heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  const int64_t bh = (int64_t)b * a.heads + h;
+
+  const u16* qbase = a.q + (int64_t)b * a.q_bstride + h * DH;
+  const u16* obase = a.d_o + (int64_t)b * a.o_bstride + h * DH;
+  const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
+  const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
+  const float* rowc_g = a.rowc + bh * (int64_t)a.n_qtiles * 128;
+  float* acc_g = a.dq_acc + bh * (int64_t)a.n_qtiles * (TQ * DH) + wave * 1024 + lane * 4;
+  const uint8_t* kinfo_g = a.keyinfo + (int64_t)b * a.nk_pad;
+  const u16* khot_g = a.khot + (int64_t)b * a.nk_pad * 16;
+
+  if (tid < a.n_kblocks) {
+    const int4 d = reinterpret_cast<const int4*>(a.kb_desc)[tid];
+    const uint8_t* fl = a.ktile_flags + (int64_t)b * a.n_ktiles64;
+    int live = 0;
+    for (int t = d.x >> 6; t <= (d.x + d.y - 1) >> 6; t++) live |= fl[t];
+    live_s[tid] = live ? 1 : 0;
+  }
+  if (tid < DH) dvm_s[tid] = a.dvmean[(int64_t)b * a.heads * DH + h * DH + tid];
+  for (int qt = tid; qt < a.n_qtiles; qt += 256) qtd_s[qt] = reinterpret_cast<const int2*>(a.qt_desc)[qt];
+  __syncthreads();
+  for (int qt = tid; qt < a.n_qtiles; qt += 256) {
+    int first = 255, last = 255;
+    for (int kb = 0; kb < a.n_kblocks; kb++)
+      if (live_s[kb] && a.visit[kb * a.n_qtiles + qt]) { if (first == 255) first = kb; last = kb; }
+    first_s[qt] = (uint8_t)first; last_s[qt] = (uint8_t)last;
+  }
+  __syncthreads();
+  for (int qt = 0; qt < a.n_qtiles; qt++) {          // query tiles nobody visits: dq = 0
+    if (first_s[qt] != 255) continue;
+    const int2 qd = qtd_s[qt];
+    for (int i = tid; i < qd.y * 8; i += 256)
+      *reinterpret_cast<uint4*>(a.dq + (int64_t)b * a.dq_bstride + (int64_t)(qd.x + (i >> 3)) * a.dq_ld + h * DH + (i & 7) * 8) = make_uint4(0, 0, 0, 0);
+  }
+
+  // ---- loop-invariant LDS BYTE offsets of this lane inside a stage / an image
+  const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const u16*)lds;
+  unsigned o_rf[4];          // row fragment (row l31, k-step ks) of a 32-row block of a [rows][64] image
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) o_rf[ks] = 2u * (unsigned)b1_off(l31, 2 * ks + lh);
+  unsigned o_tr[2][2], o_dqa[2], o_dqb[2];          // transposed reads: [t][n] of a Q / dO tile (rows 8 t + 4 lh + tq); dQ operands (rows 8 lh + 4 t + tq)
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+#pragma unroll
+    for (int n = 0; n < 2; n++) o_tr[t][n] = 2u * (unsigned)(b1_off(8 * t + 4 * lh + tq, n * 4 + 2 * tg + (tp >> 1)) + 4 * (tp & 1));
+    o_dqa[t] = 2u * (unsigned)(b1_off(8 * lh + 4 * t + tq, (wave & 1) * 4 + 2 * tg + (tp >> 1)) + 4 * (tp & 1));
+    o_dqb[t] = 2u * (unsigned)(b1_off(8 * lh + 4 * t + tq, (wave >> 1) * 4 + 2 * tg + (tp >> 1)) + 4 * (tp & 1));
+  }
+  unsigned o_ds[2];          // dS^T store: (row * 128 + 8 lh) ^ (swizzle << 4); the 16-byte chunk c of the row is at o_ds ^ (c << 4)
+#pragma unroll
+  for (int kb = 0; kb < 2; kb++) { const int r = wave * 64 + kb * 32 + l31; o_ds[kb] = (unsigned)((r * 128 + 8 * lh) ^ (b1_swz(r) << 4)); }
+  const unsigned o_rc = 16u * (unsigned)lh, o_qb = (unsigned)(l31 * 32 + 16 * lh);
+  const unsigned STAGE_B = 2u * B1_STAGE_U16, KIMG_B = lds_b + 2u * B1P_NST * B1_STAGE_U16, DSIMG_B = KIMG_B + 2u * TKB * DH;
+  const float dk_scale = 0.6931471805599453f;
+
+  for (int kbi = 0; kbi < a.n_kblocks; kbi++) {
+    if (!live_s[kbi]) continue;          // (uniform over the workgroup)
+    const int4 kd = reinterpret_cast<const int4*>(a.kb_desc)[kbi];
+    const int key_start = __builtin_amdgcn_readfirstlane(kd.x), n_keys = __builtin_amdgcn_readfirstlane(kd.y);
+    const int e_begin = __builtin_amdgcn_readfirstlane(kd.z), n_ent = __builtin_amdgcn_readfirstlane(kd.w);
+    for (int i = tid; i < n_ent; i += 256) list_s[i] = a.kb_qt[e_begin + i];
+
+    bf16x8 kf[2][4], vf[2][4], khf[2];
+    bool ok[2];
+    int keyrow[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      const int slot = wave * 64 + kb * 32 + l31;
+      const bool valid = slot < n_keys;
+      const int key = key_start + (valid ? slot : n_keys - 1);
+      keyrow[kb] = valid ? key : -1;
+      ok[kb] = valid && kinfo_g[key] != 31;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        kf[kb][s] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * a.kv_ld + 16 * s + 8 * lh);
+        vf[kb][s] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * a.kv_ld + 16 * s + 8 * lh);
+      }
+      khf[kb] = *reinterpret_cast<const bf16x8*>(khot_g + (int64_t)key * 16 + 8 * lh);
+      if (!valid) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) khf[kb][j] = 0;
+        if (lh) khf[kb][7] = (short)0x3F80;
+      }
+    }
+    const bool wave_dead = !__any(ok[0] || ok[1]);
+    // (the mask operands exist HERE: left to hipcc, their selects sank to just ahead of the first inline-asm MFMA that reads them -
+    //  a vector write needs two wait states before an MFMA reads it, and hipcc pads nothing around inline asm: wrong scores on
+    //  some wavefronts)
+    asm volatile("" : "+v"(khf[0]), "+v"(khf[1]));
+#pragma unroll
+    for (int p = 0; p < 8; p++) {          // K image: wavefront w moves the rows of its own 64 slots
+      const int r = wave * 64 + p * 8 + (lane >> 3);
+      const int key = key_start + (r < n_keys ? r : n_keys - 1);
+      B1_DMA(kbase + (int64_t)key * a.kv_ld + (((lane & 7) ^ b1_swz(r)) << 3), kimg + (wave * 8 + p) * 512, 16);
+    }
+    f32x16 dk[2][2], dv[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { dk[kb][n][r] = 0.f; dv[kb][n][r] = 0.f; }
+    if (wave_dead) {          // its 64 rows of both dS^T images stay zero for the whole block
+      for (int i = lane; i < 2 * 64 * 8; i += 64) {
+        const int buf = i >> 9, r = (i >> 3) & 63, c = i & 7;
+        *reinterpret_cast<uint4*>(dsimg + buf * (TKB * TQ) + (wave * 64 + r) * 64 + c * 8) = make_uint4(0, 0, 0, 0);
+      }
+    }
+
+    // ---- staging of one step: five 1-KiB / 256-byte pieces per wavefront (Q and dO rows 16 w .. 16 w + 15, and one of: -lse, -delta,
+    // the two halves of the mask operand): every wavefront's vmcnt sees the same count
+    auto issue = [&](uint32_t ent, int st) {
+      const int qt = (int)(ent & 0x7fffffffu);
+      const int2 qd = qtd_s[qt];
+      const int row0 = __builtin_amdgcn_readfirstlane(qd.x), nrows = __builtin_amdgcn_readfirstlane(qd.y);
+      u16* sb_ = stage_s + st * B1_STAGE_U16;
+      // wave-uniform 64-bit bases + 32-bit per-lane byte offsets, all derived from the lane id HERE (hoisted out of the loop they
+      // were ten more registers to spill)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int r8 = ln >> 3;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int p = wave * 2 + u, r = p * 8 + r8;
+        const int row = row0 + (r < nrows ? r : nrows - 1);
+        const unsigned sw = (unsigned)(((ln & 7) ^ b1_swz(r)) << 4);
+        B1_DMA(reinterpret_cast<const char*>(qbase) + (size_t)((unsigned)row * (unsigned)(a.q_ld * 2) + sw), sb_ + p * 512, 16);
+        B1_DMA(reinterpret_cast<const char*>(obase) + (size_t)((unsigned)row * (unsigned)(a.o_ld * 2) + sw), sb_ + TQ * DH + p * 512, 16);
+      }
+      if (wave < 2) B1_DMA(reinterpret_cast<const char*>(rowc_g + (int64_t)qt * 128 + wave * 64) + (size_t)((unsigned)ln * 4u), sb_ + 2 * TQ * DH + wave * 128, 4);
+      else {
+        const int r = (wave - 2) * 32 + (ln >> 1);
+        const int row = row0 + (r < nrows ? r : nrows - 1);
+        B1_DMA(reinterpret_cast<const char*>(a.qblk) + (size_t)((unsigned)row * 32u + (unsigned)(ln & 1) * 16u), sb_ + 2 * TQ * DH + 256 + (wave - 2) * 512, 16);
+      }
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // list_s visible; every wavefront is past the previous block
+    if (n_ent > 0) issue(list_s[0], 0);
+    if (n_ent > 1) issue(list_s[1], 1);
+    if (n_ent > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // K image and stage 0 landed
+
+    // ---- pipeline state
+    f32x16 S[2], dP[2], cl, cd, dq;
+    u32x4v pb[2][2], sb[2][2];
+    bf16x8 rfQ[2][4], rfO[2][4], qbf, trO[2][2], trQ[2][2], da[2], db[2];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { S[0][r] = 0.f; S[1][r] = 0.f; dP[0][r] = 0.f; dP[1][r] = 0.f; dq[r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) { pb[i][j][w] = 0u; sb[i][j][w] = 0u; }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) { trO[i][j][e] = 0; trQ[i][j][e] = 0; }
+#pragma unroll
+    for (int e = 0; e < 8; e++) { da[0][e] = 0; da[1][e] = 0; db[0][e] = 0; db[1][e] = 0; }
+    int n_young = 0;                 // memory operations issued behind the last DMA (the barrier's vmcnt lets exactly these stay in flight)
+    int prev_qt = 0;
+    bool prev_first = false, prev_last = false;
+
+    // stage / image pointers of iteration `it`: cur = step it, nxt = step it + 1; ds_cur = step it's dS^T image, ds_prev = step it - 1's
+    auto iter = [&]<bool PREV, bool CUR, bool LIVE>(const int it) __attribute__((always_inline)) {
+      constexpr bool STEADY = PREV && CUR;          // (the loop body proper: unpadded MFMAs, audited)
+      const bool has_next2 = CUR && (it + 2 < n_ent);
+      // byte addresses: stage of this step / of the next one; dS^T image of this step / of the previous one
+      const unsigned st_c = lds_b + (unsigned)(it % B1P_NST) * STAGE_B, st_n = lds_b + (unsigned)((it + 1) % B1P_NST) * STAGE_B;
+      const unsigned ds_cur = DSIMG_B + (unsigned)(it & 1) * (2u * TKB * TQ), ds_prev = DSIMG_B + (unsigned)((it & 1) ^ 1) * (2u * TKB * TQ);
+      // per-lane bases (Q tile at +0, dO at +8192, row constants at +16384, mask operand at +16896 of a stage)
+      unsigned a_rf[4], a_tr[2][2], a_da[2], a_db[2];
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) a_rf[ks] = st_c + o_rf[ks];
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        a_tr[t][0] = st_c + o_tr[t][0]; a_tr[t][1] = st_c + o_tr[t][1];
+        a_da[t] = KIMG_B + o_dqa[t]; a_db[t] = ds_prev + o_dqb[t];
+      }
+      unsigned a_rc = st_c + 16384u + o_rc, a_qb = st_c + 16896u + o_qb;
+      // (opaque to the optimiser: loop strength reduction made every (base + immediate) pair an induction variable of its own -
+      //  45 registers, spilled - instead of one base register per fragment and an immediate in the instruction)
+      asm volatile("" : "+v"(a_rf[0]), "+v"(a_rf[1]), "+v"(a_rf[2]), "+v"(a_rf[3]), "+v"(a_rc), "+v"(a_qb));
+      asm volatile("" : "+v"(a_tr[0][0]), "+v"(a_tr[0][1]), "+v"(a_tr[1][0]), "+v"(a_tr[1][1]), "+v"(a_da[0]), "+v"(a_da[1]), "+v"(a_db[0]), "+v"(a_db[1]));
+      unsigned n_off = st_n - st_c;          // (wave-uniform: the next stage's same addresses)
+      asm volatile("" : "+s"(n_off));
+      unsigned ods[2] = {o_ds[0], o_ds[1]};          // (opaque: the sixteen xor-ed variants are recomputed, not hoisted and spilled)
+      asm volatile("" : "+v"(ods[0]), "+v"(ods[1]));
+      const uint32_t ent2 = has_next2 ? list_s[it + 2] : 0u;
+      bool issued = false;
+      asm volatile("s_nop 1" ::: "memory");          // register copies of the loop's back edge before the first MFMA reads them
+      B1_SB();
+
+#define A_M(J) MF_INIT_VV(S[(J) & 1], qbf, khf[(J) & 1], cl)
+#define A_S(J, KS) MF_ACC_AA(S[(J) & 1], rfQ[(J) >> 1][KS], kf[(J) & 1][KS])
+#define A_P(J, KS) do { if ((KS) == 0) MF_INIT_AA(dP[(J) & 1], rfO[(J) >> 1][0], vf[(J) & 1][0], cd); else MF_ACC_AA(dP[(J) & 1], rfO[(J) >> 1][KS], vf[(J) & 1][KS]); } while (0)
+#define VE_(SET, R) do { const float p_ = __builtin_amdgcn_exp2f(S[SET][R]); S[SET][R] = p_; dP[SET][R] *= p_; } while (0)
+#define VC_(SET, I) do { pb[SET][(I) >> 2][(I) & 3] = pack2bf_pk(S[SET][2 * (I)], S[SET][2 * (I) + 1]); \
+                         sb[SET][(I) >> 2][(I) & 3] = pack2bf_pk(dP[SET][2 * (I)], dP[SET][2 * (I) + 1]); \
+                         asm volatile("" :: "v"(pb[SET][(I) >> 2][(I) & 3]), "v"(sb[SET][(I) >> 2][(I) & 3])); } while (0)
+#define VE(J, R) VE_((J) & 1, R)
+#define VC(J, I) VC_((J) & 1, I)
+#define VEP(R) VE_(1, R)
+#define VCP(I) VC_(1, I)
+#define C_V(J, SP, N) MF_ACCA_VV(dv[(J) & 1][N], trO[SP][N], pb[(J) & 1][SP])
+#define C_K(J, SP, N) MF_ACCA_VV(dk[(J) & 1][N], trQ[SP][N], sb[(J) & 1][SP])
+#define CP_V(J, SP, N) MF_ACCA_VV(dv[(J) & 1][N], trO[SP][N], pb[(J) & 1][SP])
+#define CP_K(J, SP, N) MF_ACCA_VV(dk[(J) & 1][N], trQ[SP][N], sb[(J) & 1][SP])
+#define DSW_(IMG, QB, KB, SET, SP, T) *LDS_P(u32x2v, (IMG) + (ods[KB] ^ (unsigned)(((QB) * 4 + 2 * (SP) + (T)) << 4))) = u32x2v{sb[SET][SP][2 * (T)], sb[SET][SP][2 * (T) + 1]}
+#define DSW(J, SP, T) DSW_(ds_cur, (J) >> 1, (J) & 1, (J) & 1, SP, T)
+#define DSWP(SP, T) DSW_(ds_prev, 1, 1, 1, SP, T)
+#define RC4_(DST, ADDR, G) do { const f32x4 t_ = LDS_RF4(ADDR); DST[4 * (G)] = t_[0]; DST[4 * (G) + 1] = t_[1]; DST[4 * (G) + 2] = t_[2]; DST[4 * (G) + 3] = t_[3]; } while (0)
+#define RC_L(QB, G) RC4_(cl, a_rc + (unsigned)((QB) * 128 + 32 * (G)), G)
+#define RC_D(QB, G) RC4_(cd, a_rc + (unsigned)(256 + (QB) * 128 + 32 * (G)), G)
+#define NRC_L(G) RC4_(cl, a_rc + n_off + (unsigned)(32 * (G)), G)
+#define NRC_D(G) RC4_(cd, a_rc + n_off + (unsigned)(256 + 32 * (G)), G)
+#define RQB(QB) qbf = LDS_R8(a_qb + (unsigned)((QB) * 1024))
+#define NRQB() qbf = LDS_R8(a_qb + n_off)
+#define RF_Q(QB, KS) rfQ[QB][KS] = LDS_R8(a_rf[KS] + (unsigned)((QB) * 4096))
+#define RF_O(QB, KS) rfO[QB][KS] = LDS_R8(a_rf[KS] + (unsigned)(8192 + (QB) * 4096))
+#define NRF_Q(KS) rfQ[0][KS] = LDS_R8(a_rf[KS] + n_off)
+#define NRF_O(KS) rfO[0][KS] = LDS_R8(a_rf[KS] + n_off + 8192u)
+#define TR2_(DST, A0, A1, IMM) do { const bf16x4 lo_ = LDS_TR((A0) + (unsigned)(IMM)), hi_ = LDS_TR((A1) + (unsigned)(IMM)); DST = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7); } while (0)
+#define TR_O(QB, SP, N) TR2_(trO[SP][N], a_tr[0][N], a_tr[1][N], 8192 + (QB) * 4096 + (SP) * 2048)
+#define TR_Q(QB, SP, N) TR2_(trQ[SP][N], a_tr[0][N], a_tr[1][N], (QB) * 4096 + (SP) * 2048)
+#define DQR(K) do { TR2_(da[(K) & 1], a_da[0], a_da[1], (K) * 2048); TR2_(db[(K) & 1], a_db[0], a_db[1], (K) * 2048); } while (0)
+#define DQM(K) MF_ACC_VV(dq, da[(K) & 1], db[(K) & 1])
+#define WAIT_ACC() do { if (issued) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+      // the barrier: this wavefront's dS^T stores are done (lgkmcnt), its pieces of the next step's stage have landed (everything
+      // older than the n_young youngest memory operations)
+#define BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+                       if (n_young == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                           \
+                       else if (n_young == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                      \
+                       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
+                       __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#define ISSUE() do { if (has_next2) { issue(ent2, (it + 2) % B1P_NST); issued = true; n_young = 0; } } while (0)
+#include "attention_bwd1_sched.inc"
+#undef A_M
+#undef A_S
+#undef A_P
+#undef VE_
+#undef VC_
+#undef VE
+#undef VC
+#undef VEP
+#undef VCP
+#undef C_V
+#undef C_K
+#undef CP_V
+#undef CP_K
+#undef DSW_
+#undef DSW
+#undef DSWP
+#undef RC4_
+#undef RC_L
+#undef RC_D
+#undef NRC_L
+#undef NRC_D
+#undef RQB
+#undef NRQB
+#undef RF_Q
+#undef RF_O
+#undef NRF_Q
+#undef NRF_O
+#undef TR2_
+#undef TR_O
+#undef TR_Q
+#undef DQR
+#undef DQM
+#undef WAIT_ACC
+#undef BARRIER
+#undef ISSUE
+      // ---- tail: store the previous step's dQ block, request the partial of this step's
+      if (PREV) {
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");          // the last dQ MFMA's result before the stores read it
+        B1_SB();
+        if (prev_last) {
+          const int2 qd = qtd_s[prev_qt];
+          const int r = (wave >> 1) * 32 + l31;
+          if (r < qd.y) {
+            u16* p = a.dq + (int64_t)b * a.dq_bstride + (int64_t)(qd.x + r) * a.dq_ld + h * DH + (wave & 1) * 32 + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+              uint2 pk;
+              pk.x = pack2bf_pk(dq[4 * g] * a.scale, dq[4 * g + 1] * a.scale);
+              pk.y = pack2bf_pk(dq[4 * g + 2] * a.scale, dq[4 * g + 3] * a.scale);
+              *reinterpret_cast<uint2*>(p + 8 * g) = pk;
+            }
+          }
+          // (a wavefront whose rows are past the tile issues no store: the counted waits assume four - pad with stores to its own
+          //  dq_acc slot, which nobody reads)
+          else {
+#pragma unroll
+            for (int g = 0; g < 4; g++) *reinterpret_cast<f32x4*>(acc_g + (int64_t)prev_qt * (TQ * DH) + g * 256) = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; g++)
+            *reinterpret_cast<f32x4*>(acc_g + (int64_t)prev_qt * (TQ * DH) + g * 256) = f32x4{dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]};
+        }
+        n_young += 4;
+      }
+      if (CUR) {
+        const uint32_t ent = list_s[it];
+        const int qt = (int)(__builtin_amdgcn_readfirstlane(ent) & 0x7fffffffu);
+        const bool first = __builtin_amdgcn_readfirstlane((int)first_s[qt]) == kbi, last = __builtin_amdgcn_readfirstlane((int)last_s[qt]) == kbi;
+        if (first) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) dq[r] = 0.f;
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(acc_g + (int64_t)qt * (TQ * DH) + g * 256);
+#pragma unroll
+            for (int e = 0; e < 4; e++) dq[4 * g + e] = v[e];
+          }
+          n_young += 4;
+        }
+        prev_qt = qt; prev_first = first; prev_last = last;
+      }
+      B1_SB();
+    };
+
+    // the first step's first block: row constants, mask operand, row fragments (the loop reads them an iteration ahead)
+    if (n_ent > 0 && !wave_dead) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 t0 = LDS_RF4(lds_b + 16384u + o_rc + 32u * g), t1 = LDS_RF4(lds_b + 16384u + 256u + o_rc + 32u * g);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { cl[4 * g + e] = t0[e]; cd[4 * g + e] = t1[e]; }
+      }
+      qbf = LDS_R8(lds_b + 16896u + o_qb);
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) { rfQ[0][ks] = LDS_R8(lds_b + o_rf[ks]); rfO[0][ks] = LDS_R8(lds_b + 8192u + o_rf[ks]); }
+    }
+    if (n_ent > 0) {
+      if (!wave_dead) {
+        iter.template operator()<false, true, true>(0);
+        for (int it = 1; it < n_ent; it++) iter.template operator()<true, true, true>(it);
+        iter.template operator()<true, false, true>(n_ent);
+      } else {
+        iter.template operator()<false, true, false>(0);
+        for (int it = 1; it < n_ent; it++) iter.template operator()<true, true, false>(it);
+        iter.template operator()<true, false, false>(n_ent);
+      }
+    }
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");          // the last dK / dV MFMAs before the epilogue reads the accumulators
+    B1_SB();
+
+    // ---- the block's dK = ln 2 * dK^T, dV = dV^T + dvmean
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      if (keyrow[kb] < 0) continue;
+      u16* dkp = a.dk + (int64_t)b * a.dkv_bstride + (int64_t)keyrow[kb] * a.dkv_ld + h * DH;
+      u16* dvp = a.dv + (int64_t)b * a.dkv_bstride + (int64_t)keyrow[kb] * a.dkv_ld + h * DH;
+#pragma unroll
+      for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int d = n * 32 + 8 * g + 4 * lh;
+          uint2 pk;
+          pk.x = pack2bf(dk[kb][n][4 * g] * dk_scale, dk[kb][n][4 * g + 1] * dk_scale);
+          pk.y = pack2bf(dk[kb][n][4 * g + 2] * dk_scale, dk[kb][n][4 * g + 3] * dk_scale);
+          *reinterpret_cast<uint2*>(dkp + d) = pk;
+          const f32x4 dvm = *reinterpret_cast<const f32x4*>(dvm_s + d);
+          pk.x = pack2bf(dv[kb][n][4 * g] + dvm[0], dv[kb][n][4 * g + 1] + dvm[1]);
+          pk.y = pack2bf(dv[kb][n][4 * g + 2] + dvm[2], dv[kb][n][4 * g + 3] + dvm[3]);
+          *reinterpret_cast<uint2*>(dvp + d) = pk;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // every wavefront is done with the K image, the list and the stages
+  }
+  for (int kbi = 0; kbi < a.n_kblocks; kbi++) {          // key blocks without a valid key in this sample: dK = 0, dV = dvmean
+    if (live_s[kbi]) continue;
+    const int4 kd = reinterpret_cast<const int4*>(a.kb_desc)[kbi];
+    for (int i = tid; i < kd.y * 8; i += 256) {
+      const int key = kd.x + (i >> 3), c = i & 7;
+      *reinterpret_cast<uint4*>(a.dk + (int64_t)b * a.dkv_bstride + (int64_t)key * a.dkv_ld + h * DH + c * 8) = make_uint4(0, 0, 0, 0);
+      uint4 pv;
+      pv.x = pack2bf(dvm_s[c * 8], dvm_s[c * 8 + 1]); pv.y = pack2bf(dvm_s[c * 8 + 2], dvm_s[c * 8 + 3]);
+      pv.z = pack2bf(dvm_s[c * 8 + 4], dvm_s[c * 8 + 5]); pv.w = pack2bf(dvm_s[c * 8 + 6], dvm_s[c * 8 + 7]);
+      *reinterpret_cast<uint4*>(a.dv + (int64_t)b * a.dkv_bstride + (int64_t)key * a.dkv_ld + h * DH + c * 8) = pv;
+    }
+  }
+}
+__global__ __launch_bounds__(256, 1) void attn_bwd1p_kernel(mca_attn_bwd1_args a, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) u16 lds_dyn[];
+  attn_bwd1p_body(a, dbg, lds_dyn);
+}
+#define B1P_LDS_BYTES ((B1P_NST * B1_STAGE_U16 + TKB * DH + 2 * TKB * TQ) * 2 + B1_MAX_LIST * 4 + B1_MAX_QT * 8 + 2 * B1_MAX_QT + B1_MAX_KB + DH * 4)
+
 #define B1_LDS_BYTES ((B1_NST * B1_STAGE_U16 + TKB * DH + 2 * TKB * TQ) * 2 + B1_MAX_LIST * 4 + 2 * B1_MAX_QT + B1_MAX_KB + DH * 4)
 
 extern "C" int mca_attn_bwd_onepass(const mca_attn_bwd1_args* a, mca_stream_t stream) {
@@ -367,9 +818,13 @@ extern "C" int mca_attn_bwd_onepass(const mca_attn_bwd1_args* a, mca_stream_t st
   static bool attr_set[64] = {false};
   bool* done = mca_dev_flag(attr_set);
   if (!*done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS_BYTES) != hipSuccess) return MCA_E_LAUNCH;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd1p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B1P_LDS_BYTES) != hipSuccess)
+      return MCA_E_LAUNCH;
     *done = true;
   }
-  hipLaunchKernelGGL(attn_bwd1_kernel, dim3(a->batch * a->heads), dim3(256), B1_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
+  // knob 9 bit 64: the plain (compiler-scheduled) form of the same algorithm instead of the pipelined one (A/B and cross-check)
+  if (mca_knobs[9] & 64) hipLaunchKernelGGL(attn_bwd1_kernel, dim3(a->batch * a->heads), dim3(256), B1_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
+  else hipLaunchKernelGGL(attn_bwd1p_kernel, dim3(a->batch * a->heads), dim3(256), B1P_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
   return launch_status();
 }
