@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd1_kernel(mca_attn_bwd1_args a,
   const u16* obase = a.d_o + (int64_t)b * a.o_bstride + h * DH;
   const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
   const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
-  const float* rowc_g = a.rowc + bh * (int64_t)a.n_qtiles * 128;
+  const float* rowc_g = a.rowc + bh * (int64_t)(a.n_qtiles + 1) * 128;          // (+ the null tile)
   float* acc_g = a.dq_acc + bh * (int64_t)a.n_qtiles * (TQ * DH);
   const uint8_t* kinfo_g = a.keyinfo + (int64_t)b * a.nk_pad;
   const u16* khot_g = a.khot + (int64_t)b * a.nk_pad * 16;
@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd1_kernel(mca_attn_bwd1_args a,
 // The production form of the kernel above: the same work decomposition, as a SOFTWARE PIPELINE whose issue order is generated
 // (tools/gen_bwd1_schedule.py -> attention_bwd1_sched.inc: one slot = one MFMA and the single-issue work in its shadow).
 //   * register classes by hand (every MFMA is inline asm): dK^T / dV^T accumulators, the K / V operand fragments and the Q / dO
-//     row fragments live in the accumulator half for the whole key block; scores, packed P / dS, row constants, transposed
-//     fragments and dQ in the vector half.  (Left to hipcc, the plain form moves 730 registers between the halves per step.)
+//     row fragments and the two dQ accumulators live in the accumulator half; scores (the row constants are read straight into
+//     them), packed P / dS, the V fragments and the transposed fragments in the vector half.  (Left to hipcc, the plain form moves 730 registers between the halves per step.)
 //   * the loop is rotated: iteration X computes the scores of blocks 0..3 of step X, and finishes step X-1 (block 3's vector work
 //     fills the shadow of A0; the dV / dK products of its blocks 2 and 3; its dQ product behind the iteration's ONE barrier); Q / dO / row-constant /
 //     mask-operand tiles arrive by LDS-DMA two steps ahead (three stages), the dQ partial of the next tile is requested a
@@ -365,21 +365,34 @@ __global__ __launch_bounds__(256, 1) void attn_bwd1_kernel(mca_attn_bwd1_args a,
 //     first vector reader of its result; the two places outside the schedule (dQ store, block epilogue) pad by hand.
 // =====================================================================================================
 #define B1P_NST 3
+#ifndef B1_ABL          // timing-only ablation builds (tools/ablate_bwd1.py): 1 no vector work, 2 no dQ product, 4 no transposed reads,
+#define B1_ABL 0        // 8 no row reads, 16 no dS^T stores, 32 no score MFMAs, 64 no dV / dK MFMAs.  0 in the product.
+#endif
 #define B1_SB() __builtin_amdgcn_sched_barrier(0)
 // (PAD: "s_nop 1" ahead of the MFMA inside the statement - two wait states between a compiler-placed register copy or select
 //  and the MFMA that reads it.  The first and the drain iteration of a key block are padded (hipcc copies the zeroed accumulators
 //  and the carried state into place just ahead of their first reader there: tools/audit_bwd1_isa.py found them 0-1 states
 //  ahead); the steady-state loop is not, and the audit checks every build of it.)
-#define MF_INIT_VV(D, A, B, C) do { if (STEADY) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(D) : "v"(A), "v"(B), "v"(C)); \
-                                    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(D) : "v"(A), "v"(B), "v"(C)); } while (0)
-#define MF_INIT_AA(D, A, B, C) do { if (STEADY) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(D) : "a"(A), "a"(B), "v"(C)); \
-                                    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(D) : "a"(A), "a"(B), "v"(C)); } while (0)
+#define MF_ACC_AV(D, A, B) do { if (STEADY) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "a"(A), "v"(B)); \
+                                else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "a"(A), "v"(B)); } while (0)
 #define MF_ACC_AA(D, A, B) do { if (STEADY) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "a"(A), "a"(B)); \
                                 else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "a"(A), "a"(B)); } while (0)
 #define MF_ACCA_VV(D, A, B) do { if (STEADY) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(D) : "v"(A), "v"(B)); \
                                  else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(D) : "v"(A), "v"(B)); } while (0)
 #define MF_ACC_VV(D, A, B) do { if (STEADY) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "v"(A), "v"(B)); \
                                 else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "v"(A), "v"(B)); } while (0)
+// LDS-DMA by hand (M0 written in the same statement): hipcc then knows of no LDS write in flight - with the builtin it drained
+// vmcnt(0) in front of the next LDS read, i.e. every iteration waited for ALL of its memory traffic.  BASE: wave-uniform 64-bit
+// pointer, OFF: this lane's 32-bit byte offset, LDS_DST: wave-uniform LDS byte address (lane l lands at + 16 l / + 4 l).  The kernel's
+// own counted s_waitcnt vmcnt + s_barrier order the data.
+#define B1_DMA16(BASE, OFF, LDS_DST)                                                                                                       \
+  do { unsigned keep_;                                                                                                                     \
+       asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"    \
+                    : "=&s"(keep_) : "v"(OFF), "s"(BASE), "s"(LDS_DST) : "memory"); } while (0)
+#define B1_DMA4(BASE, OFF, LDS_DST)                                                                                                        \
+  do { unsigned keep_;                                                                                                                     \
+       asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"      \
+                    : "=&s"(keep_) : "v"(OFF), "s"(BASE), "s"(LDS_DST) : "memory"); } while (0)
 // LDS accesses by 32-bit byte address = per-lane base register + compile-time immediate (pointer arithmetic on u16* made hipcc
 // keep one address register per constant offset and spill them)
 #define LDS_P(T, ADDR) reinterpret_cast<__attribute__((address_space(3))) T*>(static_cast<uintptr_t>(ADDR))
@@ -411,7 +424,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
   const u16* obase = a.d_o + (int64_t)b * a.o_bstride + h * DH;
   const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
   const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
-  const float* rowc_g = a.rowc + bh * (int64_t)a.n_qtiles * 128;
+  const float* rowc_g = a.rowc + bh * (int64_t)(a.n_qtiles + 1) * 128;          // (+ the null tile)
   float* acc_g = a.dq_acc + bh * (int64_t)a.n_qtiles * (TQ * DH) + wave * 1024 + lane * 4;
   const uint8_t* kinfo_g = a.keyinfo + (int64_t)b * a.nk_pad;
   const u16* khot_g = a.khot + (int64_t)b * a.nk_pad * 16;
@@ -425,6 +438,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
   }
   if (tid < DH) dvm_s[tid] = a.dvmean[(int64_t)b * a.heads * DH + h * DH + tid];
   for (int qt = tid; qt < a.n_qtiles; qt += 256) qtd_s[qt] = reinterpret_cast<const int2*>(a.qt_desc)[qt];
+  if (tid == 0) { qtd_s[a.n_qtiles] = make_int2(0, 1); first_s[a.n_qtiles] = 255; last_s[a.n_qtiles] = 255; }          // the null tile
   __syncthreads();
   for (int qt = tid; qt < a.n_qtiles; qt += 256) {
     int first = 255, last = 255;
@@ -440,23 +454,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       *reinterpret_cast<uint4*>(a.dq + (int64_t)b * a.dq_bstride + (int64_t)(qd.x + (i >> 3)) * a.dq_ld + h * DH + (i & 7) * 8) = make_uint4(0, 0, 0, 0);
   }
 
-  // ---- loop-invariant LDS BYTE offsets of this lane inside a stage / an image
   const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const u16*)lds;
-  unsigned o_rf[4];          // row fragment (row l31, k-step ks) of a 32-row block of a [rows][64] image
-#pragma unroll
-  for (int ks = 0; ks < 4; ks++) o_rf[ks] = 2u * (unsigned)b1_off(l31, 2 * ks + lh);
-  unsigned o_tr[2][2], o_dqa[2], o_dqb[2];          // transposed reads: [t][n] of a Q / dO tile (rows 8 t + 4 lh + tq); dQ operands (rows 8 lh + 4 t + tq)
-#pragma unroll
-  for (int t = 0; t < 2; t++) {
-#pragma unroll
-    for (int n = 0; n < 2; n++) o_tr[t][n] = 2u * (unsigned)(b1_off(8 * t + 4 * lh + tq, n * 4 + 2 * tg + (tp >> 1)) + 4 * (tp & 1));
-    o_dqa[t] = 2u * (unsigned)(b1_off(8 * lh + 4 * t + tq, (wave & 1) * 4 + 2 * tg + (tp >> 1)) + 4 * (tp & 1));
-    o_dqb[t] = 2u * (unsigned)(b1_off(8 * lh + 4 * t + tq, (wave >> 1) * 4 + 2 * tg + (tp >> 1)) + 4 * (tp & 1));
-  }
-  unsigned o_ds[2];          // dS^T store: (row * 128 + 8 lh) ^ (swizzle << 4); the 16-byte chunk c of the row is at o_ds ^ (c << 4)
-#pragma unroll
-  for (int kb = 0; kb < 2; kb++) { const int r = wave * 64 + kb * 32 + l31; o_ds[kb] = (unsigned)((r * 128 + 8 * lh) ^ (b1_swz(r) << 4)); }
-  const unsigned o_rc = 16u * (unsigned)lh, o_qb = (unsigned)(l31 * 32 + 16 * lh);
   const unsigned STAGE_B = 2u * B1_STAGE_U16, KIMG_B = lds_b + 2u * B1P_NST * B1_STAGE_U16, DSIMG_B = KIMG_B + 2u * TKB * DH;
   const float dk_scale = 0.6931471805599453f;
 
@@ -466,6 +464,11 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     const int key_start = __builtin_amdgcn_readfirstlane(kd.x), n_keys = __builtin_amdgcn_readfirstlane(kd.y);
     const int e_begin = __builtin_amdgcn_readfirstlane(kd.z), n_ent = __builtin_amdgcn_readfirstlane(kd.w);
     for (int i = tid; i < n_ent; i += 256) list_s[i] = a.kb_qt[e_begin + i];
+    // the NULL step(s): tile n_qtiles = {row 0, one row}, row constants -inf | 0.  One ends every sweep (the loop is rotated: it
+    // finishes the last real step); a second one makes the iteration count even (the loop is unrolled by two: no remainder copy
+    // of the body, at whose seams hipcc moved accumulators right ahead of the MFMAs that read them)
+    if (tid < 2) list_s[n_ent + tid] = (uint32_t)a.n_qtiles;
+    const int n_it = (n_ent + 2) & ~1;
 
     bf16x8 kf[2][4], vf[2][4], khf[2];
     bool ok[2];
@@ -498,7 +501,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     for (int p = 0; p < 8; p++) {          // K image: wavefront w moves the rows of its own 64 slots
       const int r = wave * 64 + p * 8 + (lane >> 3);
       const int key = key_start + (r < n_keys ? r : n_keys - 1);
-      B1_DMA(kbase + (int64_t)key * a.kv_ld + (((lane & 7) ^ b1_swz(r)) << 3), kimg + (wave * 8 + p) * 512, 16);
+      B1_DMA16(kbase, (unsigned)key * (unsigned)(a.kv_ld * 2) + (unsigned)(((lane & 7) ^ b1_swz(r)) << 4), KIMG_B + (unsigned)(wave * 8 + p) * 1024u);
     }
     f32x16 dk[2][2], dv[2][2];
 #pragma unroll
@@ -517,10 +520,10 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     // ---- staging of one step: five 1-KiB / 256-byte pieces per wavefront (Q and dO rows 16 w .. 16 w + 15, and one of: -lse, -delta,
     // the two halves of the mask operand): every wavefront's vmcnt sees the same count
     auto issue = [&](uint32_t ent, int st) {
-      const int qt = (int)(ent & 0x7fffffffu);
+      const int qt = __builtin_amdgcn_readfirstlane((int)(ent & 0x7fffffffu));          // (provably wave-uniform: an "s" operand below)
       const int2 qd = qtd_s[qt];
       const int row0 = __builtin_amdgcn_readfirstlane(qd.x), nrows = __builtin_amdgcn_readfirstlane(qd.y);
-      u16* sb_ = stage_s + st * B1_STAGE_U16;
+      const unsigned sb_ = lds_b + (unsigned)st * STAGE_B;
       // wave-uniform 64-bit bases + 32-bit per-lane byte offsets, all derived from the lane id HERE (hoisted out of the loop they
       // were ten more registers to spill)
       int ln = lane;
@@ -531,120 +534,159 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
         const int p = wave * 2 + u, r = p * 8 + r8;
         const int row = row0 + (r < nrows ? r : nrows - 1);
         const unsigned sw = (unsigned)(((ln & 7) ^ b1_swz(r)) << 4);
-        B1_DMA(reinterpret_cast<const char*>(qbase) + (size_t)((unsigned)row * (unsigned)(a.q_ld * 2) + sw), sb_ + p * 512, 16);
-        B1_DMA(reinterpret_cast<const char*>(obase) + (size_t)((unsigned)row * (unsigned)(a.o_ld * 2) + sw), sb_ + TQ * DH + p * 512, 16);
+        B1_DMA16(qbase, (unsigned)row * (unsigned)(a.q_ld * 2) + sw, sb_ + (unsigned)p * 1024u);
+        B1_DMA16(obase, (unsigned)row * (unsigned)(a.o_ld * 2) + sw, sb_ + 8192u + (unsigned)p * 1024u);
       }
-      if (wave < 2) B1_DMA(reinterpret_cast<const char*>(rowc_g + (int64_t)qt * 128 + wave * 64) + (size_t)((unsigned)ln * 4u), sb_ + 2 * TQ * DH + wave * 128, 4);
-      else {
+      if (wave < 2) {
+        const float* rb = rowc_g + (int64_t)qt * 128 + wave * 64;
+        B1_DMA4(rb, (unsigned)ln * 4u, sb_ + 16384u + (unsigned)wave * 256u);
+      } else {
         const int r = (wave - 2) * 32 + (ln >> 1);
         const int row = row0 + (r < nrows ? r : nrows - 1);
-        B1_DMA(reinterpret_cast<const char*>(a.qblk) + (size_t)((unsigned)row * 32u + (unsigned)(ln & 1) * 16u), sb_ + 2 * TQ * DH + 256 + (wave - 2) * 512, 16);
+        B1_DMA16(a.qblk, (unsigned)row * 32u + (unsigned)(ln & 1) * 16u, sb_ + 16896u + (unsigned)(wave - 2) * 1024u);
       }
     };
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // list_s visible; every wavefront is past the previous block
-    if (n_ent > 0) issue(list_s[0], 0);
-    if (n_ent > 1) issue(list_s[1], 1);
-    if (n_ent > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();          // K image and stage 0 landed
+    issue(list_s[0], 0);          // (n_it >= 2: a key block has at least one real step and the null step)
+    issue(list_s[1], 1);
 
     // ---- pipeline state
-    f32x16 S[2], dP[2], cl, cd, dq;
+    // acc2: the dQ accumulators of two steps (accumulator half).  acc2[s & 1] receives the OLD partial of step s's tile two
+    // iterations before step s's dQ product (iteration s + 1) accumulates onto it in place
+    f32x16 S[2], dP[2], acc2[2];
     u32x4v pb[2][2], sb[2][2];
-    bf16x8 rfQ[2][4], rfO[2][4], qbf, trO[2][2], trQ[2][2], da[2], db[2];
+    bf16x8 rfQ[4], rfO[4], qbf, trO[2][2], trQ[2][2], da[2], db[2];
+    // (deliberately uninitialised: every element is written before its first real use, and a zero held 'just in case' stays live -
+    //  48 registers of zeros through the loop in an earlier build)
+    // ---- LDS BYTE offsets of this lane inside a stage / an image: derived HERE from an opaque copy of the lane id (held across the
+    // key-block loop they were sixteen more live registers through the pipeline)
+    int ln_ = lane;
+    asm volatile("" : "+v"(ln_));
+    const int l31_ = ln_ & 31, lh_ = ln_ >> 5, tq_ = (ln_ & 15) >> 2, tp_ = ln_ & 3, tg_ = (ln_ >> 4) & 1;
+    unsigned o_rf[4];          // row fragment (row l31_, k-step ks) of a 32-row block of a [rows][64] image
+  #pragma unroll
+    for (int ks = 0; ks < 4; ks++) o_rf[ks] = 2u * (unsigned)b1_off(l31_, 2 * ks + lh_);
+    unsigned o_tr[2][2], o_dqa[2], o_dqb[2];          // transposed reads: [t][n] of a Q / dO tile (rows 8 t + 4 lh_ + tq_); dQ operands (rows 8 lh_ + 4 t + tq_)
+  #pragma unroll
+    for (int t = 0; t < 2; t++) {
+  #pragma unroll
+      for (int n = 0; n < 2; n++) o_tr[t][n] = 2u * (unsigned)(b1_off(8 * t + 4 * lh_ + tq_, n * 4 + 2 * tg_ + (tp_ >> 1)) + 4 * (tp_ & 1));
+      o_dqa[t] = 2u * (unsigned)(b1_off(8 * lh_ + 4 * t + tq_, (wave & 1) * 4 + 2 * tg_ + (tp_ >> 1)) + 4 * (tp_ & 1));
+      o_dqb[t] = 2u * (unsigned)(b1_off(8 * lh_ + 4 * t + tq_, (wave >> 1) * 4 + 2 * tg_ + (tp_ >> 1)) + 4 * (tp_ & 1));
+    }
+    unsigned o_ds[2];          // dS^T store: (row * 128 + 8 lh_) ^ (swizzle << 4); the 16-byte chunk c of the row is at o_ds ^ (c << 4)
+  #pragma unroll
+    for (int kb = 0; kb < 2; kb++) { const int r = wave * 64 + kb * 32 + l31_; o_ds[kb] = (unsigned)((r * 128 + 8 * lh_) ^ (b1_swz(r) << 4)); }
+    const unsigned o_rc = 16u * (unsigned)lh_, o_qb = (unsigned)(l31_ * 32 + 16 * lh_);
+    unsigned a_rf[4], a_tr[2][2], a_da[2], a_db[2], a_rc = lds_b + 16384u + o_rc, a_qb = lds_b + 16896u + o_qb, ods[2] = {o_ds[0], o_ds[1]};
 #pragma unroll
-    for (int r = 0; r < 16; r++) { S[0][r] = 0.f; S[1][r] = 0.f; dP[0][r] = 0.f; dP[1][r] = 0.f; dq[r] = 0.f; }
+    for (int ks = 0; ks < 4; ks++) a_rf[ks] = lds_b + o_rf[ks];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int w = 0; w < 4; w++) { pb[i][j][w] = 0u; sb[i][j][w] = 0u; }
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) { trO[i][j][e] = 0; trQ[i][j][e] = 0; }
-#pragma unroll
-    for (int e = 0; e < 8; e++) { da[0][e] = 0; da[1][e] = 0; db[0][e] = 0; db[1][e] = 0; }
-    int n_young = 0;                 // memory operations issued behind the last DMA (the barrier's vmcnt lets exactly these stay in flight)
-    int prev_qt = 0;
+    for (int t = 0; t < 2; t++) {
+      a_tr[t][0] = lds_b + o_tr[t][0]; a_tr[t][1] = lds_b + o_tr[t][1];
+      a_da[t] = KIMG_B + o_dqa[t]; a_db[t] = DSIMG_B + (2u * TKB * TQ) + o_dqb[t];          // (iteration 0 reads nothing from it)
+    }
+    // counted waits: vm_n = vector-memory operations issued so far in this block; a wait "for everything up to mark m" lets the
+    // vm_n - m younger operations stay in flight (rounded down to an immediate the switch below knows: stricter is always safe)
+    int vm_n = 0, mark_dma = 0, mark_ld[2] = {0, 0};
+    int prev_qt = 0, cur_qt = 0;
     bool prev_first = false, prev_last = false;
-
-    // stage / image pointers of iteration `it`: cur = step it, nxt = step it + 1; ds_cur = step it's dS^T image, ds_prev = step it - 1's
-    auto iter = [&]<bool PREV, bool CUR, bool LIVE>(const int it) __attribute__((always_inline)) {
-      constexpr bool STEADY = PREV && CUR;          // (the loop body proper: unpadded MFMAs, audited)
-      const bool has_next2 = CUR && (it + 2 < n_ent);
-      // byte addresses: stage of this step / of the next one; dS^T image of this step / of the previous one
+#define VM_WAIT(YOUNGER) do { const int y_ = (YOUNGER);                                                                   \
+                              if (y_ >= 26) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");                               \
+                              else if (y_ >= 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");                          \
+                              else if (y_ >= 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");                          \
+                              else if (y_ >= 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");                          \
+                              else if (y_ >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                            \
+                              else if (y_ >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                            \
+                              else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+    // the old dQ partial of step s's tile -> acc2[s & 1].  Inline asm, always four loads: hipcc then keeps no count of its own for
+    // them (its count cannot see the LDS-DMA: it drained vmcnt(0) ahead of the first dQ product, every iteration) and the kernel's
+    // counts do not depend on the tile.  A first visit has no partial: it re-reads the slot the previous step stored (cached; the
+    // value is never used - the first product of a first visit starts from the constant 0, DQM).  The loaded registers are
+    // touched by nothing but the dQ MFMAs behind the counted wait (tools/audit_bwd1_isa.py checks that).
+    auto acc_load = [&](int s_idx, f32x16& dst, int& mark) {
+      const int qt = (int)(__builtin_amdgcn_readfirstlane(list_s[s_idx]) & 0x7fffffffu);
+      const bool first = __builtin_amdgcn_readfirstlane((int)first_s[qt]) == kbi || (dbg & 128);
+      const float* src = acc_g + (int64_t)(first ? prev_qt : qt) * (TQ * DH);
+      f32x4 t0, t1, t2, t3;
+      asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"
+                   "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"
+                   : "=a"(t0), "=a"(t1), "=a"(t2), "=a"(t3) : "v"(src) : "memory");
+#pragma unroll
+      for (int e = 0; e < 4; e++) { dst[e] = t0[e]; dst[4 + e] = t1[e]; dst[8 + e] = t2[e]; dst[12 + e] = t3[e]; }
+      vm_n += 4;
+      mark = vm_n;
+    };
+    // ONE loop body (every iteration, the first and the last included, runs it whole: the first on a neutral "previous step" -
+    // scores of -inf, packed operands and fragments of zero: P = dS = 0 -, the last on the block's NULL step, whose row constants are
+    // -inf.  Six specialised copies of a 500-register body made hipcc spill accumulators right behind the MFMAs that wrote them.)
+    // LIVE: this wavefront has a valid key; PAR = it & 1.
+    auto iter = [&]<bool LIVE, int PAR>(const int it) __attribute__((always_inline)) {
+      constexpr bool PREV = true, CUR = true;
+      constexpr bool STEADY = LIVE;          // (a wavefront without a valid key runs its few MFMAs padded)
+      const bool has_next2 = it + 2 < n_it;
+      // byte addresses of this lane (carried across the iterations: advanced by wave-uniform deltas at the end of each, so that no
+      // loop-invariant offset registers stay live): a_rf / a_tr / a_rc / a_qb point into the stage of step `it`, a_db into the dS^T
+      // image of step it - 1, ds_cur is the image of step `it`
       const unsigned st_c = lds_b + (unsigned)(it % B1P_NST) * STAGE_B, st_n = lds_b + (unsigned)((it + 1) % B1P_NST) * STAGE_B;
       const unsigned ds_cur = DSIMG_B + (unsigned)(it & 1) * (2u * TKB * TQ), ds_prev = DSIMG_B + (unsigned)((it & 1) ^ 1) * (2u * TKB * TQ);
-      // per-lane bases (Q tile at +0, dO at +8192, row constants at +16384, mask operand at +16896 of a stage)
-      unsigned a_rf[4], a_tr[2][2], a_da[2], a_db[2];
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++) a_rf[ks] = st_c + o_rf[ks];
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        a_tr[t][0] = st_c + o_tr[t][0]; a_tr[t][1] = st_c + o_tr[t][1];
-        a_da[t] = KIMG_B + o_dqa[t]; a_db[t] = ds_prev + o_dqb[t];
-      }
-      unsigned a_rc = st_c + 16384u + o_rc, a_qb = st_c + 16896u + o_qb;
       // (opaque to the optimiser: loop strength reduction made every (base + immediate) pair an induction variable of its own -
       //  45 registers, spilled - instead of one base register per fragment and an immediate in the instruction)
       asm volatile("" : "+v"(a_rf[0]), "+v"(a_rf[1]), "+v"(a_rf[2]), "+v"(a_rf[3]), "+v"(a_rc), "+v"(a_qb));
       asm volatile("" : "+v"(a_tr[0][0]), "+v"(a_tr[0][1]), "+v"(a_tr[1][0]), "+v"(a_tr[1][1]), "+v"(a_da[0]), "+v"(a_da[1]), "+v"(a_db[0]), "+v"(a_db[1]));
       unsigned n_off = st_n - st_c;          // (wave-uniform: the next stage's same addresses)
       asm volatile("" : "+s"(n_off));
-      unsigned ods[2] = {o_ds[0], o_ds[1]};          // (opaque: the sixteen xor-ed variants are recomputed, not hoisted and spilled)
-      asm volatile("" : "+v"(ods[0]), "+v"(ods[1]));
+      asm volatile("" : "+v"(ods[0]), "+v"(ods[1]));          // (opaque: the sixteen xor-ed variants are recomputed, not hoisted and spilled)
       const uint32_t ent2 = has_next2 ? list_s[it + 2] : 0u;
-      bool issued = false;
       asm volatile("s_nop 1" ::: "memory");          // register copies of the loop's back edge before the first MFMA reads them
       B1_SB();
 
-#define A_M(J) MF_INIT_VV(S[(J) & 1], qbf, khf[(J) & 1], cl)
-#define A_S(J, KS) MF_ACC_AA(S[(J) & 1], rfQ[(J) >> 1][KS], kf[(J) & 1][KS])
-#define A_P(J, KS) do { if ((KS) == 0) MF_INIT_AA(dP[(J) & 1], rfO[(J) >> 1][0], vf[(J) & 1][0], cd); else MF_ACC_AA(dP[(J) & 1], rfO[(J) >> 1][KS], vf[(J) & 1][KS]); } while (0)
-#define VE_(SET, R) do { const float p_ = __builtin_amdgcn_exp2f(S[SET][R]); S[SET][R] = p_; dP[SET][R] *= p_; } while (0)
-#define VC_(SET, I) do { pb[SET][(I) >> 2][(I) & 3] = pack2bf_pk(S[SET][2 * (I)], S[SET][2 * (I) + 1]); \
+#define A_M(J) if (!(B1_ABL & 32)) MF_ACC_VV(S[(J) & 1], qbf, khf[(J) & 1])
+#define A_S(J, KS) if (!(B1_ABL & 32)) MF_ACC_AA(S[(J) & 1], rfQ[KS], kf[(J) & 1][KS])
+#define A_P(J, KS) if (!(B1_ABL & 32)) MF_ACC_AV(dP[(J) & 1], rfO[KS], vf[(J) & 1][KS])
+#define VE_(SET, R) do { if (B1_ABL & 1) break; const float p_ = __builtin_amdgcn_exp2f(S[SET][R]); S[SET][R] = p_; dP[SET][R] *= p_; } while (0)
+#define VC_(SET, I) do { if (B1_ABL & 1) break; pb[SET][(I) >> 2][(I) & 3] = pack2bf_pk(S[SET][2 * (I)], S[SET][2 * (I) + 1]); \
                          sb[SET][(I) >> 2][(I) & 3] = pack2bf_pk(dP[SET][2 * (I)], dP[SET][2 * (I) + 1]); \
                          asm volatile("" :: "v"(pb[SET][(I) >> 2][(I) & 3]), "v"(sb[SET][(I) >> 2][(I) & 3])); } while (0)
 #define VE(J, R) VE_((J) & 1, R)
 #define VC(J, I) VC_((J) & 1, I)
 #define VEP(R) VE_(1, R)
 #define VCP(I) VC_(1, I)
-#define C_V(J, SP, N) MF_ACCA_VV(dv[(J) & 1][N], trO[SP][N], pb[(J) & 1][SP])
-#define C_K(J, SP, N) MF_ACCA_VV(dk[(J) & 1][N], trQ[SP][N], sb[(J) & 1][SP])
-#define CP_V(J, SP, N) MF_ACCA_VV(dv[(J) & 1][N], trO[SP][N], pb[(J) & 1][SP])
-#define CP_K(J, SP, N) MF_ACCA_VV(dk[(J) & 1][N], trQ[SP][N], sb[(J) & 1][SP])
-#define DSW_(IMG, QB, KB, SET, SP, T) *LDS_P(u32x2v, (IMG) + (ods[KB] ^ (unsigned)(((QB) * 4 + 2 * (SP) + (T)) << 4))) = u32x2v{sb[SET][SP][2 * (T)], sb[SET][SP][2 * (T) + 1]}
+#define C_V(J, SP, N) if (!(B1_ABL & 64)) MF_ACCA_VV(dv[(J) & 1][N], trO[SP][N], pb[(J) & 1][SP])
+#define C_K(J, SP, N) if (!(B1_ABL & 64)) MF_ACCA_VV(dk[(J) & 1][N], trQ[SP][N], sb[(J) & 1][SP])
+#define CP_V(J, SP, N) if (!(B1_ABL & 64)) MF_ACCA_VV(dv[(J) & 1][N], trO[SP][N], pb[(J) & 1][SP])
+#define CP_K(J, SP, N) if (!(B1_ABL & 64)) MF_ACCA_VV(dk[(J) & 1][N], trQ[SP][N], sb[(J) & 1][SP])
+#define DSW_(IMG, QB, KB, SET, SP, T) if (!(B1_ABL & 16)) *LDS_P(u32x2v, (IMG) + (ods[KB] ^ (unsigned)(((QB) * 4 + 2 * (SP) + (T)) << 4))) = u32x2v{sb[SET][SP][2 * (T)], sb[SET][SP][2 * (T) + 1]}
 #define DSW(J, SP, T) DSW_(ds_cur, (J) >> 1, (J) & 1, (J) & 1, SP, T)
 #define DSWP(SP, T) DSW_(ds_prev, 1, 1, 1, SP, T)
-#define RC4_(DST, ADDR, G) do { const f32x4 t_ = LDS_RF4(ADDR); DST[4 * (G)] = t_[0]; DST[4 * (G) + 1] = t_[1]; DST[4 * (G) + 2] = t_[2]; DST[4 * (G) + 3] = t_[3]; } while (0)
-#define RC_L(QB, G) RC4_(cl, a_rc + (unsigned)((QB) * 128 + 32 * (G)), G)
-#define RC_D(QB, G) RC4_(cd, a_rc + (unsigned)(256 + (QB) * 128 + 32 * (G)), G)
-#define NRC_L(G) RC4_(cl, a_rc + n_off + (unsigned)(32 * (G)), G)
-#define NRC_D(G) RC4_(cd, a_rc + n_off + (unsigned)(256 + 32 * (G)), G)
-#define RQB(QB) qbf = LDS_R8(a_qb + (unsigned)((QB) * 1024))
-#define NRQB() qbf = LDS_R8(a_qb + n_off)
-#define RF_Q(QB, KS) rfQ[QB][KS] = LDS_R8(a_rf[KS] + (unsigned)((QB) * 4096))
-#define RF_O(QB, KS) rfO[QB][KS] = LDS_R8(a_rf[KS] + (unsigned)(8192 + (QB) * 4096))
-#define NRF_Q(KS) rfQ[0][KS] = LDS_R8(a_rf[KS] + n_off)
-#define NRF_O(KS) rfO[0][KS] = LDS_R8(a_rf[KS] + n_off + 8192u)
+#define RC4_(DST, ADDR, G) do { if (B1_ABL & 8) break; const f32x4 t_ = LDS_RF4(ADDR); DST[4 * (G)] = t_[0]; DST[4 * (G) + 1] = t_[1]; DST[4 * (G) + 2] = t_[2]; DST[4 * (G) + 3] = t_[3]; } while (0)
+#define RC_L(J, G) RC4_(S[(J) & 1], a_rc + (unsigned)(((J) >> 1) * 128 + 32 * (G)), G)
+#define RC_D(J, G) RC4_(dP[(J) & 1], a_rc + (unsigned)(256 + ((J) >> 1) * 128 + 32 * (G)), G)
+#define NRC_L(G) RC4_(S[0], a_rc + n_off + (unsigned)(32 * (G)), G)
+#define NRC_D(G) RC4_(dP[0], a_rc + n_off + (unsigned)(256 + 32 * (G)), G)
+#define RQB(QB) if (!(B1_ABL & 8)) qbf = LDS_R8(a_qb + (unsigned)((QB) * 1024))
+#define NRQB() if (!(B1_ABL & 8)) qbf = LDS_R8(a_qb + n_off)
+#define RF_Q(QB, KS) if (!(B1_ABL & 8)) rfQ[KS] = LDS_R8(a_rf[KS] + (unsigned)((QB) * 4096))
+#define RF_O(QB, KS) if (!(B1_ABL & 8)) rfO[KS] = LDS_R8(a_rf[KS] + (unsigned)(8192 + (QB) * 4096))
+#define NRF_Q(KS) if (!(B1_ABL & 8)) rfQ[KS] = LDS_R8(a_rf[KS] + n_off)
+#define NRF_O(KS) if (!(B1_ABL & 8)) rfO[KS] = LDS_R8(a_rf[KS] + n_off + 8192u)
 #define TR2_(DST, A0, A1, IMM) do { const bf16x4 lo_ = LDS_TR((A0) + (unsigned)(IMM)), hi_ = LDS_TR((A1) + (unsigned)(IMM)); DST = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7); } while (0)
-#define TR_O(QB, SP, N) TR2_(trO[SP][N], a_tr[0][N], a_tr[1][N], 8192 + (QB) * 4096 + (SP) * 2048)
-#define TR_Q(QB, SP, N) TR2_(trQ[SP][N], a_tr[0][N], a_tr[1][N], (QB) * 4096 + (SP) * 2048)
-#define DQR(K) do { TR2_(da[(K) & 1], a_da[0], a_da[1], (K) * 2048); TR2_(db[(K) & 1], a_db[0], a_db[1], (K) * 2048); } while (0)
-#define DQM(K) MF_ACC_VV(dq, da[(K) & 1], db[(K) & 1])
-#define WAIT_ACC() do { if (issued) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
-      // the barrier: this wavefront's dS^T stores are done (lgkmcnt), its pieces of the next step's stage have landed (everything
-      // older than the n_young youngest memory operations)
-#define BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
-                       if (n_young == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                           \
-                       else if (n_young == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                      \
-                       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
+#define TR_O(QB, SP, N) if (!(B1_ABL & 4)) TR2_(trO[SP][N], a_tr[0][N], a_tr[1][N], 8192 + (QB) * 4096 + (SP) * 2048)
+#define TR_Q(QB, SP, N) if (!(B1_ABL & 4)) TR2_(trQ[SP][N], a_tr[0][N], a_tr[1][N], (QB) * 4096 + (SP) * 2048)
+#define DQR(K) do { if (B1_ABL & 2) break; TR2_(da[(K) & 1], a_da[0], a_da[1], (K) * 2048); TR2_(db[(K) & 1], a_db[0], a_db[1], (K) * 2048); } while (0)
+      // (the first product of a tile's first visit starts from the constant 0: no zeroing of the accumulator, whose only other
+      //  definition - the loads of the old partial - then goes straight to the accumulator half)
+#define DQM(K) do { if (B1_ABL & 2) break;                                                                                   \
+                    if ((K) == 0) { VM_WAIT(vm_n - mark_ld[PAR ^ 1]);          /* (a first visit too: its unused load must have landed) */ \
+                                    /* (padded: hipcc may assemble the loaded partial into the accumulator's registers just ahead) */ \
+                                    if (prev_first) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc2[PAR ^ 1]) : "v"(da[0]), "v"(db[0])); \
+                                    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc2[PAR ^ 1]) : "v"(da[0]), "v"(db[0])); } \
+                    else MF_ACCA_VV(acc2[PAR ^ 1], da[(K) & 1], db[(K) & 1]); } while (0)
+      // the barrier: this wavefront's dS^T stores are done (lgkmcnt) and its pieces of the NEXT step's stage have landed
+#define BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); VM_WAIT(vm_n - mark_dma);                  \
                        __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-#define ISSUE() do { if (has_next2) { issue(ent2, (it + 2) % B1P_NST); issued = true; n_young = 0; } } while (0)
+#define ISSUE() do { mark_dma = vm_n; if (has_next2 && !(dbg & 512)) { issue(ent2, (it + 2) % B1P_NST); vm_n += 5; mark_dma = vm_n; } } while (0)
 #include "attention_bwd1_sched.inc"
 #undef A_M
 #undef A_S
@@ -678,18 +720,21 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
 #undef TR_Q
 #undef DQR
 #undef DQM
-#undef WAIT_ACC
 #undef BARRIER
 #undef ISSUE
-      // ---- tail: store the previous step's dQ block, request the partial of this step's
-      if (PREV) {
-        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");          // the last dQ MFMA's result before the stores read it
+      // ---- tail: the previous step's dQ block (accumulated onto its old partial) goes out as the new partial or, on the tile's
+      // last visit, as dq; the same accumulator then receives the old partial of the step after next
+      {
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");          // the last dQ MFMA's result before anything else reads it
         B1_SB();
-        if (prev_last) {
-          const int2 qd = qtd_s[prev_qt];
-          const int r = (wave >> 1) * 32 + l31;
-          if (r < qd.y) {
-            u16* p = a.dq + (int64_t)b * a.dq_bstride + (int64_t)(qd.x + r) * a.dq_ld + h * DH + (wave & 1) * 32 + 4 * lh;
+        f32x16& dq = acc2[PAR ^ 1];
+        if (it > 0 && it <= n_ent && !(dbg & 256)) {          // (no previous step in iteration 0; a null step's product goes nowhere)
+          if (prev_last) {
+            const int2 qd = qtd_s[prev_qt];
+            const int r = (wave >> 1) * 32 + l31;
+            // (a lane past the tile's rows stores to its own dq_acc slot, which nobody reads: every lane issues four stores)
+            u16* p = r < qd.y ? a.dq + (int64_t)b * a.dq_bstride + (int64_t)(qd.x + r) * a.dq_ld + h * DH + (wave & 1) * 32 + 4 * lh
+                              : reinterpret_cast<u16*>(acc_g + (int64_t)prev_qt * (TQ * DH));
 #pragma unroll
             for (int g = 0; g < 4; g++) {
               uint2 pk;
@@ -697,63 +742,74 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
               pk.y = pack2bf_pk(dq[4 * g + 2] * a.scale, dq[4 * g + 3] * a.scale);
               *reinterpret_cast<uint2*>(p + 8 * g) = pk;
             }
-          }
-          // (a wavefront whose rows are past the tile issues no store: the counted waits assume four - pad with stores to its own
-          //  dq_acc slot, which nobody reads)
-          else {
+          } else {
 #pragma unroll
-            for (int g = 0; g < 4; g++) *reinterpret_cast<f32x4*>(acc_g + (int64_t)prev_qt * (TQ * DH) + g * 256) = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < 4; g++)
+              *reinterpret_cast<f32x4*>(acc_g + (int64_t)prev_qt * (TQ * DH) + g * 256) = f32x4{dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]};
           }
-        } else {
-#pragma unroll
-          for (int g = 0; g < 4; g++)
-            *reinterpret_cast<f32x4*>(acc_g + (int64_t)prev_qt * (TQ * DH) + g * 256) = f32x4{dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]};
+          vm_n += 4;
         }
-        n_young += 4;
       }
-      if (CUR) {
-        const uint32_t ent = list_s[it];
-        const int qt = (int)(__builtin_amdgcn_readfirstlane(ent) & 0x7fffffffu);
-        const bool first = __builtin_amdgcn_readfirstlane((int)first_s[qt]) == kbi, last = __builtin_amdgcn_readfirstlane((int)last_s[qt]) == kbi;
-        if (first) {
+      if (it + 1 < n_ent) acc_load(it + 1, acc2[PAR ^ 1], mark_ld[PAR ^ 1]);          // (the null step has no partial)
+      {          // addresses of the next iteration
+        const unsigned d_st = n_off, d_ds = ds_cur - ds_prev;          // (wave-uniform; unsigned wrap-around is the subtraction)
 #pragma unroll
-          for (int r = 0; r < 16; r++) dq[r] = 0.f;
-        } else {
+        for (int ks = 0; ks < 4; ks++) a_rf[ks] += d_st;
 #pragma unroll
-          for (int g = 0; g < 4; g++) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(acc_g + (int64_t)qt * (TQ * DH) + g * 256);
-#pragma unroll
-            for (int e = 0; e < 4; e++) dq[4 * g + e] = v[e];
-          }
-          n_young += 4;
-        }
-        prev_qt = qt; prev_first = first; prev_last = last;
+        for (int t = 0; t < 2; t++) { a_tr[t][0] += d_st; a_tr[t][1] += d_st; a_db[t] += d_ds; }
+        a_rc += d_st; a_qb += d_st;
+      }
+      {
+        const int qt = (int)(__builtin_amdgcn_readfirstlane(list_s[it]) & 0x7fffffffu);
+        prev_qt = qt;
+        prev_first = __builtin_amdgcn_readfirstlane((int)first_s[qt]) == kbi || (dbg & 128);
+        prev_last = __builtin_amdgcn_readfirstlane((int)last_s[qt]) == kbi;
+        cur_qt = qt;
       }
       B1_SB();
     };
 
-    // the first step's first block: row constants, mask operand, row fragments (the loop reads them an iteration ahead)
-    if (n_ent > 0 && !wave_dead) {
+    // (behind the lambdas that use the counters) step 0's old partial, then: K image and stage 0 landed - stage 1 and the partial
+    // stay in flight
+    vm_n = 0; mark_dma = 0;
+    acc_load(0, acc2[0], mark_ld[0]);
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");          // (stage 1's five pieces and the partial's four loads stay in flight)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    mark_dma = 0;          // (stage 1's pieces: older than everything counted in vm_n)
+    mark_ld[1] = 0;
+    if (!wave_dead) {
+      // the first step's first block: row constants (into score set 0), mask operand, row fragments - the loop reads them an
+      // iteration ahead; and the neutral previous step: block 3' scores of -inf (P = 0), packed operands of block 2' and every
+      // transposed fragment zero (0 x finite: the products of iteration 0 that belong to no step add exact zeros)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const f32x4 t0 = LDS_RF4(lds_b + 16384u + o_rc + 32u * g), t1 = LDS_RF4(lds_b + 16384u + 256u + o_rc + 32u * g);
 #pragma unroll
-        for (int e = 0; e < 4; e++) { cl[4 * g + e] = t0[e]; cd[4 * g + e] = t1[e]; }
+        for (int e = 0; e < 4; e++) { S[0][4 * g + e] = t0[e]; dP[0][4 * g + e] = t1[e]; }
       }
       qbf = LDS_R8(lds_b + 16896u + o_qb);
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++) { rfQ[0][ks] = LDS_R8(lds_b + o_rf[ks]); rfO[0][ks] = LDS_R8(lds_b + 8192u + o_rf[ks]); }
+      for (int ks = 0; ks < 4; ks++) { rfQ[ks] = LDS_R8(lds_b + o_rf[ks]); rfO[ks] = LDS_R8(lds_b + 8192u + o_rf[ks]); }
+#pragma unroll
+      for (int r = 0; r < 16; r++) { S[1][r] = -INFINITY; dP[1][r] = 0.f; }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) { pb[0][i][w] = 0u; sb[0][i][w] = 0u; pb[1][i][w] = 0u; sb[1][i][w] = 0u; }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) { trO[i][j][e] = 0; trQ[i][j][e] = 0; }
     }
-    if (n_ent > 0) {
-      if (!wave_dead) {
-        iter.template operator()<false, true, true>(0);
-        for (int it = 1; it < n_ent; it++) iter.template operator()<true, true, true>(it);
-        iter.template operator()<true, false, true>(n_ent);
-      } else {
-        iter.template operator()<false, true, false>(0);
-        for (int it = 1; it < n_ent; it++) iter.template operator()<true, true, false>(it);
-        iter.template operator()<true, false, false>(n_ent);
-      }
+    prev_qt = 0; prev_first = true; prev_last = false;
+    // iterations 0 .. n_it - 1 (n_it even), parity of `it` as a template argument
+    if (!wave_dead) {
+      for (int it = 0; it < n_it; it += 2) { iter.template operator()<true, 0>(it); iter.template operator()<true, 1>(it + 1); }
+    } else {
+      for (int it = 0; it < n_it; it += 2) { iter.template operator()<false, 0>(it); iter.template operator()<false, 1>(it + 1); }
     }
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");          // the last dK / dV MFMAs before the epilogue reads the accumulators
     B1_SB();
@@ -807,7 +863,7 @@ extern "C" int mca_attn_bwd_onepass(const mca_attn_bwd1_args* a, mca_stream_t st
   if (!a || !a->q || !a->k || !a->v || !a->d_o || !a->rowc || !a->dvmean || !a->dq || !a->dk || !a->dv || !a->dq_acc) return MCA_E_BADARG;
   if (!a->keyinfo || !a->ktile_flags || !a->khot || !a->qblk || !a->qt_desc || !a->kb_desc || !a->kb_qt || !a->visit) return MCA_E_BADARG;
   if (a->batch <= 0 || a->heads <= 0 || a->n <= 0 || a->n_qtiles <= 0 || a->n_kblocks <= 0) return MCA_E_BADARG;
-  if (a->n_qtiles > B1_MAX_QT || a->n_kblocks > B1_MAX_KB || a->max_list > B1_MAX_LIST) return MCA_E_UNSUPPORTED;
+  if (a->n_qtiles >= B1_MAX_QT || a->n_kblocks > B1_MAX_KB || a->max_list + 2 > B1_MAX_LIST) return MCA_E_UNSUPPORTED;
   if (a->q_ld % 8 || a->kv_ld % 8 || a->o_ld % 8 || a->q_bstride % 8 || a->kv_bstride % 8 || a->o_bstride % 8) return MCA_E_ALIGN;
   if ((uintptr_t)a->q % 16 || (uintptr_t)a->k % 16 || (uintptr_t)a->v % 16 || (uintptr_t)a->d_o % 16 || (uintptr_t)a->khot % 16 || (uintptr_t)a->qblk % 16) return MCA_E_ALIGN;
   if (a->dq_ld % 8 || a->dq_bstride % 8 || (uintptr_t)a->dq % 16 || a->dkv_ld % 8 || a->dkv_bstride % 8 || (uintptr_t)a->dk % 16 || (uintptr_t)a->dv % 16) return MCA_E_ALIGN;

@@ -634,7 +634,8 @@ extern "C" int mca_attn_bwd_dkv(const mca_attn_bwd2_args* a, mca_stream_t stream
 // =====================================================================================================
 #define PREP_ROWS 32
 // row_slot != NULL (one-pass backward, attention_bwd1.hip): the row constants go out NEGATED and in that kernel's tile order
-// instead: rowc[b, h, tile, 0, pos] = -lse[b, h, q], rowc[b, h, tile, 1, pos] = -delta, row_slot[q] = tile * 64 + pos; positions
+// instead: rowc[b, h, tile, 0, pos] = -lse[b, h, q], rowc[b, h, tile, 1, pos] = -delta, row_slot[q] = tile * 64 + pos (n_qtiles + 1
+// tiles per (b, h): the last one is the one-pass kernel's null tile, never written here); positions
 // past a tile's rows keep what the caller initialised them with (-inf | 0: a row that contributes nothing)
 __device__ __forceinline__ void attn_bwd_prep_block(const int bx, const int by, const u16* __restrict__ o, const u16* __restrict__ d_o,
                                                     int64_t bstride, int64_t ld, float* __restrict__ delta, int heads, int nq,
@@ -680,7 +681,7 @@ __device__ __forceinline__ void attn_bwd_prep_block(const int bx, const int by, 
         if (!row_slot) delta[((int64_t)b * heads + h0 + hh) * nq + q_begin + r] = del_s[hh][r];
         else {
           const int q = q_begin + r, slot = row_slot[q];
-          float* dst = rowc + (((int64_t)b * heads + h0 + hh) * n_qtiles + (slot >> 6)) * 128 + (slot & 63);
+          float* dst = rowc + (((int64_t)b * heads + h0 + hh) * (n_qtiles + 1) + (slot >> 6)) * 128 + (slot & 63);          // (+ 1: the null tile)
           dst[0] = -lse[((int64_t)b * heads + h0 + hh) * nq + q];
           dst[64] = -del_s[hh][r];
         }

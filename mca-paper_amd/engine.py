@@ -86,7 +86,7 @@ class _OnePassSched:
         self.kb_qt = _dev(s.kb_qt.astype(np.uint32).view(np.int32), device)
         self.visit, self.row_slot = _dev(s.visit.astype(np.uint8), device), _dev(s.row_slot.astype(np.int32), device)
         self.n_qt, self.n_kb, self.max_list = len(s.qt_desc), len(s.kb_desc), int(s.kb_desc[:, 3].max())
-        self.fits = self.n_qt <= 256 and self.n_kb <= 64 and self.max_list <= 256          # the kernel's LDS tables
+        self.fits = self.n_qt < 256 and self.n_kb <= 64 and self.max_list + 2 <= 256          # the kernel's LDS tables
 
 
 class _BlockSched:
@@ -569,7 +569,7 @@ class FusionEngine:
         """one-pass backward of the layer attention (attention_bwd1.hip): dq, dk, dv bf16, every element written"""
         N, esz, sc = self.N, 2, self.sched_onepass
         if "rowc" not in ws:          # positions past a tile's rows: -inf | 0 (written once; the prep kernel only touches real rows)
-            rc = torch.empty(b, self.H, sc.n_qt, 2, 64, dtype=torch.float32, device=self.device)
+            rc = torch.empty(b, self.H, sc.n_qt + 1, 2, 64, dtype=torch.float32, device=self.device)          # (+ the null tile)
             rc[:, :, :, 0] = float("-inf"); rc[:, :, :, 1] = 0.0
             ws["rowc"] = rc
             ws["dq_acc"] = torch.empty(b * self.H * sc.n_qt * 4096, dtype=torch.float32, device=self.device)

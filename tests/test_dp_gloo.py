@@ -1,4 +1,6 @@
-"""Data-parallel path on CPU: world_size 2, gloo.  The collective logic of mca-paper_amd/dp.py (one packed
+"""Data-parallel path on CPU: world sizes 2 / 4 / 8, gloo, MCA-fcl and MMA (zorro) with 40 % of the modalities dropped (BASELINE
+configs[2] / configs[3]; labels rank * b + arange(b): utils/contrastive_loss_with_temperature.py:26-31, per-rank row masks with
+dropped modalities: model.py:198-207).  The collective logic of mca-paper_amd/dp.py (one packed
 all-gather of pooled embeddings + presence bits; bucketed gradient averaging) is driven with the ORACLE as the
 compute, and must reproduce a single-process run on the concatenated batch:
     grads_DP  ==  d/dtheta [ (1/W) * sum_r loss_r ]     (DDP mean over ranks, all-gather with backprop)
@@ -16,12 +18,13 @@ import torch.multiprocessing as mp
 from oracle import mca_oracle as O
 
 
-def _cfg():
+def _cfg(variant="mca"):
     enc = {"a": {"type": "EmbeddedSequenceEncoder", "input_size": 6, "max_tokens": 10, "embedding_dim": 32},
            "b": {"type": "EmbeddedSequenceEncoder", "input_size": 5, "max_tokens": 7, "embedding_dim": 32},
            "c": {"type": "TabularEncoder", "num_embeddings": 9, "max_tokens": 9, "max_value": 100, "embedding_dim": 32}}
+    mma = variant == "mma"          # MMA: masked multimodal attention (zorro), no fusion-channel losses
     return dict(encoder_configs=enc, dim=32, depth=2, heads=2, dim_head=16, ff_mult=4, num_fusion_tokens=8, batch_size=4,
-                fcl=True, fcl_root=[0, 1, 2], bimodal_contrastive=True, non_fusion_fcl=False, fusion_combos=[3, 2], zorro=False,
+                fcl=not mma, fcl_root=[0, 1, 2], bimodal_contrastive=True, non_fusion_fcl=False, fusion_combos=[3, 2], zorro=mma,
                 eao=False, no_fusion=False, mean_pool=False)
 
 
@@ -60,9 +63,9 @@ def _state(cfg):
     return sd
 
 
-def _batch(cfg, B):
+def _batch(cfg, B, p_drop=0.3):
     pkg = importlib.import_module("mca-paper_amd")
-    return pkg.data.synthetic_batch(cfg, B, seed=99, p_drop=0.3)
+    return pkg.data.synthetic_batch(cfg, B, seed=99, p_drop=p_drop)
 
 
 def _slice(batch, lo, hi):
@@ -84,18 +87,18 @@ def _sum_of_rank_losses(S, pooled_all, present_all, logit_scale, b, W, names):
     return tot
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, variant="mca", b=4, p_drop=0.3):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dp = importlib.import_module("mca-paper_amd.dp")
-        cfg = _cfg(); S = O.Structure(cfg); names = S.modalities
+        cfg = _cfg(variant); S = O.Structure(cfg); names = S.modalities
         sd = _state(cfg)
         params = {k: v for k, v in sd.items() if O.is_param(k)}
         for p in params.values():
             p.requires_grad_(True)
-        b = 4
-        local = _slice(_batch(cfg, b * world), rank * b, (rank + 1) * b)
+        local = _slice(_batch(cfg, b * world, p_drop), rank * b, (rank + 1) * b)
         P = O.Prec("fp32")
         tokens, padding, sample_mask = O.encode_and_pack(S, sd, local, P)
         pooled = O.mca_trunk(S, sd, tokens, padding, P)
@@ -126,28 +129,40 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_dp_world2_matches_single_process(tmp_path):
+@pytest.mark.parametrize("world,variant,b,p_drop", [(2, "mca", 4, 0.3), (2, "mma", 4, 0.4), (4, "mca", 2, 0.3), (4, "mma", 2, 0.4),
+                                                    (8, "mca", 2, 0.3), (8, "mma", 2, 0.4)])
+def test_dp_matches_single_process(tmp_path, world, variant, b, p_drop):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, out, variant, b, p_drop), nprocs=world, join=True)
     got = torch.load(out)
     # single process, concatenated batch: objective (1/W) sum_r loss_r with full autograd through the gather
-    cfg = _cfg(); S = O.Structure(cfg); names = S.modalities
+    cfg = _cfg(variant); S = O.Structure(cfg); names = S.modalities
     sd = _state(cfg)
     params = {k: v for k, v in sd.items() if O.is_param(k)}
     for p in params.values():
         p.requires_grad_(True)
-    W, b = 2, 4
+    W = world
     P = O.Prec("fp32")
-    tokens, padding, sample_mask = O.encode_and_pack(S, sd, _batch(cfg, W * b), P)
+    batch = _batch(cfg, W * b, p_drop)
+    tokens, padding, sample_mask = O.encode_and_pack(S, sd, batch, P)
     pooled = O.mca_trunk(S, sd, tokens, padding, P)
     present = _present(sample_mask, names)
+    if p_drop >= 0.4:
+        assert int((present != (1 << len(names)) - 1).sum()) > 0          # (the dropped-modality row masks are exercised)
     obj = _sum_of_rank_losses(S, pooled, present, sd["loss.loss_fn.logit_scale"], b, W, names) / W
     obj.backward()
     ref = torch.cat([(params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])).reshape(-1) for k in got["order"]])
     err = (got["flat"] - ref).abs().max() / ref.abs().max()
     assert err < 2e-5, err
     assert got["flat"].abs().max() > 0
+    # rank 0's own loss = the loss of its rows of the concatenated batch against ALL columns, labels rank * b + arange(b)
+    sm0 = {n: ((present[:b] >> i) & 1).bool() for i, n in enumerate(names)}
+    own_ref = O.pretraining_loss(S, pooled[:b].detach(), sm0, sd["loss.loss_fn.logit_scale"].detach(), pooled_all=pooled.detach(), rank=0)["loss"]
+    if torch.isnan(own_ref):
+        assert torch.isnan(got["own_loss"])
+    else:
+        assert abs(float(got["own_loss"]) - float(own_ref)) < 1e-5 * max(1.0, abs(float(own_ref)))
 
 
 def _cut_worker(rank, world, port, out):

@@ -627,9 +627,19 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first, prescaled=True, spi
         ref2 = (dq2.float(), dkv2[:, :, D:2 * D].float(), dkv2[:, :, 2 * D:].float())          # (the fp32-dq form of the loop's last turn)
         outs = []
         for aligned in (True, False):
-            got = _run_onepass(H, S_.build_onepass_schedule(qmask_np, st.kgroup, 64, 256, aligned), b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean,
-                               keyinfo, kflags, khot, qblk)
+            sc_ = S_.build_onepass_schedule(qmask_np, st.kgroup, 64, 256, aligned)
+            got = _run_onepass(H, sc_, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean, keyinfo, kflags, khot, qblk)
             for rep in got:
+                if torch.isnan(rep[0].float()).any() or torch.isnan(rep[1].float()).any():          # where: tile, wavefront block, sample
+                    nq_, msg = torch.isnan(rep[0].float()), []
+                    for t, (r0, rn) in enumerate(sc_.qt_desc.tolist()):
+                        for s_ in range(b):
+                            for hh in range(heads):
+                                blk_ = nq_[s_, r0:r0 + rn, hh * 64:hh * 64 + 64]
+                                if blk_.any():
+                                    ii = blk_.nonzero()
+                                    msg.append(f"sample {s_} head {hh} tile {t} rows {sorted(set(ii[:, 0].tolist()))[:6]}.. cols {sorted(set(ii[:, 1].tolist()))[:6]}..")
+                    raise AssertionError(f"NaN in the one-pass backward (aligned={aligned}): dq {int(nq_.sum())}, dkv {int(torch.isnan(rep[1].float()).sum())}; " + "; ".join(msg[:12]))
                 e_q, e_k, e_v = rel(rep[0].float(), rdq), rel(rep[1][:, :, D:2 * D].float(), rdk), rel(rep[1][:, :, 2 * D:].float(), rdv)
                 assert e_q < 1.5e-2 and e_k < 1.5e-2 and e_v < 1.5e-2, f"one-pass backward rel err dq {e_q} dk {e_k} dv {e_v} (aligned={aligned})"
                 assert (rep[1][:, :, :D] == 0).all()
@@ -646,7 +656,7 @@ def _run_onepass(H, sc, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean_ref, keyin
     i32 = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int32) if x.dtype == np.uint32 else np.ascontiguousarray(x)).to(dev)
     qt_desc, kb_desc, kb_qt, visit, row_slot = i32(sc.qt_desc), i32(sc.kb_desc), i32(sc.kb_qt), i32(sc.visit), i32(sc.row_slot)
     nqt, nkb = len(sc.qt_desc), len(sc.kb_desc)
-    rowc = torch.empty(b, heads, nqt, 2, 64, device=dev)
+    rowc = torch.empty(b, heads, nqt + 1, 2, 64, device=dev)          # (+ the null tile)
     rowc[:, :, :, 0] = float("-inf"); rowc[:, :, :, 1] = 0.0
     dvmean = torch.full_like(dvmean_ref, 3.0)
     H.call("mca_attn_bwd_prep_onepass", o.data_ptr(), d_o.data_ptr(), N * D, D, lse.data_ptr(), row_slot.data_ptr(), rowc.data_ptr(),
@@ -659,6 +669,7 @@ def _run_onepass(H, sc, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean_ref, keyin
         assert torch.equal(rowc[:, :, t, 0, :rn], -lse[:, :, r0:r0 + rn])
         assert (rowc[:, :, t, 1, :rn] + delta_ref[:, :, r0:r0 + rn]).abs().max() < 1e-3 * (1 + float(delta_ref.abs().max()))
         assert torch.isinf(rowc[:, :, t, 0, rn:]).all() and (rowc[:, :, t, 1, rn:] == 0).all()
+    assert torch.isinf(rowc[:, :, nqt, 0]).all() and (rowc[:, :, nqt, 1] == 0).all()
     acc = torch.full((b * heads * nqt * 4096,), float("nan"), device=dev)          # contents irrelevant on entry
     out = []
     for _ in range(2):

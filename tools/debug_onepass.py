@@ -13,6 +13,13 @@ else:
 N, D, dev = st.n_tokens, heads * 64, "cuda"
 g = torch.Generator(device=dev).manual_seed(11)
 pad = torch.zeros(b, N, dtype=torch.bool, device=dev)
+if os.environ.get("DBG_PAD"):          # the test's padding: a random valid prefix per modality
+    off_ = 0
+    for mi, n_ in enumerate(st.token_dims):
+        ln_ = torch.randint(1, n_ + 1, (b,), generator=g, device=dev)
+        pad[:, off_:off_ + n_] = torch.arange(n_, device=dev)[None] >= ln_[:, None]
+        off_ += n_
+    print("valid lengths per modality:", [(~pad[:, o_:o_ + n_]).sum(1).tolist() for o_, n_ in zip([0, 70, 115], st.token_dims)] if shape == "small" else "")
 qkv = T.bf(torch.randn(b, N, 3 * D, device=dev, generator=g))
 qkv[:, :, :D] = T.bf(qkv[:, :, :D].float() * T.C2)
 nk_pad = (N + 255) // 256 * 256
@@ -59,3 +66,41 @@ for hh in range(heads):
             e = min(kn, w + 32)
             print(f"  key block {kb} keys {k0 + w}..{k0 + e - 1}: dk " + " ".join(f"{rel(got[1][s_, k0 + w:k0 + e, D + hh * 64:D + hh * 64 + 64], ref[1][s_, k0 + w:k0 + e, D + hh * 64:D + hh * 64 + 64]):.3f}" for s_ in range(b))
                   + "  dv " + " ".join(f"{rel(got[1][s_, k0 + w:k0 + e, 2 * D + hh * 64:2 * D + hh * 64 + 64], ref[1][s_, k0 + w:k0 + e, 2 * D + hh * 64:2 * D + hh * 64 + 64]):.3f}" for s_ in range(b)))
+nan = torch.isnan(got[1].float())
+print("NaN count total", int(nan.sum()), "per sample", [int(nan[i].sum()) for i in range(b)])
+idx = nan.nonzero()
+if len(idx):
+    print("keys with NaN:", sorted(set(idx[:, 1].tolist()))[:40], "columns:", sorted(set((idx[:, 2] // 64).tolist())), "d within head:", sorted(set((idx[:, 2] % 64).tolist()))[:70])
+    # finite part of the affected rows vs reference
+    print("inf count", int(torch.isinf(got[1].float()).sum()))
+nq_ = torch.isnan(got[0].float())
+print("dq NaN count", int(nq_.sum()))
+for t, (r0, rn) in enumerate(sc.qt_desc.tolist()):
+    for s_ in range(b):
+        for hh in range(heads):
+            blk_ = nq_[s_, r0:r0 + rn, hh * 64:hh * 64 + 64]
+            if blk_.any():
+                print(f"  sample {s_} head {hh} tile {t}: NaN rows {sorted(set(blk_.nonzero()[:, 0].tolist()))[:40]} cols {sorted(set(blk_.nonzero()[:, 1].tolist()))[:70]}")
+print("---- repeat 6x each kernel, NaN counts (dq, dkv):")
+for rep in range(6):
+    with H.knobs(k9=64):
+        r_ = T._run_onepass(H, sc, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean, keyinfo, kflags, khot, qblk)
+    g_ = T._run_onepass(H, sc, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean, keyinfo, kflags, khot, qblk)
+    cnt = lambda t: int(torch.isnan(t.float()).sum())
+    print("plain", [(cnt(x[0]), cnt(x[1])) for x in r_], "pipelined", [(cnt(x[0]), cnt(x[1])) for x in g_])
+    for name, outs in (("plain", r_), ("pipelined", g_)):
+        for x in outs:
+            n_ = torch.isnan(x[1].float())
+            if n_.any():
+                i_ = n_.nonzero()
+                print("   ", name, "NaN samples", sorted(set(i_[:, 0].tolist())), "keys", sorted(set(i_[:, 1].tolist()))[:12], "..", "col blocks", sorted(set((i_[:, 2] // 64).tolist())))
+print("---- NaN positions (flat element offsets) over 12 launches of the pipelined kernel")
+for rep in range(12):
+    g_ = T._run_onepass(H, sc, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean, keyinfo, kflags, khot, qblk)
+    for li, x in enumerate(g_):
+        for nm, t in (("dq", x[0]), ("dkv", x[1])):
+            f = t.view(-1).view(torch.int16)
+            n_ = torch.isnan(t.float()).view(-1)
+            if n_.any():
+                pos = n_.nonzero().view(-1).tolist()
+                print(rep, li, nm, "ptr", hex(t.data_ptr()), "n", len(pos), "offsets", pos[:16], "bits", [hex(int(f[p]) & 0xffff) for p in pos[:8]], "row len", t.shape[-1])

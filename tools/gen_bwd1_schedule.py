@@ -15,8 +15,9 @@ The loop is ROTATED: iteration X runs A0..A3, V0..V2, C0, C1, W0..W2 of step X, 
 The one barrier of an iteration sits behind W3' (early in the iteration, in the shadow of A0 / C2', whose MFMAs do not depend on
 it); behind it come dQ' and the DMA of step X+2 (three stages); the row constants / fragments of step X+1's first block are read
 at the end of the iteration (their stage landed before this iteration's barrier).
-    MFMA stream:   A0 | C2' | A1 | C3' | A2 | C0 | A3 | C1      with the 16 dQ' MFMAs spread behind the barrier
-(A1 writes score set 1 only behind V3', which reads block 3's scores there: two score sets suffice.)
+    MFMA stream:   A0 | C2' | C3' | A1 | A2 | C0 | A3 | C1      with the 16 dQ' MFMAs spread behind the barrier
+The row constants of a block are read STRAIGHT INTO its score accumulators (the start values of the S^T / dP^T chains), so a
+block's constants can only be requested once the vector work of the block that used the set before is done (block 1: V3').
 Score sets and packed sets alternate (block j uses set j & 1).  Every other item has an EARLIEST slot (its producers: an MFMA
 result needs LAG slots before a vector instruction may read it - an inline-asm MFMA gets no hazard padding from hipcc, the distance
 IS the padding; a register set is free only behind its last reader) and a DEADLINE (its consumer minus the LDS latency); a list
@@ -26,11 +27,11 @@ Usage: python tools/gen_bwd1_schedule.py   (writes the .inc; the kernel defines 
 import os
 
 LAG = 2          # slots between an MFMA and the first vector instruction that reads its result (>= 11 wait states for 8 passes)
-LDS_LAT = 3      # slots between an LDS read and the MFMA that consumes it
+LDS_LAT = 6      # slots between an LDS read and the MFMA that consumes it (measured: with 3 the MFMAs waited 170 us per layer for fragments)
 VW = 2           # slots between a vector write of an MFMA operand (packed P / dS) and that MFMA (hipcc pads nothing around inline asm: 2 wait states)
 BUDGET = 24      # issue cycles of fillers per slot (an MFMA holds the issue port for 8 of its 32 cycles)
 COST = {"VE": 12, "VC": 8, "VEP": 12, "VCP": 8, "RC_L": 4, "RC_D": 4, "RQB": 4, "RF_Q": 4, "RF_O": 4, "TR_O": 8, "TR_Q": 8, "DSW": 6,
-        "DSWP": 6, "DQR": 16, "BARRIER": 24, "ISSUE": 24, "WAIT_ACC": 0, "NRC_L": 4, "NRC_D": 4, "NRQB": 4, "NRF_Q": 4, "NRF_O": 4}
+        "DSWP": 6, "DQR": 16, "BARRIER": 24, "ISSUE": 24, "ACC_LD": 16, "NRC_L": 4, "NRC_D": 4, "NRQB": 4, "NRF_Q": 4, "NRF_O": 4}
 
 
 def a_mfmas(j):
@@ -66,7 +67,7 @@ DQ_START = 20          # first stream position a dQ' MFMA may take (behind the b
 
 def mfma_stream():
     dq = [f"DQM({k})" for k in range(16)]
-    base = a_mfmas(0) + c_mfmas(2, True) + a_mfmas(1) + c_mfmas(3, True) + a_mfmas(2) + c_mfmas(0) + a_mfmas(3) + c_mfmas(1)
+    base = a_mfmas(0) + c_mfmas(2, True) + c_mfmas(3, True) + a_mfmas(1) + a_mfmas(2) + c_mfmas(0) + a_mfmas(3) + c_mfmas(1)
     return spread_from(base, dq, DQ_START)
 
 
@@ -86,33 +87,34 @@ def build():
     a3_tail = n - 1 - pos["A_P(3, 3)"]
     v3_ready = max(0, LAG - a3_tail)
     for r in range(16):
-        add(f"VEP({r})", v3_ready, pos["A_M(1)"] - 1)
+        add(f"VEP({r})", v3_ready, pos["A_M(1)"] - LDS_LAT - 1)
     for i in range(8):
         sp = i >> 2
         # packed set 1: C1, its last reader, ended the previous iteration; next reader C3'
-        add(f"VCP({i})", v3_ready, min(pos["A_M(1)"] - 1, pos[f"CP_V(3, {sp}, 0)"] - VW, pos[f"CP_K(3, {sp}, 0)"] - VW))
+        add(f"VCP({i})", v3_ready, min(pos["A_M(1)"] - LDS_LAT - 1, pos[f"CP_V(3, {sp}, 0)"] - VW, pos[f"CP_K(3, {sp}, 0)"] - VW))
     for sp in range(2):
         for t in range(2):
             add(f"DSWP({sp}, {t})", v3_ready, end)
     add("BARRIER()", 0, DQ_START - LDS_LAT - 1)
-    add("ISSUE()", 0, DQ_START)          # the DMA of step X + 2: right behind the barrier, ahead of WAIT_ACC (whose vmcnt counts its pieces)
-    # ---- row constants / mask operand / row fragments.  qb 0 of THIS step was read by the previous iteration (N* items below);
-    # qb 1 reuses the constants' registers behind their first readers in A1 (row fragments: one register set per qb)
-    for g in range(4):
-        add(f"RC_L(1, {g})", pos["A_M(1)"] + 1, pos["A_M(2)"] - LDS_LAT)
-        add(f"RC_D(1, {g})", pos["A_P(1, 0)"] + 1, pos["A_P(2, 0)"] - LDS_LAT)
+    add("ISSUE()", 0, DQ_START)          # the DMA of step X + 2: right behind the barrier
+    # ---- mask operand / row fragments: ONE register set each.  qb 0 of THIS step was read by the previous iteration (N* items);
+    # qb 1 follows behind the readers of qb 0 in A1, the next step's qb 0 behind the readers of qb 1 in A3
     add("RQB(1)", pos["A_M(1)"] + 1, pos["A_M(2)"] - LDS_LAT)
     for ks in range(4):
-        add(f"RF_Q(1, {ks})", 0, pos[f"A_S(2, {ks})"] - LDS_LAT)
-        add(f"RF_O(1, {ks})", 0, pos[f"A_P(2, {ks})"] - LDS_LAT)
-    # the NEXT step's qb 0: constants behind A3's first readers, fragments behind A1's last readers; all before the iteration ends
-    for g in range(4):
-        add(f"NRC_L({g})", pos["A_M(3)"] + 1, n - LDS_LAT)
-        add(f"NRC_D({g})", pos["A_P(3, 0)"] + 1, n - LDS_LAT)
-    add("NRQB()", pos["A_M(3)"] + 1, n - LDS_LAT)
+        add(f"RF_Q(1, {ks})", pos[f"A_S(1, {ks})"] + 1, pos[f"A_S(2, {ks})"] - LDS_LAT)
+        add(f"RF_O(1, {ks})", pos[f"A_P(1, {ks})"] + 1, pos[f"A_P(2, {ks})"] - LDS_LAT)
+    add("NRQB()", pos["A_M(3)"] + 1, n + pos["A_M(0)"] - LDS_LAT)
     for ks in range(4):
-        add(f"NRF_Q({ks})", pos[f"A_S(1, {ks})"] + 1, n - LDS_LAT)
-        add(f"NRF_O({ks})", pos[f"A_P(1, {ks})"] + 1, n - LDS_LAT)
+        add(f"NRF_Q({ks})", pos[f"A_S(3, {ks})"] + 1, n + pos[f"A_S(0, {ks})"] - LDS_LAT)
+        add(f"NRF_O({ks})", pos[f"A_P(3, {ks})"] + 1, n + pos[f"A_P(0, {ks})"] - LDS_LAT)
+    # ---- row constants of block j: into the score set j & 1, behind the vector work of the block that held it (dependencies below)
+    for j in (1, 2, 3):
+        for g in range(4):
+            add(f"RC_L({j}, {g})", 0, pos[f"A_M({j})"] - LDS_LAT)
+            add(f"RC_D({j}, {g})", 0, pos[f"A_P({j}, 0)"] - LDS_LAT)
+    for g in range(4):          # block 0 of the NEXT step (set 0: behind V2)
+        add(f"NRC_L({g})", 0, n + pos["A_M(0)"] - LDS_LAT)
+        add(f"NRC_D({g})", 0, n + pos["A_P(0, 0)"] - LDS_LAT)
     # ---- transposed fragments: ONE register set; readers in stream order: C2', C3' (qb 1 of the previous step, read at the end of the
     # previous iteration), C0, C1 (qb 0); the fragments of qb 1 of THIS step follow behind C1 (consumed by the next iteration)
     for sp in range(2):
@@ -125,7 +127,7 @@ def build():
     # block 2: the next iteration's A0)
     for j in range(3):
         ready = pos[f"A_P({j}, 3)"] + LAG
-        dl_scores = pos[f"A_M({j + 2})"] - 1 if j + 2 < 4 else end
+        dl_scores = pos[f"A_M({j + 2})"] - LDS_LAT - 1 if j + 2 < 4 else n + pos["A_M(0)"] - LDS_LAT - 1
         for r in range(16):
             add(f"VE({j}, {r})", ready, dl_scores)
         for i in range(8):
@@ -141,7 +143,6 @@ def build():
                 add(f"DSW({j}, {sp}, {t})", ready, end)
     for k in range(16):
         add(f"DQR({k})", 0 if k < 2 else pos[f"DQM({k - 2})"] + 1, pos[f"DQM({k})"] - LDS_LAT)          # two operand register sets
-    add("WAIT_ACC()", pos["DQM(0)"], pos["DQM(0)"])
 
     # dependencies between fillers (same or later slot, in this order inside a slot)
     after = {}
@@ -162,11 +163,20 @@ def build():
                 # the dS^T image of this step is the one dQ'' (two steps back) read until the previous iteration ended: any wavefront
                 # may write it only behind this iteration's barrier
                 after[f"DSW({j}, {sp}, {t})"] = [f"VC({j}, {4 * sp + 2 * t})", f"VC({j}, {4 * sp + 2 * t + 1})", "BARRIER()"]
+    holder = {1: [f"VEP({r})" for r in range(16)] + [f"VCP({i})" for i in range(8)],
+              2: [f"VE(0, {r})" for r in range(16)] + [f"VC(0, {i})" for i in range(8)],
+              3: [f"VE(1, {r})" for r in range(16)] + [f"VC(1, {i})" for i in range(8)]}
+    for j in (1, 2, 3):
+        for g in range(4):
+            after[f"RC_L({j}, {g})"] = list(holder[j]); after[f"RC_D({j}, {g})"] = list(holder[j])
+    for g in range(4):
+        after[f"NRC_L({g})"] = [f"VE(2, {r})" for r in range(16)] + [f"VC(2, {i})" for i in range(8)]
+        after[f"NRC_D({g})"] = list(after[f"NRC_L({g})"])
     for i in range(8):          # V1 overwrites the packed dS dwords W3' stores (set 1)
         after[f"VC(1, {i})"] = after[f"VC(1, {i})"] + [f"DSWP({i >> 2}, {(i & 3) >> 1})"]
     for i in range(8):          # V2 overwrites the packed dS dwords W0 stores (set 0)
         after[f"VC(2, {i})"] = after[f"VC(2, {i})"] + [f"DSW(0, {i >> 2}, {(i & 3) >> 1})"]
-    for nm in [k for k in after if k.startswith("NR")] + [k for k in items if k.startswith("NR")]:
+    for nm in [k for k in items if k.startswith("NR")]:
         after[nm] = list(set(after.get(nm, []) + ["BARRIER()"]))          # the next step's stage is visible behind the barrier
     for _ in range(4):          # a predecessor inherits its successors' deadlines
         for nm, preds in after.items():
@@ -198,7 +208,7 @@ def build():
     return slots, pos, placed
 
 
-PREV_ITEMS = ("DQM", "DQR", "WAIT_ACC")
+PREV_ITEMS = ("DQM", "DQR")
 PREV_LIVE_ITEMS = ("CP_V", "CP_K", "VEP", "VCP", "DSWP")
 NEXT_ITEMS = ("NRC_L", "NRC_D", "NRQB", "NRF_Q", "NRF_O")
 
@@ -221,14 +231,9 @@ def emit(slots, path):
              f"// {sum(1 for s in slots if s['mfma'])} matrix instructions; LAG {LAG}, LDS latency {LDS_LAT} slots, filler budget {BUDGET} cycles per slot"]
     for si, s in enumerate(slots):
         parts = []
-        for f in s["fill"]:
-            if f.startswith("WAIT_ACC"):          # ahead of the slot's MFMA
-                parts.append(f"if ({guard_of(f)}) {{ {f}; }}")
         if s["mfma"]:
             parts.append(f"if ({guard_of(s['mfma'])}) {{ {s['mfma']}; }}")
         for f in s["fill"]:
-            if f.startswith("WAIT_ACC"):
-                continue
             g = guard_of(f)
             parts.append(f"if ({g}) {{ {f}; }}" if g else f"{f};")
         lines.append(f"/* slot {si:3d} */ " + " ".join(parts) + " B1_SB();")
