@@ -381,6 +381,55 @@ __global__ __launch_bounds__(256, 1) void attn_bwd1_kernel(mca_attn_bwd1_args a,
                                  else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(D) : "v"(A), "v"(B)); } while (0)
 #define MF_ACC_VV(D, A, B) do { if (STEADY) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "v"(A), "v"(B)); \
                                 else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(D) : "v"(A), "v"(B)); } while (0)
+// The two dQ accumulators are OWNED registers, a[224:239] and a[240:255]: they are the landing registers of asynchronous loads (the
+// old partial arrives while other work runs), and a value hipcc can see it may copy, spill or reuse the moment the loading
+// statement ends - it did: copies at the loop's back edge and a fragment read into registers whose load was still in flight.
+// Every statement that touches them names them and lists them as clobbers; tools/audit_bwd1_isa.py proves nothing else does.
+#define ACC_CLOB_0 "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239"
+#define ACC_CLOB_1 "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+template <int BUF> __device__ __forceinline__ void b1_acc_load(const float* src) {          // four 1-KiB pieces of this lane's slot
+  if (BUF == 0) asm volatile("global_load_dwordx4 a[224:227], %0, off\n\tglobal_load_dwordx4 a[228:231], %0, off offset:1024\n\t"
+                             "global_load_dwordx4 a[232:235], %0, off offset:2048\n\tglobal_load_dwordx4 a[236:239], %0, off offset:3072"
+                             :: "v"(src) : "memory", ACC_CLOB_0);
+  else asm volatile("global_load_dwordx4 a[240:243], %0, off\n\tglobal_load_dwordx4 a[244:247], %0, off offset:1024\n\t"
+                    "global_load_dwordx4 a[248:251], %0, off offset:2048\n\tglobal_load_dwordx4 a[252:255], %0, off offset:3072"
+                    :: "v"(src) : "memory", ACC_CLOB_1);
+}
+template <int BUF> __device__ __forceinline__ void b1_acc_store(float* dst) {          // (s_nop 1: the data registers of the last store)
+  if (BUF == 0) asm volatile("global_store_dwordx4 %0, a[224:227], off\n\tglobal_store_dwordx4 %0, a[228:231], off offset:1024\n\t"
+                             "global_store_dwordx4 %0, a[232:235], off offset:2048\n\tglobal_store_dwordx4 %0, a[236:239], off offset:3072\n\ts_nop 1"
+                             :: "v"(dst) : "memory");
+  else asm volatile("global_store_dwordx4 %0, a[240:243], off\n\tglobal_store_dwordx4 %0, a[244:247], off offset:1024\n\t"
+                    "global_store_dwordx4 %0, a[248:251], off offset:2048\n\tglobal_store_dwordx4 %0, a[252:255], off offset:3072\n\ts_nop 1"
+                    :: "v"(dst) : "memory");
+}
+template <int BUF> __device__ __forceinline__ void b1_acc_read(float (&t)[16]) {
+  if (BUF == 0) asm volatile("v_accvgpr_read_b32 %0, a224\n\tv_accvgpr_read_b32 %1, a225\n\tv_accvgpr_read_b32 %2, a226\n\tv_accvgpr_read_b32 %3, a227\n\t"
+                             "v_accvgpr_read_b32 %4, a228\n\tv_accvgpr_read_b32 %5, a229\n\tv_accvgpr_read_b32 %6, a230\n\tv_accvgpr_read_b32 %7, a231\n\t"
+                             "v_accvgpr_read_b32 %8, a232\n\tv_accvgpr_read_b32 %9, a233\n\tv_accvgpr_read_b32 %10, a234\n\tv_accvgpr_read_b32 %11, a235\n\t"
+                             "v_accvgpr_read_b32 %12, a236\n\tv_accvgpr_read_b32 %13, a237\n\tv_accvgpr_read_b32 %14, a238\n\tv_accvgpr_read_b32 %15, a239"
+                             : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]),
+                               "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+  else asm volatile("v_accvgpr_read_b32 %0, a240\n\tv_accvgpr_read_b32 %1, a241\n\tv_accvgpr_read_b32 %2, a242\n\tv_accvgpr_read_b32 %3, a243\n\t"
+                    "v_accvgpr_read_b32 %4, a244\n\tv_accvgpr_read_b32 %5, a245\n\tv_accvgpr_read_b32 %6, a246\n\tv_accvgpr_read_b32 %7, a247\n\t"
+                    "v_accvgpr_read_b32 %8, a248\n\tv_accvgpr_read_b32 %9, a249\n\tv_accvgpr_read_b32 %10, a250\n\tv_accvgpr_read_b32 %11, a251\n\t"
+                    "v_accvgpr_read_b32 %12, a252\n\tv_accvgpr_read_b32 %13, a253\n\tv_accvgpr_read_b32 %14, a254\n\tv_accvgpr_read_b32 %15, a255"
+                    : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]),
+                      "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+}
+// the dQ product's MFMAs on an owned accumulator (always padded: two per iteration carry the pad, the other fourteen do not need
+// it - their operands come from LDS reads - but one form keeps the strings few); ZERO: the first product of a tile's first visit
+template <int BUF, bool ZERO, bool PAD> __device__ __forceinline__ void b1_acc_mfma(const bf16x8& a_, const bf16x8& b_) {
+  if (BUF == 0) {
+    if (ZERO) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[224:239], %0, %1, 0" :: "v"(a_), "v"(b_) : ACC_CLOB_0);
+    else if (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[224:239], %0, %1, a[224:239]" :: "v"(a_), "v"(b_) : ACC_CLOB_0);
+    else asm volatile("v_mfma_f32_32x32x16_bf16 a[224:239], %0, %1, a[224:239]" :: "v"(a_), "v"(b_) : ACC_CLOB_0);
+  } else {
+    if (ZERO) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[240:255], %0, %1, 0" :: "v"(a_), "v"(b_) : ACC_CLOB_1);
+    else if (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[240:255], %0, %1, a[240:255]" :: "v"(a_), "v"(b_) : ACC_CLOB_1);
+    else asm volatile("v_mfma_f32_32x32x16_bf16 a[240:255], %0, %1, a[240:255]" :: "v"(a_), "v"(b_) : ACC_CLOB_1);
+  }
+}
 // LDS-DMA by hand (M0 written in the same statement): hipcc then knows of no LDS write in flight - with the builtin it drained
 // vmcnt(0) in front of the next LDS read, i.e. every iteration waited for ALL of its memory traffic.  BASE: wave-uniform 64-bit
 // pointer, OFF: this lane's 32-bit byte offset, LDS_DST: wave-uniform LDS byte address (lane l lands at + 16 l / + 4 l).  The kernel's
@@ -548,13 +597,11 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     };
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // list_s visible; every wavefront is past the previous block
-    issue(list_s[0], 0);          // (n_it >= 2: a key block has at least one real step and the null step)
-    issue(list_s[1], 1);
 
     // ---- pipeline state
-    // acc2: the dQ accumulators of two steps (accumulator half).  acc2[s & 1] receives the OLD partial of step s's tile two
-    // iterations before step s's dQ product (iteration s + 1) accumulates onto it in place
-    f32x16 S[2], dP[2], acc2[2];
+    // (the dQ accumulators of two steps are the owned registers a[224:255]: buffer s & 1 receives the OLD partial of step s's tile
+    //  two iterations before step s's dQ product - iteration s + 1 - accumulates onto it in place)
+    f32x16 S[2], dP[2];
     u32x4v pb[2][2], sb[2][2];
     bf16x8 rfQ[4], rfO[4], qbf, trO[2][2], trQ[2][2], da[2], db[2];
     // (deliberately uninitialised: every element is written before its first real use, and a zero held 'just in case' stays live -
@@ -600,21 +647,13 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
                               else if (y_ >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                            \
                               else if (y_ >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                            \
                               else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
-    // the old dQ partial of step s's tile -> acc2[s & 1].  Inline asm, always four loads: hipcc then keeps no count of its own for
-    // them (its count cannot see the LDS-DMA: it drained vmcnt(0) ahead of the first dQ product, every iteration) and the kernel's
-    // counts do not depend on the tile.  A first visit has no partial: it re-reads the slot the previous step stored (cached; the
-    // value is never used - the first product of a first visit starts from the constant 0, DQM).  The loaded registers are
-    // touched by nothing but the dQ MFMAs behind the counted wait (tools/audit_bwd1_isa.py checks that).
-    auto acc_load = [&](int s_idx, f32x16& dst, int& mark) {
+    // the old dQ partial of step s's tile -> accumulator buffer BUF = s & 1.  Always four loads: the kernel's counts then do not
+    // depend on the tile.  A first visit has no partial: it re-reads the slot the previous step stored (cached; the value is never
+    // used - the first product of a first visit starts from the constant 0, DQM).
+    auto acc_load = [&]<int BUF>(int s_idx, int& mark) __attribute__((always_inline)) {
       const int qt = (int)(__builtin_amdgcn_readfirstlane(list_s[s_idx]) & 0x7fffffffu);
       const bool first = __builtin_amdgcn_readfirstlane((int)first_s[qt]) == kbi || (dbg & 128);
-      const float* src = acc_g + (int64_t)(first ? prev_qt : qt) * (TQ * DH);
-      f32x4 t0, t1, t2, t3;
-      asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"
-                   "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"
-                   : "=a"(t0), "=a"(t1), "=a"(t2), "=a"(t3) : "v"(src) : "memory");
-#pragma unroll
-      for (int e = 0; e < 4; e++) { dst[e] = t0[e]; dst[4 + e] = t1[e]; dst[8 + e] = t2[e]; dst[12 + e] = t3[e]; }
+      b1_acc_load<BUF>(acc_g + (int64_t)(first ? prev_qt : qt) * (TQ * DH));
       vm_n += 4;
       mark = vm_n;
     };
@@ -675,14 +714,13 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
 #define TR_O(QB, SP, N) if (!(B1_ABL & 4)) TR2_(trO[SP][N], a_tr[0][N], a_tr[1][N], 8192 + (QB) * 4096 + (SP) * 2048)
 #define TR_Q(QB, SP, N) if (!(B1_ABL & 4)) TR2_(trQ[SP][N], a_tr[0][N], a_tr[1][N], (QB) * 4096 + (SP) * 2048)
 #define DQR(K) do { if (B1_ABL & 2) break; TR2_(da[(K) & 1], a_da[0], a_da[1], (K) * 2048); TR2_(db[(K) & 1], a_db[0], a_db[1], (K) * 2048); } while (0)
-      // (the first product of a tile's first visit starts from the constant 0: no zeroing of the accumulator, whose only other
-      //  definition - the loads of the old partial - then goes straight to the accumulator half)
+      // (the first product of a tile's first visit starts from the constant 0; behind the counted wait in either case: an unused load
+      //  that lands later would overwrite the product)
 #define DQM(K) do { if (B1_ABL & 2) break;                                                                                   \
-                    if ((K) == 0) { VM_WAIT(vm_n - mark_ld[PAR ^ 1]);          /* (a first visit too: its unused load must have landed) */ \
-                                    /* (padded: hipcc may assemble the loaded partial into the accumulator's registers just ahead) */ \
-                                    if (prev_first) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc2[PAR ^ 1]) : "v"(da[0]), "v"(db[0])); \
-                                    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc2[PAR ^ 1]) : "v"(da[0]), "v"(db[0])); } \
-                    else MF_ACCA_VV(acc2[PAR ^ 1], da[(K) & 1], db[(K) & 1]); } while (0)
+                    if ((K) == 0) { VM_WAIT(vm_n - mark_ld[PAR ^ 1]);                                                        \
+                                    if (prev_first) b1_acc_mfma<PAR ^ 1, true, true>(da[0], db[0]);                          \
+                                    else b1_acc_mfma<PAR ^ 1, false, true>(da[0], db[0]); }                                  \
+                    else b1_acc_mfma<PAR ^ 1, false, !STEADY>(da[(K) & 1], db[(K) & 1]); } while (0)
       // the barrier: this wavefront's dS^T stores are done (lgkmcnt) and its pieces of the NEXT step's stage have landed
 #define BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); VM_WAIT(vm_n - mark_dma);                  \
                        __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
@@ -727,9 +765,10 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       {
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");          // the last dQ MFMA's result before anything else reads it
         B1_SB();
-        f32x16& dq = acc2[PAR ^ 1];
         if (it > 0 && it <= n_ent && !(dbg & 256)) {          // (no previous step in iteration 0; a null step's product goes nowhere)
           if (prev_last) {
+            float dq[16];
+            b1_acc_read<PAR ^ 1>(dq);
             const int2 qd = qtd_s[prev_qt];
             const int r = (wave >> 1) * 32 + l31;
             // (a lane past the tile's rows stores to its own dq_acc slot, which nobody reads: every lane issues four stores)
@@ -742,15 +781,11 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
               pk.y = pack2bf_pk(dq[4 * g + 2] * a.scale, dq[4 * g + 3] * a.scale);
               *reinterpret_cast<uint2*>(p + 8 * g) = pk;
             }
-          } else {
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-              *reinterpret_cast<f32x4*>(acc_g + (int64_t)prev_qt * (TQ * DH) + g * 256) = f32x4{dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]};
-          }
+          } else b1_acc_store<PAR ^ 1>(acc_g + (int64_t)prev_qt * (TQ * DH));
           vm_n += 4;
         }
       }
-      if (it + 1 < n_ent) acc_load(it + 1, acc2[PAR ^ 1], mark_ld[PAR ^ 1]);          // (the null step has no partial)
+      if (it + 1 < n_ent) acc_load.template operator()<PAR ^ 1>(it + 1, mark_ld[PAR ^ 1]);          // (the null step has no partial)
       {          // addresses of the next iteration
         const unsigned d_st = n_off, d_ds = ds_cur - ds_prev;          // (wave-uniform; unsigned wrap-around is the subtraction)
 #pragma unroll
@@ -769,15 +804,17 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       B1_SB();
     };
 
-    // (behind the lambdas that use the counters) step 0's old partial, then: K image and stage 0 landed - stage 1 and the partial
-    // stay in flight
-    vm_n = 0; mark_dma = 0;
-    acc_load(0, acc2[0], mark_ld[0]);
-    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");          // (stage 1's five pieces and the partial's four loads stay in flight)
+    // (behind the lambdas that use the counters) step 0's old partial, the first two stages; K image, partial and stage 0 landed
+    // Order: the partial's loads are OLDER than stage 1's pieces, so the one wait below covers them: an inline-asm load's
+    // registers count as written for hipcc as soon as the statement ends - it copied them into the loop's registers at the loop
+    // entry, before the data had landed, and the data then landed in registers that held something else by then.
+    acc_load.template operator()<0>(0, mark_ld[0]);
+    issue(list_s[0], 0);          // (n_it >= 2: a key block has at least one real step and the null step)
+    issue(list_s[1], 1);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");          // (only stage 1's five pieces stay in flight)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    mark_dma = 0;          // (stage 1's pieces: older than everything counted in vm_n)
-    mark_ld[1] = 0;
+    vm_n = 5; mark_dma = 5; mark_ld[0] = 0; mark_ld[1] = 0;          // (counted from stage 1's pieces on)
     if (!wave_dead) {
       // the first step's first block: row constants (into score set 0), mask operand, row fragments - the loop reads them an
       // iteration ahead; and the neutral previous step: block 3' scores of -inf (P = 0), packed operands of block 2' and every

@@ -115,10 +115,43 @@ def audit(text: str):
     return problems, n_mfma, n_asm_mfma
 
 
+OWNED = {("a", i) for i in range(224, 256)}          # the two dQ accumulators (ACC_CLOB_0 / ACC_CLOB_1 of attention_bwd1.hip)
+
+
+def audit_owned(text: str):
+    """(c) the dQ accumulators a[224:255] are the landing registers of asynchronous loads; hipcc believes a register written when
+    the statement that names it ends.  So NOTHING outside an inline-asm statement may read or write them, anywhere in the kernel."""
+    start = text.index(f"_Z17{KERNEL}")
+    end = text.index(".amdhsa_kernel", start) if ".amdhsa_kernel" in text[start:] else len(text)
+    problems, in_asm, n_asm = [], False, 0
+    for ln, raw in enumerate(text[start:end].split("\n")):
+        s_ = raw.strip()
+        if s_.startswith(";;#ASMSTART"):
+            in_asm = True; continue
+        if s_.startswith(";;#ASMEND"):
+            in_asm = False; continue
+        p_ = parse(raw)
+        if p_ is None:
+            continue
+        regs = set()
+        for o in p_[1]:
+            regs |= regs_of(o)
+        if regs & OWNED:
+            if in_asm:
+                n_asm += 1
+            else:
+                problems.append(f"line {ln}: '{p_[0]}' (not inline asm) touches {sorted(regs & OWNED)[:2]}..")
+    return problems, n_asm
+
+
 if __name__ == "__main__":
     txt = open(sys.argv[1]).read() if len(sys.argv) > 1 else compile_isa()
     probs, n, na = audit(txt)
     print(f"{KERNEL}: {n} MFMAs ({na} inline asm), {len(probs)} hazard(s)")
     for p in probs[:40]:
         print("  " + p)
-    sys.exit(1 if probs else 0)
+    probs2, nl = audit_owned(txt)
+    print(f"{KERNEL}: {nl} inline-asm instructions on the owned accumulators a[224:255], {len(probs2)} compiler instruction(s) touching them")
+    for p in probs2[:20]:
+        print("  " + p)
+    sys.exit(1 if (probs or probs2) else 0)

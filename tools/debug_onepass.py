@@ -11,15 +11,18 @@ if shape == "small":
 else:
     st, b, heads = S.FusionStructure([1500, 450, 450, 50], 88, (4, 3, 2), fcl=True), 2, 2
 N, D, dev = st.n_tokens, heads * 64, "cuda"
-g = torch.Generator(device=dev).manual_seed(11)
+g = torch.Generator(device=dev).manual_seed(int(os.environ.get("DBG_SEED", "11")))
 pad = torch.zeros(b, N, dtype=torch.bool, device=dev)
 if os.environ.get("DBG_PAD"):          # the test's padding: a random valid prefix per modality
     off_ = 0
     for mi, n_ in enumerate(st.token_dims):
         ln_ = torch.randint(1, n_ + 1, (b,), generator=g, device=dev)
+        if os.environ.get("DBG_DROP") and mi == 0:
+            ln_[0] = 0
         pad[:, off_:off_ + n_] = torch.arange(n_, device=dev)[None] >= ln_[:, None]
         off_ += n_
-    print("valid lengths per modality:", [(~pad[:, o_:o_ + n_]).sum(1).tolist() for o_, n_ in zip([0, 70, 115], st.token_dims)] if shape == "small" else "")
+    offs_ = np.concatenate([[0], np.cumsum(st.token_dims)]).tolist()
+    print("valid lengths per modality:", [(~pad[:, o_:o_ + n_]).sum(1).tolist() for o_, n_ in zip(offs_, st.token_dims)])
 qkv = T.bf(torch.randn(b, N, 3 * D, device=dev, generator=g))
 qkv[:, :, :D] = T.bf(qkv[:, :, :D].float() * T.C2)
 nk_pad = (N + 255) // 256 * 256
