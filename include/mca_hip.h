@@ -330,9 +330,11 @@ int mca_attn_bwd_dkv_fp8(const mca_attn_bwd2_args* args, const mca_attn_fp8_bwd_
  * irrelevant on entry.  dq, dk, dv bf16, every element written.  n_qtiles < 256, n_kblocks <= 64, max_list < 256, else MCA_E_UNSUPPORTED
  * (the caller keeps the two-pass form).                                                                                  */
 typedef struct {
-  const uint16_t* q; int64_t q_bstride; int64_t q_ld;
+  const uint16_t* q; int64_t q_bstride; int64_t q_ld;           /* q[b*q_bstride + head*q_hstride + i*q_ld + d]                       */
   const uint16_t* k; const uint16_t* v; int64_t kv_bstride; int64_t kv_ld;
-  const uint16_t* d_o; int64_t o_bstride; int64_t o_ld;
+  const uint16_t* d_o; int64_t o_bstride; int64_t o_ld;        /* d_o[b*o_bstride + head*o_hstride + i*o_ld + d]                     */
+  int64_t q_hstride, o_hstride;                                /* elements between heads: 64 in a (b, n, heads*64) matrix (0 = 64);   */
+                                                               /* n*64 in the head-major packed copies of mca_attn_bwd_prep_onepass  */
   const float* rowc; const float* dvmean;
   uint16_t* dq; int64_t dq_bstride; int64_t dq_ld;
   uint16_t* dk; uint16_t* dv; int64_t dkv_bstride; int64_t dkv_ld;
@@ -346,9 +348,12 @@ typedef struct {
 } mca_attn_bwd1_args;
 int mca_attn_bwd_onepass(const mca_attn_bwd1_args* args, mca_stream_t stream);
 /* mca_attn_bwd_prep for the one-pass form: rowc in tile order (row_slot[q] = tile * 64 + position) instead of delta; dvmean as
- * mca_attn_bwd_prep                                                                                                      */
+ * mca_attn_bwd_prep.  Optional (q_hm and do_hm both or neither): head-major packed copies q_hm / do_hm [batch][heads][n][64] of
+ * q (read with q_bstride / q_ld) and d_o - the one-pass kernel then reads a 64-row tile of a head as 8 KiB of contiguous memory
+ * (pass them as its q / d_o with q_bstride = heads*n*64, q_hstride = n*64, q_ld = 64).                                   */
 int mca_attn_bwd_prep_onepass(const uint16_t* o, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld, const float* lse,
                               const int32_t* row_slot, float* rowc, float* dvmean, int batch, int heads, int n, int n_qtiles,
+                              const uint16_t* q, int64_t q_bstride, int64_t q_ld, uint16_t* q_hm, uint16_t* do_hm,
                               mca_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

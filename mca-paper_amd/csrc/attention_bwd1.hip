@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd1_kernel(mca_attn_bwd1_args a,
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
   const int64_t bh = (int64_t)b * a.heads + h;
 
-  const u16* qbase = a.q + (int64_t)b * a.q_bstride + h * DH;
-  const u16* obase = a.d_o + (int64_t)b * a.o_bstride + h * DH;
+  const u16* qbase = a.q + (int64_t)b * a.q_bstride + h * (a.q_hstride ? a.q_hstride : (int64_t)DH);
+  const u16* obase = a.d_o + (int64_t)b * a.o_bstride + h * (a.o_hstride ? a.o_hstride : (int64_t)DH);
   const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
   const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
   const float* rowc_g = a.rowc + bh * (int64_t)(a.n_qtiles + 1) * 128;          // (+ the null tile)
@@ -469,8 +469,8 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
   const int64_t bh = (int64_t)b * a.heads + h;
 
-  const u16* qbase = a.q + (int64_t)b * a.q_bstride + h * DH;
-  const u16* obase = a.d_o + (int64_t)b * a.o_bstride + h * DH;
+  const u16* qbase = a.q + (int64_t)b * a.q_bstride + h * (a.q_hstride ? a.q_hstride : (int64_t)DH);
+  const u16* obase = a.d_o + (int64_t)b * a.o_bstride + h * (a.o_hstride ? a.o_hstride : (int64_t)DH);
   const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
   const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
   const float* rowc_g = a.rowc + bh * (int64_t)(a.n_qtiles + 1) * 128;          // (+ the null tile)
@@ -583,8 +583,9 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
         const int p = wave * 2 + u, r = p * 8 + r8;
         const int row = row0 + (r < nrows ? r : nrows - 1);
         const unsigned sw = (unsigned)(((ln & 7) ^ b1_swz(r)) << 4);
-        B1_DMA16(qbase, (unsigned)row * (unsigned)(a.q_ld * 2) + sw, sb_ + (unsigned)p * 1024u);
-        B1_DMA16(obase, (unsigned)row * (unsigned)(a.o_ld * 2) + sw, sb_ + 8192u + (unsigned)p * 1024u);
+        // (knob 9 bit 1024, timing only: the same bytes from contiguous 128-byte rows instead of rows q_ld apart)
+        B1_DMA16(qbase, (unsigned)row * ((dbg & 1024) ? 128u : (unsigned)(a.q_ld * 2)) + sw, sb_ + (unsigned)p * 1024u);
+        B1_DMA16(obase, (unsigned)row * ((dbg & 1024) ? 128u : (unsigned)(a.o_ld * 2)) + sw, sb_ + 8192u + (unsigned)p * 1024u);
       }
       if (wave < 2) {
         const float* rb = rowc_g + (int64_t)qt * 128 + wave * 64;
@@ -901,7 +902,7 @@ extern "C" int mca_attn_bwd_onepass(const mca_attn_bwd1_args* a, mca_stream_t st
   if (!a->keyinfo || !a->ktile_flags || !a->khot || !a->qblk || !a->qt_desc || !a->kb_desc || !a->kb_qt || !a->visit) return MCA_E_BADARG;
   if (a->batch <= 0 || a->heads <= 0 || a->n <= 0 || a->n_qtiles <= 0 || a->n_kblocks <= 0) return MCA_E_BADARG;
   if (a->n_qtiles >= B1_MAX_QT || a->n_kblocks > B1_MAX_KB || a->max_list + 2 > B1_MAX_LIST) return MCA_E_UNSUPPORTED;
-  if (a->q_ld % 8 || a->kv_ld % 8 || a->o_ld % 8 || a->q_bstride % 8 || a->kv_bstride % 8 || a->o_bstride % 8) return MCA_E_ALIGN;
+  if (a->q_ld % 8 || a->kv_ld % 8 || a->o_ld % 8 || a->q_bstride % 8 || a->kv_bstride % 8 || a->o_bstride % 8 || a->q_hstride % 8 || a->o_hstride % 8) return MCA_E_ALIGN;
   if ((uintptr_t)a->q % 16 || (uintptr_t)a->k % 16 || (uintptr_t)a->v % 16 || (uintptr_t)a->d_o % 16 || (uintptr_t)a->khot % 16 || (uintptr_t)a->qblk % 16) return MCA_E_ALIGN;
   if (a->dq_ld % 8 || a->dq_bstride % 8 || (uintptr_t)a->dq % 16 || a->dkv_ld % 8 || a->dkv_bstride % 8 || (uintptr_t)a->dk % 16 || (uintptr_t)a->dv % 16) return MCA_E_ALIGN;
   if ((uintptr_t)a->dq_acc % 16 || (uintptr_t)a->rowc % 4 || (uintptr_t)a->kb_desc % 16 || (uintptr_t)a->qt_desc % 8) return MCA_E_ALIGN;

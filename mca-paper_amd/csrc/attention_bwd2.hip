@@ -640,7 +640,9 @@ extern "C" int mca_attn_bwd_dkv(const mca_attn_bwd2_args* a, mca_stream_t stream
 __device__ __forceinline__ void attn_bwd_prep_block(const int bx, const int by, const u16* __restrict__ o, const u16* __restrict__ d_o,
                                                     int64_t bstride, int64_t ld, float* __restrict__ delta, int heads, int nq,
                                                     const float* __restrict__ lse, const int32_t* __restrict__ row_slot,
-                                                    float* __restrict__ rowc, int n_qtiles) {
+                                                    float* __restrict__ rowc, int n_qtiles,
+                                                    const u16* __restrict__ qsrc, int64_t q_bstride, int64_t q_ld,
+                                                    u16* __restrict__ q_hm, u16* __restrict__ do_hm) {
   // delta is (b, head, q): a row touches it at a stride of nq floats per head.  It crosses LDS so that the global accesses are
   // 128-byte runs along q (one row at a time they were 4-byte accesses in 8 different lines per row).
   __shared__ float del_s[8][PREP_ROWS];
@@ -665,6 +667,13 @@ __device__ __forceinline__ void attn_bwd_prep_block(const int bx, const int by, 
     for (int k = 0; k < PREP_ROWS / 4; k++) {
       const int q = q_begin + wave + 4 * k;
       if (q >= q_end) break;
+      // head-major packed copies for the one-pass backward ([b][head][row][64]: a 64-row tile of one head is 8 KiB contiguous; read
+      // from rows 3 KiB apart its LDS-DMA pieces were eight 128-byte segments in eight DRAM pages: 200 us per layer at b = 32)
+      if (do_hm && c < cols) {
+        const int64_t dst = (((int64_t)b * heads + h0 + hl) * nq + q) * DH + (lane & 7) * 8;
+        *reinterpret_cast<bf16x8*>(do_hm + dst) = dvs[k];
+        *reinterpret_cast<bf16x8*>(q_hm + dst) = *reinterpret_cast<const bf16x8*>(qsrc + (int64_t)b * q_bstride + (int64_t)q * q_ld + c);
+      }
       float part = 0.f;
       if (c < cols) {
 #pragma unroll
@@ -758,8 +767,11 @@ __device__ __forceinline__ void attn_dvmean_block(const int bx, const int by, co
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const u16* __restrict__ o, const u16* __restrict__ d_o, int64_t bstride, int64_t ld,
                                                              const float* __restrict__ lse, float* __restrict__ delta,
                                                              float* __restrict__ dvmean, int heads, int nq, float inv_nk, int n_prep,
-                                                             const int32_t* __restrict__ row_slot, float* __restrict__ rowc, int n_qtiles) {
-  if ((int)blockIdx.x < n_prep) attn_bwd_prep_block((int)blockIdx.x, (int)blockIdx.y, o, d_o, bstride, ld, delta, heads, nq, lse, row_slot, rowc, n_qtiles);
+                                                             const int32_t* __restrict__ row_slot, float* __restrict__ rowc, int n_qtiles,
+                                                             const u16* __restrict__ qsrc, int64_t q_bstride, int64_t q_ld,
+                                                             u16* __restrict__ q_hm, u16* __restrict__ do_hm) {
+  if ((int)blockIdx.x < n_prep) attn_bwd_prep_block((int)blockIdx.x, (int)blockIdx.y, o, d_o, bstride, ld, delta, heads, nq, lse, row_slot, rowc, n_qtiles,
+                                                    qsrc, q_bstride, q_ld, q_hm, do_hm);
   else attn_dvmean_block((int)blockIdx.x - n_prep, (int)blockIdx.y, d_o, bstride, ld, lse, dvmean, heads, nq, inv_nk);
 }
 extern "C" int mca_attn_bwd_prep(const uint16_t* o, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld,
@@ -770,17 +782,21 @@ extern "C" int mca_attn_bwd_prep(const uint16_t* o, const uint16_t* d_o, int64_t
   if (heads > 65535 || batch > 65535) return MCA_E_UNSUPPORTED;
   const int n_prep = (nq + PREP_ROWS - 1) / PREP_ROWS;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(n_prep + heads, batch), dim3(256), 0, as_stream(stream), o, d_o, o_bstride, o_ld, lse, delta,
-                     dvmean, heads, nq, 1.f / (float)nk, n_prep, (const int32_t*)nullptr, (float*)nullptr, 0);
+                     dvmean, heads, nq, 1.f / (float)nk, n_prep, (const int32_t*)nullptr, (float*)nullptr, 0, (const u16*)nullptr, (int64_t)0, (int64_t)0,
+                     (u16*)nullptr, (u16*)nullptr);
   return launch_status();
 }
 extern "C" int mca_attn_bwd_prep_onepass(const uint16_t* o, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld, const float* lse,
                                          const int32_t* row_slot, float* rowc, float* dvmean, int batch, int heads, int n, int n_qtiles,
+                                         const uint16_t* q, int64_t q_bstride, int64_t q_ld, uint16_t* q_hm, uint16_t* do_hm,
                                          mca_stream_t stream) {
   if (!o || !d_o || !lse || !row_slot || !rowc || !dvmean || batch <= 0 || heads <= 0 || n <= 0 || n_qtiles <= 0) return MCA_E_BADARG;
+  if ((q_hm != nullptr) != (do_hm != nullptr) || (q_hm && !q)) return MCA_E_BADARG;
+  if (q_hm && (q_ld % 8 || q_bstride % 8 || (uintptr_t)q % 16 || (uintptr_t)q_hm % 16 || (uintptr_t)do_hm % 16)) return MCA_E_ALIGN;
   if (o_ld % 8 || o_bstride % 8 || (uintptr_t)o % 16 || (uintptr_t)d_o % 16) return MCA_E_ALIGN;
   if (heads > 65535 || batch > 65535) return MCA_E_UNSUPPORTED;
   const int n_prep = (n + PREP_ROWS - 1) / PREP_ROWS;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(n_prep + heads, batch), dim3(256), 0, as_stream(stream), o, d_o, o_bstride, o_ld, lse, (float*)nullptr,
-                     dvmean, heads, n, 1.f / (float)n, n_prep, row_slot, rowc, n_qtiles);
+                     dvmean, heads, n, 1.f / (float)n, n_prep, row_slot, rowc, n_qtiles, q, q_bstride, q_ld, q_hm, do_hm);
   return launch_status();
 }

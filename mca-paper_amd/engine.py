@@ -573,13 +573,17 @@ class FusionEngine:
             rc[:, :, :, 0] = float("-inf"); rc[:, :, :, 1] = 0.0
             ws["rowc"] = rc
             ws["dq_acc"] = torch.empty(b * self.H * sc.n_qt * 4096, dtype=torch.float32, device=self.device)
+            # head-major packed copies of q and dO (written by the prep launch): a query tile of a head is contiguous memory
+            ws["q_hm"] = torch.empty(b * self.H * N * 64, dtype=torch.bfloat16, device=self.device)
+            ws["do_hm"] = torch.empty(b * self.H * N * 64, dtype=torch.bfloat16, device=self.device)
         call("mca_attn_bwd_prep_onepass", o.data_ptr(), d_o.data_ptr(), N * o.stride(0), o.stride(0), lse.data_ptr(), sc.row_slot.data_ptr(),
-             ws["rowc"].data_ptr(), ws["dvmean"].data_ptr(), b, self.H, N, sc.n_qt, stream_ptr())
+             ws["rowc"].data_ptr(), ws["dvmean"].data_ptr(), b, self.H, N, sc.n_qt, q, q_bstride, q_ld, ws["q_hm"].data_ptr(),
+             ws["do_hm"].data_ptr(), stream_ptr())
         a = AttnBwd1Args()
-        a.q, a.q_bstride, a.q_ld = q, q_bstride, q_ld
+        a.q, a.q_bstride, a.q_hstride, a.q_ld = ws["q_hm"].data_ptr(), self.H * N * 64, N * 64, 64
         a.k, a.v = kv.data_ptr() + k_off * esz, kv.data_ptr() + v_off * esz
         a.kv_bstride, a.kv_ld = N * kv_ld, kv_ld
-        a.d_o, a.o_bstride, a.o_ld = d_o.data_ptr(), N * d_o.stride(0), d_o.stride(0)
+        a.d_o, a.o_bstride, a.o_hstride, a.o_ld = ws["do_hm"].data_ptr(), self.H * N * 64, N * 64, 64
         a.rowc, a.dvmean = ws["rowc"].data_ptr(), ws["dvmean"].data_ptr()
         a.dq, a.dq_bstride, a.dq_ld = dq_ptr, dq_bstride, dq_ld
         a.dk, a.dv = dkv.data_ptr() + dk_off * esz, dkv.data_ptr() + dv_off * esz

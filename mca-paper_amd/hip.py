@@ -104,6 +104,7 @@ class AttnBwd1Args(C.Structure):
         ("q", C.c_void_p), ("q_bstride", C.c_int64), ("q_ld", C.c_int64),
         ("k", C.c_void_p), ("v", C.c_void_p), ("kv_bstride", C.c_int64), ("kv_ld", C.c_int64),
         ("d_o", C.c_void_p), ("o_bstride", C.c_int64), ("o_ld", C.c_int64),
+        ("q_hstride", C.c_int64), ("o_hstride", C.c_int64),
         ("rowc", C.c_void_p), ("dvmean", C.c_void_p),
         ("dq", C.c_void_p), ("dq_bstride", C.c_int64), ("dq_ld", C.c_int64),
         ("dk", C.c_void_p), ("dv", C.c_void_p), ("dkv_bstride", C.c_int64), ("dkv_ld", C.c_int64),
@@ -153,7 +154,7 @@ SIGNATURES = {
     "mca_attn_fwd_fp8": (_I, [C.POINTER(AttnFwdArgs), C.POINTER(AttnFp8Operands), _P]),
     "mca_attn_bwd_prep": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mca_attn_bwd_onepass": (_I, [C.POINTER(AttnBwd1Args), _P]),
-    "mca_attn_bwd_prep_onepass": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "mca_attn_bwd_prep_onepass": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I64, _I64, _P, _P, _P]),
     "mca_attn_bwd_dq": (_I, [C.POINTER(AttnBwd2Args), _P]),
     "mca_attn_bwd_dkv": (_I, [C.POINTER(AttnBwd2Args), _P]),
     "mca_attn_quant_bwd_mxfp8": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _P, _I64, _I64, C.POINTER(AttnFp8BwdOperands), _I, _I, _I, _I, _P]),

@@ -200,10 +200,14 @@ def _cut_runs(runs, cap: int):
     return pieces
 
 
-def build_onepass_schedule(qmask: np.ndarray, kgroup: np.ndarray, tq: int = 64, tk: int = 256, aligned: bool = True) -> OnePassSchedule:
+def build_onepass_schedule(qmask: np.ndarray, kgroup: np.ndarray, tq: int = 64, tk: int = 256, aligned: bool = True,
+                           serpentine: bool = True) -> OnePassSchedule:
     """Query tiles of at most ``tq`` rows and key blocks of at most ``tk`` keys.  aligned: both are cut ALONG the structure (a
     modality's 1,500 tokens become 24 query tiles of 62-63 rows and 6 key blocks of 250 keys: no tile straddles two modalities,
-    CMU: 193 steps of 64 x 256 per (sample, head) against 210 on the plain grid); else the plain grid."""
+    CMU: 193 steps of 64 x 256 per (sample, head) against 210 on the plain grid); else the plain grid.
+    serpentine: every other key block walks its query tiles in descending order, so the tiles a sweep ends on are the ones the next
+    sweep starts with: their Q / dO rows and dQ partials are re-used at a short distance (L2 / Infinity Cache instead of HBM;
+    the order of a block's list is free: a tile's first / last visit is decided per key block)."""
     n = len(qmask)
     assert len(kgroup) == n, "self-attention only"
     if aligned:
@@ -221,11 +225,13 @@ def build_onepass_schedule(qmask: np.ndarray, kgroup: np.ndarray, tq: int = 64, 
     kb_desc, kb_qt = [], []
     for ki, (k0, kn) in enumerate(kbs):
         first = len(kb_qt)
+        ent = []
         for qi, (q0, qn) in enumerate(qts):
             blk = allowed[q0:q0 + qn, k0:k0 + kn]
             if blk.any():
                 visit[ki, qi] = 1
-                kb_qt.append(np.uint32(qi) | (np.uint32(1 << 31) if blk.all() else np.uint32(0)))
+                ent.append(np.uint32(qi) | (np.uint32(1 << 31) if blk.all() else np.uint32(0)))
+        kb_qt.extend(ent[::-1] if (serpentine and ki % 2 == 1) else ent)
         kb_desc.append((k0, kn, first, len(kb_qt) - first))
     row_slot = np.zeros(n, np.int32)
     for qi, (q0, qn) in enumerate(qts):

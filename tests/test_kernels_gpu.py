@@ -659,10 +659,13 @@ def _run_onepass(H, sc, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean_ref, keyin
     rowc = torch.empty(b, heads, nqt + 1, 2, 64, device=dev)          # (+ the null tile)
     rowc[:, :, :, 0] = float("-inf"); rowc[:, :, :, 1] = 0.0
     dvmean = torch.full_like(dvmean_ref, 3.0)
+    q_hm = torch.zeros(b, heads, N, 64, dtype=torch.bfloat16, device=dev); do_hm = torch.zeros_like(q_hm)
     H.call("mca_attn_bwd_prep_onepass", o.data_ptr(), d_o.data_ptr(), N * D, D, lse.data_ptr(), row_slot.data_ptr(), rowc.data_ptr(),
-           dvmean.data_ptr(), b, heads, N, nqt, H.stream_ptr())
+           dvmean.data_ptr(), b, heads, N, nqt, qkv.data_ptr(), N * 3 * D, 3 * D, q_hm.data_ptr(), do_hm.data_ptr(), H.stream_ptr())
     torch.cuda.synchronize()
     assert torch.equal(dvmean, dvmean_ref)
+    # the head-major packed copies, bit for bit
+    assert torch.equal(q_hm, qkv[:, :, :D].view(b, N, heads, 64).permute(0, 2, 1, 3)) and torch.equal(do_hm, d_o.view(b, N, heads, 64).permute(0, 2, 1, 3))
     # the row constants, tile by tile
     delta_ref = (d_o.float() * o.float().view(b, N, D)).view(b, N, heads, 64).sum(-1).permute(0, 2, 1)          # (b, h, N)
     for t, (r0, rn) in enumerate(sc.qt_desc.tolist()):
@@ -672,13 +675,17 @@ def _run_onepass(H, sc, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean_ref, keyin
     assert torch.isinf(rowc[:, :, nqt, 0]).all() and (rowc[:, :, nqt, 1] == 0).all()
     acc = torch.full((b * heads * nqt * 4096,), float("nan"), device=dev)          # contents irrelevant on entry
     out = []
-    for _ in range(2):
+    for rep_i in range(2):          # first launch: q / dO from the (b, n, heads*64) matrices; second: from the packed copies (same bits)
         dq = torch.full((b, N, D), 7.0, device=dev, dtype=torch.bfloat16)
         dkv = torch.zeros(b, N, 3 * D, dtype=torch.bfloat16, device=dev)
         a1 = H.AttnBwd1Args()
-        a1.q, a1.q_bstride, a1.q_ld = qkv.data_ptr(), N * 3 * D, 3 * D
         a1.k, a1.v, a1.kv_bstride, a1.kv_ld = qkv.data_ptr() + D * 2, qkv.data_ptr() + 2 * D * 2, N * 3 * D, 3 * D
-        a1.d_o, a1.o_bstride, a1.o_ld = d_o.data_ptr(), N * D, D
+        if rep_i == 0:
+            a1.q, a1.q_bstride, a1.q_ld = qkv.data_ptr(), N * 3 * D, 3 * D
+            a1.d_o, a1.o_bstride, a1.o_ld = d_o.data_ptr(), N * D, D
+        else:
+            a1.q, a1.q_bstride, a1.q_hstride, a1.q_ld = q_hm.data_ptr(), heads * N * 64, N * 64, 64
+            a1.d_o, a1.o_bstride, a1.o_hstride, a1.o_ld = do_hm.data_ptr(), heads * N * 64, N * 64, 64
         a1.rowc, a1.dvmean = rowc.data_ptr(), dvmean.data_ptr()
         a1.dq, a1.dq_bstride, a1.dq_ld = dq.data_ptr(), N * D, D
         a1.dk, a1.dv, a1.dkv_bstride, a1.dkv_ld = dkv.data_ptr() + D * 2, dkv.data_ptr() + 2 * D * 2, N * 3 * D, 3 * D
