@@ -88,7 +88,7 @@ class GpuStateSampler:
 MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic GFLOP per sample per step, mask-aware, 2 flop/MAC, bwd = 2 x fwd
 STEP_GFLOP = {"cmu_mca": 334.8, "cmu_mma": 337.4, "long_mca": 885.7}
-PMC_JSON = os.path.join("profiles", "r04_hbm_traffic_pmc.json")
+PMC_JSON = os.path.join("profiles", "r05_hbm_traffic_pmc.json")
 
 
 def pmc_traffic(kernel_key: str):
@@ -99,7 +99,7 @@ def pmc_traffic(kernel_key: str):
     path = os.path.join(REPO, PMC_JSON)
     names = {"mca_gemm_nt": "gemm_nt_", "mca_gemm_tn_acc": "gemm_tn_", "mca_gemm_tn_acc_group": "gemm_tn_256x256_group_kernel",
              "mca_attn_fwd/layer": "attn_fwd_kernel", "mca_attn_bwd_dkv/layer": "attn_bwd_dkv_kernel",
-             "mca_attn_bwd_dq/layer": "attn_bwd_dq_kernel", "mca_gemm_nt_geglu_fwd": "gemm_nt_persist256_kernel<true>",
+             "mca_attn_bwd_dq/layer": "attn_bwd_dq_kernel", "mca_attn_bwd_onepass/layer": "attn_bwd1p_kernel", "mca_gemm_nt_geglu_fwd": "gemm_nt_persist256_kernel<true>",
              "mca_gemm_nt_geglu_bwd": "gemm_nt_persist_kernel<3", "mca_gemm_nt_lnres": "gemm_nt_256_kernel<false, 1, 1, 2>"}
     if not os.path.exists(path) or kernel_key not in names:
         return None
@@ -336,7 +336,7 @@ def main():
             eng.overlap_wgrad = False
         step()
         eng.overlap_wgrad = saved
-    timed = ("mca_attn_bwd_prep", "mca_attn_vmean_if_needed", "mca_attn_vmean", "mca_layernorm_fwd", "mca_layernorm_bwd", "mca_attn_fwd", "mca_attn_fwd_fp8", "mca_attn_quant_mxfp8", "mca_attn_bwd_dq", "mca_attn_bwd_dkv", "mca_attn_bwd_dq_fp8", "mca_attn_bwd_dkv_fp8", "mca_attn_quant_bwd_mxfp8", "mca_gemm_nt", "mca_gemm_nt_lnres", "mca_gemm_nt_geglu_fwd", "mca_gemm_nt_geglu_bwd",
+    timed = ("mca_attn_bwd_prep", "mca_attn_bwd_prep_onepass", "mca_attn_bwd_onepass", "mca_attn_vmean_if_needed", "mca_attn_vmean", "mca_layernorm_fwd", "mca_layernorm_bwd", "mca_attn_fwd", "mca_attn_fwd_fp8", "mca_attn_quant_mxfp8", "mca_attn_bwd_dq", "mca_attn_bwd_dkv", "mca_attn_bwd_dq_fp8", "mca_attn_bwd_dkv_fp8", "mca_attn_quant_bwd_mxfp8", "mca_gemm_nt", "mca_gemm_nt_lnres", "mca_gemm_nt_geglu_fwd", "mca_gemm_nt_geglu_bwd",
              "mca_gemm_tn_acc", "mca_gemm_tn_acc_group")
     kernel_timing = not args.no_kernel_timing
     if graphed is not None and kernel_timing:

@@ -350,7 +350,9 @@ int mca_attn_bwd_onepass(const mca_attn_bwd1_args* args, mca_stream_t stream);
 /* mca_attn_bwd_prep for the one-pass form: rowc in tile order (row_slot[q] = tile * 64 + position) instead of delta; dvmean as
  * mca_attn_bwd_prep.  Optional (q_hm and do_hm both or neither): head-major packed copies q_hm / do_hm [batch][heads][n][64] of
  * q (read with q_bstride / q_ld) and d_o - the one-pass kernel then reads a 64-row tile of a head as 8 KiB of contiguous memory
- * (pass them as its q / d_o with q_bstride = heads*n*64, q_hstride = n*64, q_ld = 64).                                   */
+ * (pass them as its q / d_o with q_bstride = heads*n*64, q_hstride = n*64, q_ld = 64: the form the pipelined kernel takes; other
+ * strides run the plain form of the same algorithm).  Both buffers need 64 rows (8 KiB) of readable slack behind the last row:
+ * the kernel reads whole 64-row tiles.                                                                                    */
 int mca_attn_bwd_prep_onepass(const uint16_t* o, const uint16_t* d_o, int64_t o_bstride, int64_t o_ld, const float* lse,
                               const int32_t* row_slot, float* rowc, float* dvmean, int batch, int heads, int n, int n_qtiles,
                               const uint16_t* q, int64_t q_bstride, int64_t q_ld, uint16_t* q_hm, uint16_t* do_hm,

@@ -455,8 +455,8 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
   u16* stage_s = lds;                                             // B1P_NST stages
   u16* kimg = stage_s + B1P_NST * B1_STAGE_U16;
   u16* dsimg = kimg + TKB * DH;
-  uint32_t* list_s = reinterpret_cast<uint32_t*>(dsimg + 2 * TKB * TQ);
-  int2* qtd_s = reinterpret_cast<int2*>(list_s + B1_MAX_LIST);            // query tile table {first row, rows}
+  int2* meta_s = reinterpret_cast<int2*>(dsimg + 2 * TKB * TQ);           // the key block's steps: {tile | (1 first, 2 last visit) << 16 | rows << 20, first row}
+  int2* qtd_s = reinterpret_cast<int2*>(meta_s + B1_MAX_LIST);            // query tile table {first row, rows}
   uint8_t* first_s = reinterpret_cast<uint8_t*>(qtd_s + B1_MAX_QT);
   uint8_t* last_s = first_s + B1_MAX_QT;
   uint8_t* live_s = last_s + B1_MAX_QT;
@@ -512,12 +512,18 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     const int4 kd = reinterpret_cast<const int4*>(a.kb_desc)[kbi];
     const int key_start = __builtin_amdgcn_readfirstlane(kd.x), n_keys = __builtin_amdgcn_readfirstlane(kd.y);
     const int e_begin = __builtin_amdgcn_readfirstlane(kd.z), n_ent = __builtin_amdgcn_readfirstlane(kd.w);
-    for (int i = tid; i < n_ent; i += 256) list_s[i] = a.kb_qt[e_begin + i];
     // the NULL step(s): tile n_qtiles = {row 0, one row}, row constants -inf | 0.  One ends every sweep (the loop is rotated: it
     // finishes the last real step); a second one makes the iteration count even (the loop is unrolled by two: no remainder copy
     // of the body, at whose seams hipcc moved accumulators right ahead of the MFMAs that read them)
-    if (tid < 2) list_s[n_ent + tid] = (uint32_t)a.n_qtiles;
     const int n_it = (n_ent + 2) & ~1;
+    // per-step records (one 16-byte LDS read per iteration, issued ahead of the barrier's own lgkmcnt(0) and carried in scalar
+    // registers from then on: separate reads of the list, the tile table and the visit flags each drained the LDS queue - with
+    // every fragment prefetch in it - four times per iteration)
+    for (int i = tid; i < n_it; i += 256) {
+      const int qt = i < n_ent ? (int)(a.kb_qt[e_begin + i] & 0x7fffffffu) : a.n_qtiles;
+      const int2 qd = qtd_s[qt];
+      meta_s[i] = make_int2(qt | (((int)first_s[qt] == kbi ? 1 : 0) << 16) | (((int)last_s[qt] == kbi ? 2 : 0) << 16) | (qd.y << 20), qd.x);
+    }
 
     bf16x8 kf[2][4], vf[2][4], khf[2];
     bool ok[2];
@@ -568,24 +574,21 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
 
     // ---- staging of one step: five 1-KiB / 256-byte pieces per wavefront (Q and dO rows 16 w .. 16 w + 15, and one of: -lse, -delta,
     // the two halves of the mask operand): every wavefront's vmcnt sees the same count
-    auto issue = [&](uint32_t ent, int st) {
-      const int qt = __builtin_amdgcn_readfirstlane((int)(ent & 0x7fffffffu));          // (provably wave-uniform: an "s" operand below)
-      const int2 qd = qtd_s[qt];
-      const int row0 = __builtin_amdgcn_readfirstlane(qd.x), nrows = __builtin_amdgcn_readfirstlane(qd.y);
+    // per-lane byte offsets of this wavefront's two Q / dO pieces inside a tile (row 8 p + lane / 8, swizzled 16-byte chunk): the
+    // packed copies are read WITHOUT clamping to the tile's rows (rows past them belong to the next tile or to the 63 rows of
+    // slack behind the buffer: finite values behind row constants of -inf)
+    auto issue = [&](int qt, int row0, int nrows, int st) {          // qt, row0, nrows: wave-uniform (scalar registers)
       const unsigned sb_ = lds_b + (unsigned)st * STAGE_B;
-      // wave-uniform 64-bit bases + 32-bit per-lane byte offsets, all derived from the lane id HERE (hoisted out of the loop they
-      // were ten more registers to spill)
-      int ln = lane;
+      const u16* qrow = qbase + (int64_t)row0 * DH;
+      const u16* orow = obase + (int64_t)row0 * DH;
+      int ln = lane;          // (offsets derived from the lane id HERE: hoisted out of the loop they were registers to spill)
       asm volatile("" : "+v"(ln));
-      const int r8 = ln >> 3;
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        const int p = wave * 2 + u, r = p * 8 + r8;
-        const int row = row0 + (r < nrows ? r : nrows - 1);
-        const unsigned sw = (unsigned)(((ln & 7) ^ b1_swz(r)) << 4);
-        // (knob 9 bit 1024, timing only: the same bytes from contiguous 128-byte rows instead of rows q_ld apart)
-        B1_DMA16(qbase, (unsigned)row * ((dbg & 1024) ? 128u : (unsigned)(a.q_ld * 2)) + sw, sb_ + (unsigned)p * 1024u);
-        B1_DMA16(obase, (unsigned)row * ((dbg & 1024) ? 128u : (unsigned)(a.o_ld * 2)) + sw, sb_ + 8192u + (unsigned)p * 1024u);
+        const int r = (wave * 2 + u) * 8 + (ln >> 3);
+        const unsigned o_dma = (unsigned)(r * 128 + (((ln & 7) ^ b1_swz(r)) << 4));
+        B1_DMA16(qrow, o_dma, sb_ + (unsigned)(wave * 2 + u) * 1024u);
+        B1_DMA16(orow, o_dma, sb_ + 8192u + (unsigned)(wave * 2 + u) * 1024u);
       }
       if (wave < 2) {
         const float* rb = rowc_g + (int64_t)qt * 128 + wave * 64;
@@ -597,7 +600,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       }
     };
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();          // list_s visible; every wavefront is past the previous block
+    __builtin_amdgcn_s_barrier();          // meta_s visible; every wavefront is past the previous block
 
     // ---- pipeline state
     // (the dQ accumulators of two steps are the owned registers a[224:255]: buffer s & 1 receives the OLD partial of step s's tile
@@ -638,8 +641,15 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     // counted waits: vm_n = vector-memory operations issued so far in this block; a wait "for everything up to mark m" lets the
     // vm_n - m younger operations stay in flight (rounded down to an immediate the switch below knows: stricter is always safe)
     int vm_n = 0, mark_dma = 0, mark_ld[2] = {0, 0};
-    int prev_qt = 0, cur_qt = 0;
-    bool prev_first = false, prev_last = false;
+    // records of steps it + 1, it, it - 1, in scalar registers
+#define M_QT(M) ((M).x & 0xffff)
+#define M_FIRST(M) (((M).x >> 16) & 1)
+#define M_LAST(M) (((M).x >> 17) & 1)
+#define M_ROWS(M) ((int)((unsigned)(M).x >> 20))
+#define M_ROW0(M) ((M).y)
+    int2 m1 = meta_s[1], m0 = meta_s[0], mp = make_int2(1 << 16 | 1 << 20, 0);
+    m1 = make_int2(__builtin_amdgcn_readfirstlane(m1.x), __builtin_amdgcn_readfirstlane(m1.y));
+    m0 = make_int2(__builtin_amdgcn_readfirstlane(m0.x), __builtin_amdgcn_readfirstlane(m0.y));
 #define VM_WAIT(YOUNGER) do { const int y_ = (YOUNGER);                                                                   \
                               if (y_ >= 26) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");                               \
                               else if (y_ >= 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");                          \
@@ -651,10 +661,9 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     // the old dQ partial of step s's tile -> accumulator buffer BUF = s & 1.  Always four loads: the kernel's counts then do not
     // depend on the tile.  A first visit has no partial: it re-reads the slot the previous step stored (cached; the value is never
     // used - the first product of a first visit starts from the constant 0, DQM).
-    auto acc_load = [&]<int BUF>(int s_idx, int& mark) __attribute__((always_inline)) {
-      const int qt = (int)(__builtin_amdgcn_readfirstlane(list_s[s_idx]) & 0x7fffffffu);
-      const bool first = __builtin_amdgcn_readfirstlane((int)first_s[qt]) == kbi || (dbg & 128);
-      b1_acc_load<BUF>(acc_g + (int64_t)(first ? prev_qt : qt) * (TQ * DH));
+    auto acc_load = [&]<int BUF>(const int2& m, int dummy_qt, int& mark) __attribute__((always_inline)) {
+      const bool first = M_FIRST(m) || (dbg & 128);
+      b1_acc_load<BUF>(acc_g + (int64_t)(first ? dummy_qt : M_QT(m)) * (TQ * DH));
       vm_n += 4;
       mark = vm_n;
     };
@@ -678,7 +687,8 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       unsigned n_off = st_n - st_c;          // (wave-uniform: the next stage's same addresses)
       asm volatile("" : "+s"(n_off));
       asm volatile("" : "+v"(ods[0]), "+v"(ods[1]));          // (opaque: the sixteen xor-ed variants are recomputed, not hoisted and spilled)
-      const uint32_t ent2 = has_next2 ? list_s[it + 2] : 0u;
+      const int2 m2v = meta_s[has_next2 ? it + 2 : it];          // (read here, ahead of the barrier's lgkmcnt(0); made scalar behind it)
+      const bool prev_first = M_FIRST(mp) || (dbg & 128) || it == 0, prev_last = M_LAST(mp) != 0;
       asm volatile("s_nop 1" ::: "memory");          // register copies of the loop's back edge before the first MFMA reads them
       B1_SB();
 
@@ -725,7 +735,10 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       // the barrier: this wavefront's dS^T stores are done (lgkmcnt) and its pieces of the NEXT step's stage have landed
 #define BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); VM_WAIT(vm_n - mark_dma);                  \
                        __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-#define ISSUE() do { mark_dma = vm_n; if (has_next2 && !(dbg & 512)) { issue(ent2, (it + 2) % B1P_NST); vm_n += 5; mark_dma = vm_n; } } while (0)
+#define ISSUE() do { mark_dma = vm_n; if (has_next2 && !(dbg & 512)) {                                                              \
+                       const int2 m2s_ = make_int2(__builtin_amdgcn_readfirstlane(m2v.x), __builtin_amdgcn_readfirstlane(m2v.y));   \
+                       issue(M_QT(m2s_), M_ROW0(m2s_), M_ROWS(m2s_), (it + 2) % B1P_NST);                                            \
+                       vm_n += 5; mark_dma = vm_n; } } while (0)
 #include "attention_bwd1_sched.inc"
 #undef A_M
 #undef A_S
@@ -763,18 +776,19 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
 #undef ISSUE
       // ---- tail: the previous step's dQ block (accumulated onto its old partial) goes out as the new partial or, on the tile's
       // last visit, as dq; the same accumulator then receives the old partial of the step after next
-      {
-        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");          // the last dQ MFMA's result before anything else reads it
-        B1_SB();
+      {          // (the last dQ MFMA sits six MFMA slots back in the stream: its result is long written)
         if (it > 0 && it <= n_ent && !(dbg & 256)) {          // (no previous step in iteration 0; a null step's product goes nowhere)
           if (prev_last) {
             float dq[16];
             b1_acc_read<PAR ^ 1>(dq);
-            const int2 qd = qtd_s[prev_qt];
-            const int r = (wave >> 1) * 32 + l31;
+            // (addresses from an opaque copy of the lane id: held across the loop they were spilled, and every reload drained vmcnt)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int r = (wave >> 1) * 32 + (ln & 31);
+            u16* dqb = a.dq + (int64_t)b * a.dq_bstride + h * DH + (wave & 1) * 32;          // (wave-uniform)
             // (a lane past the tile's rows stores to its own dq_acc slot, which nobody reads: every lane issues four stores)
-            u16* p = r < qd.y ? a.dq + (int64_t)b * a.dq_bstride + (int64_t)(qd.x + r) * a.dq_ld + h * DH + (wave & 1) * 32 + 4 * lh
-                              : reinterpret_cast<u16*>(acc_g + (int64_t)prev_qt * (TQ * DH));
+            u16* p = r < M_ROWS(mp) ? dqb + (size_t)(unsigned)((M_ROW0(mp) + r) * (int)a.dq_ld + 4 * (ln >> 5))
+                                    : reinterpret_cast<u16*>(acc_g + (int64_t)M_QT(mp) * (TQ * DH));
 #pragma unroll
             for (int g = 0; g < 4; g++) {
               uint2 pk;
@@ -782,11 +796,11 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
               pk.y = pack2bf_pk(dq[4 * g + 2] * a.scale, dq[4 * g + 3] * a.scale);
               *reinterpret_cast<uint2*>(p + 8 * g) = pk;
             }
-          } else b1_acc_store<PAR ^ 1>(acc_g + (int64_t)prev_qt * (TQ * DH));
+          } else b1_acc_store<PAR ^ 1>(acc_g + (int64_t)M_QT(mp) * (TQ * DH));
           vm_n += 4;
         }
       }
-      if (it + 1 < n_ent) acc_load.template operator()<PAR ^ 1>(it + 1, mark_ld[PAR ^ 1]);          // (the null step has no partial)
+      if (it + 1 < n_ent) acc_load.template operator()<PAR ^ 1>(m1, M_QT(m0), mark_ld[PAR ^ 1]);          // (the null step has no partial)
       {          // addresses of the next iteration
         const unsigned d_st = n_off, d_ds = ds_cur - ds_prev;          // (wave-uniform; unsigned wrap-around is the subtraction)
 #pragma unroll
@@ -795,13 +809,9 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
         for (int t = 0; t < 2; t++) { a_tr[t][0] += d_st; a_tr[t][1] += d_st; a_db[t] += d_ds; }
         a_rc += d_st; a_qb += d_st;
       }
-      {
-        const int qt = (int)(__builtin_amdgcn_readfirstlane(list_s[it]) & 0x7fffffffu);
-        prev_qt = qt;
-        prev_first = __builtin_amdgcn_readfirstlane((int)first_s[qt]) == kbi || (dbg & 128);
-        prev_last = __builtin_amdgcn_readfirstlane((int)last_s[qt]) == kbi;
-        cur_qt = qt;
-      }
+      // the records move on: step it + 2's becomes step it + 1's, ...
+      mp = m0; m0 = m1;
+      m1 = make_int2(__builtin_amdgcn_readfirstlane(m2v.x), __builtin_amdgcn_readfirstlane(m2v.y));
       B1_SB();
     };
 
@@ -809,9 +819,9 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     // Order: the partial's loads are OLDER than stage 1's pieces, so the one wait below covers them: an inline-asm load's
     // registers count as written for hipcc as soon as the statement ends - it copied them into the loop's registers at the loop
     // entry, before the data had landed, and the data then landed in registers that held something else by then.
-    acc_load.template operator()<0>(0, mark_ld[0]);
-    issue(list_s[0], 0);          // (n_it >= 2: a key block has at least one real step and the null step)
-    issue(list_s[1], 1);
+    acc_load.template operator()<0>(m0, 0, mark_ld[0]);
+    issue(M_QT(m0), M_ROW0(m0), M_ROWS(m0), 0);          // (n_it >= 2: a key block has at least one real step and the null step)
+    issue(M_QT(m1), M_ROW0(m1), M_ROWS(m1), 1);
     asm volatile("s_waitcnt vmcnt(5)" ::: "memory");          // (only stage 1's five pieces stay in flight)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -842,7 +852,6 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
 #pragma unroll
           for (int e = 0; e < 8; e++) { trO[i][j][e] = 0; trQ[i][j][e] = 0; }
     }
-    prev_qt = 0; prev_first = true; prev_last = false;
     // iterations 0 .. n_it - 1 (n_it even), parity of `it` as a template argument
     if (!wave_dead) {
       for (int it = 0; it < n_it; it += 2) { iter.template operator()<true, 0>(it); iter.template operator()<true, 1>(it + 1); }
@@ -873,8 +882,9 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
           *reinterpret_cast<uint2*>(dvp + d) = pk;
         }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();          // every wavefront is done with the K image, the list and the stages
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the block's dK / dV and dQ stores stay in flight)
+    __builtin_amdgcn_s_barrier();          // every wavefront is done with the K image, the records and the stages
+    asm volatile("" ::: "memory");
   }
   for (int kbi = 0; kbi < a.n_kblocks; kbi++) {          // key blocks without a valid key in this sample: dK = 0, dV = dvmean
     if (live_s[kbi]) continue;
@@ -893,7 +903,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd1p_kernel(mca_attn_bwd1_args a
   extern __shared__ __attribute__((aligned(16))) u16 lds_dyn[];
   attn_bwd1p_body(a, dbg, lds_dyn);
 }
-#define B1P_LDS_BYTES ((B1P_NST * B1_STAGE_U16 + TKB * DH + 2 * TKB * TQ) * 2 + B1_MAX_LIST * 4 + B1_MAX_QT * 8 + 2 * B1_MAX_QT + B1_MAX_KB + DH * 4)
+#define B1P_LDS_BYTES ((B1P_NST * B1_STAGE_U16 + TKB * DH + 2 * TKB * TQ) * 2 + B1_MAX_LIST * 8 + B1_MAX_QT * 8 + 2 * B1_MAX_QT + B1_MAX_KB + DH * 4)
 
 #define B1_LDS_BYTES ((B1_NST * B1_STAGE_U16 + TKB * DH + 2 * TKB * TQ) * 2 + B1_MAX_LIST * 4 + 2 * B1_MAX_QT + B1_MAX_KB + DH * 4)
 
@@ -918,7 +928,9 @@ extern "C" int mca_attn_bwd_onepass(const mca_attn_bwd1_args* a, mca_stream_t st
     *done = true;
   }
   // knob 9 bit 64: the plain (compiler-scheduled) form of the same algorithm instead of the pipelined one (A/B and cross-check)
-  if (mca_knobs[9] & 64) hipLaunchKernelGGL(attn_bwd1_kernel, dim3(a->batch * a->heads), dim3(256), B1_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
+  // the pipelined kernel reads q / dO from the head-major packed copies only (64-element rows: a tile is 8 KiB contiguous)
+  const bool packed = a->q_ld == DH && a->o_ld == DH && a->q_hstride && a->o_hstride;
+  if ((mca_knobs[9] & 64) || !packed) hipLaunchKernelGGL(attn_bwd1_kernel, dim3(a->batch * a->heads), dim3(256), B1_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
   else hipLaunchKernelGGL(attn_bwd1p_kernel, dim3(a->batch * a->heads), dim3(256), B1P_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
   return launch_status();
 }

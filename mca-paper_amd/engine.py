@@ -574,8 +574,9 @@ class FusionEngine:
             ws["rowc"] = rc
             ws["dq_acc"] = torch.empty(b * self.H * sc.n_qt * 4096, dtype=torch.float32, device=self.device)
             # head-major packed copies of q and dO (written by the prep launch): a query tile of a head is contiguous memory
-            ws["q_hm"] = torch.empty(b * self.H * N * 64, dtype=torch.bfloat16, device=self.device)
-            ws["do_hm"] = torch.empty(b * self.H * N * 64, dtype=torch.bfloat16, device=self.device)
+            # (+ 64 rows: the kernel reads whole 64-row tiles, the last one past its rows)
+            ws["q_hm"] = torch.zeros((b * self.H * N + 64) * 64, dtype=torch.bfloat16, device=self.device)
+            ws["do_hm"] = torch.zeros((b * self.H * N + 64) * 64, dtype=torch.bfloat16, device=self.device)
         call("mca_attn_bwd_prep_onepass", o.data_ptr(), d_o.data_ptr(), N * o.stride(0), o.stride(0), lse.data_ptr(), sc.row_slot.data_ptr(),
              ws["rowc"].data_ptr(), ws["dvmean"].data_ptr(), b, self.H, N, sc.n_qt, q, q_bstride, q_ld, ws["q_hm"].data_ptr(),
              ws["do_hm"].data_ptr(), stream_ptr())

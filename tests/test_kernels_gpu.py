@@ -659,7 +659,9 @@ def _run_onepass(H, sc, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean_ref, keyin
     rowc = torch.empty(b, heads, nqt + 1, 2, 64, device=dev)          # (+ the null tile)
     rowc[:, :, :, 0] = float("-inf"); rowc[:, :, :, 1] = 0.0
     dvmean = torch.full_like(dvmean_ref, 3.0)
-    q_hm = torch.zeros(b, heads, N, 64, dtype=torch.bfloat16, device=dev); do_hm = torch.zeros_like(q_hm)
+    # (+ 64 rows of slack: the kernel reads whole 64-row tiles of the packed copies, the last one past its rows)
+    q_buf = torch.zeros((b * heads * N + 64) * 64, dtype=torch.bfloat16, device=dev); do_buf = torch.zeros_like(q_buf)
+    q_hm, do_hm = q_buf[:b * heads * N * 64].view(b, heads, N, 64), do_buf[:b * heads * N * 64].view(b, heads, N, 64)
     H.call("mca_attn_bwd_prep_onepass", o.data_ptr(), d_o.data_ptr(), N * D, D, lse.data_ptr(), row_slot.data_ptr(), rowc.data_ptr(),
            dvmean.data_ptr(), b, heads, N, nqt, qkv.data_ptr(), N * 3 * D, 3 * D, q_hm.data_ptr(), do_hm.data_ptr(), H.stream_ptr())
     torch.cuda.synchronize()

@@ -51,8 +51,18 @@ def cname(j, w, sp, n):
     return f"CP_{w}({j}, {sp}, {n})" if j >= 2 else f"C_{w}({j}, {sp}, {n})"
 
 
+DQ_END_GAP = 6         # MFMA slots behind the last dQ' MFMA: its result is stored right behind the stream (12 wait states, without nops)
+
+
 def spread_from(main, extra, start):
-    """the items of `extra` spread evenly through main[start:]"""
+    """the items of `extra` spread evenly through main[start:len(main) - DQ_END_GAP] (the rest of main follows)"""
+    keep = main[len(main) - DQ_END_GAP:]
+    main = main[:len(main) - DQ_END_GAP]
+    out = _spread_from(main, extra, start)
+    return out + keep
+
+
+def _spread_from(main, extra, start):
     head, tail = main[:start], main[start:]
     out, n, m, e = [], len(tail), len(extra), 0
     for i, x in enumerate(tail):
