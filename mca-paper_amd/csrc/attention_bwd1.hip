@@ -387,35 +387,25 @@ __global__ __launch_bounds__(256, 1) void attn_bwd1_kernel(mca_attn_bwd1_args a,
 // Every statement that touches them names them and lists them as clobbers; tools/audit_bwd1_isa.py proves nothing else does.
 #define ACC_CLOB_0 "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239"
 #define ACC_CLOB_1 "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
-template <int BUF> __device__ __forceinline__ void b1_acc_load(const float* src) {          // four 1-KiB pieces of this lane's slot
-  if (BUF == 0) asm volatile("global_load_dwordx4 a[224:227], %0, off\n\tglobal_load_dwordx4 a[228:231], %0, off offset:1024\n\t"
-                             "global_load_dwordx4 a[232:235], %0, off offset:2048\n\tglobal_load_dwordx4 a[236:239], %0, off offset:3072"
-                             :: "v"(src) : "memory", ACC_CLOB_0);
-  else asm volatile("global_load_dwordx4 a[240:243], %0, off\n\tglobal_load_dwordx4 a[244:247], %0, off offset:1024\n\t"
-                    "global_load_dwordx4 a[248:251], %0, off offset:2048\n\tglobal_load_dwordx4 a[252:255], %0, off offset:3072"
-                    :: "v"(src) : "memory", ACC_CLOB_1);
+// one 1-KiB piece G of this wavefront's 4-KiB slot: SBASE wave-uniform (scalar registers), VOFF = 16 * lane
+template <int BUF, int G> __device__ __forceinline__ void b1_acc_load1(unsigned voff, const float* sbase) {
+#define L_(R, O) asm volatile("global_load_dwordx4 " R ", %0, %1 offset:" O :: "v"(voff), "s"(sbase) : "memory", ACC_CLOB_0, ACC_CLOB_1)
+  if (BUF == 0) { if (G == 0) L_("a[224:227]", "0"); else if (G == 1) L_("a[228:231]", "1024"); else if (G == 2) L_("a[232:235]", "2048"); else L_("a[236:239]", "3072"); }
+  else { if (G == 0) L_("a[240:243]", "0"); else if (G == 1) L_("a[244:247]", "1024"); else if (G == 2) L_("a[248:251]", "2048"); else L_("a[252:255]", "3072"); }
+#undef L_
 }
-template <int BUF> __device__ __forceinline__ void b1_acc_store(float* dst) {          // (s_nop 1: the data registers of the last store)
-  if (BUF == 0) asm volatile("global_store_dwordx4 %0, a[224:227], off\n\tglobal_store_dwordx4 %0, a[228:231], off offset:1024\n\t"
-                             "global_store_dwordx4 %0, a[232:235], off offset:2048\n\tglobal_store_dwordx4 %0, a[236:239], off offset:3072\n\ts_nop 1"
-                             :: "v"(dst) : "memory");
-  else asm volatile("global_store_dwordx4 %0, a[240:243], off\n\tglobal_store_dwordx4 %0, a[244:247], off offset:1024\n\t"
-                    "global_store_dwordx4 %0, a[248:251], off offset:2048\n\tglobal_store_dwordx4 %0, a[252:255], off offset:3072\n\ts_nop 1"
-                    :: "v"(dst) : "memory");
+template <int BUF, int G> __device__ __forceinline__ void b1_acc_store1(unsigned voff, float* sbase) {
+#define S_(R, O) asm volatile("global_store_dwordx4 %0, " R ", %1 offset:" O :: "v"(voff), "s"(sbase) : "memory")
+  if (BUF == 0) { if (G == 0) S_("a[224:227]", "0"); else if (G == 1) S_("a[228:231]", "1024"); else if (G == 2) S_("a[232:235]", "2048"); else S_("a[236:239]", "3072"); }
+  else { if (G == 0) S_("a[240:243]", "0"); else if (G == 1) S_("a[244:247]", "1024"); else if (G == 2) S_("a[248:251]", "2048"); else S_("a[252:255]", "3072"); }
+#undef S_
 }
-template <int BUF> __device__ __forceinline__ void b1_acc_read(float (&t)[16]) {
-  if (BUF == 0) asm volatile("v_accvgpr_read_b32 %0, a224\n\tv_accvgpr_read_b32 %1, a225\n\tv_accvgpr_read_b32 %2, a226\n\tv_accvgpr_read_b32 %3, a227\n\t"
-                             "v_accvgpr_read_b32 %4, a228\n\tv_accvgpr_read_b32 %5, a229\n\tv_accvgpr_read_b32 %6, a230\n\tv_accvgpr_read_b32 %7, a231\n\t"
-                             "v_accvgpr_read_b32 %8, a232\n\tv_accvgpr_read_b32 %9, a233\n\tv_accvgpr_read_b32 %10, a234\n\tv_accvgpr_read_b32 %11, a235\n\t"
-                             "v_accvgpr_read_b32 %12, a236\n\tv_accvgpr_read_b32 %13, a237\n\tv_accvgpr_read_b32 %14, a238\n\tv_accvgpr_read_b32 %15, a239"
-                             : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]),
-                               "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
-  else asm volatile("v_accvgpr_read_b32 %0, a240\n\tv_accvgpr_read_b32 %1, a241\n\tv_accvgpr_read_b32 %2, a242\n\tv_accvgpr_read_b32 %3, a243\n\t"
-                    "v_accvgpr_read_b32 %4, a244\n\tv_accvgpr_read_b32 %5, a245\n\tv_accvgpr_read_b32 %6, a246\n\tv_accvgpr_read_b32 %7, a247\n\t"
-                    "v_accvgpr_read_b32 %8, a248\n\tv_accvgpr_read_b32 %9, a249\n\tv_accvgpr_read_b32 %10, a250\n\tv_accvgpr_read_b32 %11, a251\n\t"
-                    "v_accvgpr_read_b32 %12, a252\n\tv_accvgpr_read_b32 %13, a253\n\tv_accvgpr_read_b32 %14, a254\n\tv_accvgpr_read_b32 %15, a255"
-                    : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]), "=v"(t[4]), "=v"(t[5]), "=v"(t[6]), "=v"(t[7]), "=v"(t[8]), "=v"(t[9]),
-                      "=v"(t[10]), "=v"(t[11]), "=v"(t[12]), "=v"(t[13]), "=v"(t[14]), "=v"(t[15]));
+template <int BUF, int G> __device__ __forceinline__ void b1_acc_read4(float (&t)[4]) {
+#define R_(A, B, C, D) asm volatile("v_accvgpr_read_b32 %0, " A "\n\tv_accvgpr_read_b32 %1, " B "\n\tv_accvgpr_read_b32 %2, " C "\n\tv_accvgpr_read_b32 %3, " D \
+                                    : "=v"(t[0]), "=v"(t[1]), "=v"(t[2]), "=v"(t[3]))
+  if (BUF == 0) { if (G == 0) R_("a224", "a225", "a226", "a227"); else if (G == 1) R_("a228", "a229", "a230", "a231"); else if (G == 2) R_("a232", "a233", "a234", "a235"); else R_("a236", "a237", "a238", "a239"); }
+  else { if (G == 0) R_("a240", "a241", "a242", "a243"); else if (G == 1) R_("a244", "a245", "a246", "a247"); else if (G == 2) R_("a248", "a249", "a250", "a251"); else R_("a252", "a253", "a254", "a255"); }
+#undef R_
 }
 // the dQ product's MFMAs on an owned accumulator (always padded: two per iteration carry the pad, the other fourteen do not need
 // it - their operands come from LDS reads - but one form keeps the strings few); ZERO: the first product of a tile's first visit
@@ -449,6 +439,13 @@ template <int BUF, bool ZERO, bool PAD> __device__ __forceinline__ void b1_acc_m
 #define LDS_RF4(ADDR) (*LDS_P(const f32x4, ADDR))
 #define LDS_TR(ADDR) __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_P(bf16x4, ADDR))
 
+// a step's record {tile | (1 first, 2 last visit of the tile by this (sample, head)) << 16 | rows << 20, first row}
+#define M_QT(M) ((M).x & 0xffff)
+#define M_FIRST(M) (((M).x >> 16) & 1)
+#define M_LAST(M) (((M).x >> 17) & 1)
+#define M_ROWS(M) ((int)((unsigned)(M).x >> 20))
+#define M_ROW0(M) ((M).y)
+
 // (the body is a __device__ function: the host pass of hipcc checks the register constraints of inline asm in a __global__ body
 //  against the host's register classes)
 __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, const int dbg, u16* lds) {
@@ -474,7 +471,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
   const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
   const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
   const float* rowc_g = a.rowc + bh * (int64_t)(a.n_qtiles + 1) * 128;          // (+ the null tile)
-  float* acc_g = a.dq_acc + bh * (int64_t)a.n_qtiles * (TQ * DH) + wave * 1024 + lane * 4;
+  float* acc_s = a.dq_acc + bh * (int64_t)a.n_qtiles * (TQ * DH) + wave * 1024;          // (wave-uniform; lane l's slot at + 4 l)
   const uint8_t* kinfo_g = a.keyinfo + (int64_t)b * a.nk_pad;
   const u16* khot_g = a.khot + (int64_t)b * a.nk_pad * 16;
 
@@ -577,25 +574,23 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     // per-lane byte offsets of this wavefront's two Q / dO pieces inside a tile (row 8 p + lane / 8, swizzled 16-byte chunk): the
     // packed copies are read WITHOUT clamping to the tile's rows (rows past them belong to the next tile or to the 63 rows of
     // slack behind the buffer: finite values behind row constants of -inf)
-    auto issue = [&](int qt, int row0, int nrows, int st) {          // qt, row0, nrows: wave-uniform (scalar registers)
+    // piece P of a stage: 0 / 2 the two Q pieces of this wavefront, 1 / 3 the dO pieces, 4 its share of the row constants / mask operand
+    auto dma_piece = [&]<int P>(const int2& m, int st) __attribute__((always_inline)) {          // m: the step's record (scalar registers)
       const unsigned sb_ = lds_b + (unsigned)st * STAGE_B;
-      const u16* qrow = qbase + (int64_t)row0 * DH;
-      const u16* orow = obase + (int64_t)row0 * DH;
       int ln = lane;          // (offsets derived from the lane id HERE: hoisted out of the loop they were registers to spill)
       asm volatile("" : "+v"(ln));
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
+      if (P < 4) {
+        constexpr int u = P >> 1;
+        const u16* rowp = ((P & 1) ? obase : qbase) + (int64_t)M_ROW0(m) * DH;
         const int r = (wave * 2 + u) * 8 + (ln >> 3);
         const unsigned o_dma = (unsigned)(r * 128 + (((ln & 7) ^ b1_swz(r)) << 4));
-        B1_DMA16(qrow, o_dma, sb_ + (unsigned)(wave * 2 + u) * 1024u);
-        B1_DMA16(orow, o_dma, sb_ + 8192u + (unsigned)(wave * 2 + u) * 1024u);
-      }
-      if (wave < 2) {
-        const float* rb = rowc_g + (int64_t)qt * 128 + wave * 64;
+        B1_DMA16(rowp, o_dma, sb_ + ((P & 1) ? 8192u : 0u) + (unsigned)(wave * 2 + u) * 1024u);
+      } else if (wave < 2) {
+        const float* rb = rowc_g + (int64_t)M_QT(m) * 128 + wave * 64;
         B1_DMA4(rb, (unsigned)ln * 4u, sb_ + 16384u + (unsigned)wave * 256u);
       } else {
-        const int r = (wave - 2) * 32 + (ln >> 1);
-        const int row = row0 + (r < nrows ? r : nrows - 1);
+        const int r = (wave - 2) * 32 + (ln >> 1), nrows = M_ROWS(m);
+        const int row = M_ROW0(m) + (r < nrows ? r : nrows - 1);
         B1_DMA16(a.qblk, (unsigned)row * 32u + (unsigned)(ln & 1) * 16u, sb_ + 16896u + (unsigned)(wave - 2) * 1024u);
       }
     };
@@ -641,31 +636,40 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     // counted waits: vm_n = vector-memory operations issued so far in this block; a wait "for everything up to mark m" lets the
     // vm_n - m younger operations stay in flight (rounded down to an immediate the switch below knows: stricter is always safe)
     int vm_n = 0, mark_dma = 0, mark_ld[2] = {0, 0};
-    // records of steps it + 1, it, it - 1, in scalar registers
-#define M_QT(M) ((M).x & 0xffff)
-#define M_FIRST(M) (((M).x >> 16) & 1)
-#define M_LAST(M) (((M).x >> 17) & 1)
-#define M_ROWS(M) ((int)((unsigned)(M).x >> 20))
-#define M_ROW0(M) ((M).y)
-    int2 m1 = meta_s[1], m0 = meta_s[0], mp = make_int2(1 << 16 | 1 << 20, 0);
+    // records of steps it + 1, it, it - 1, it - 2, in scalar registers
+    int2 m1 = meta_s[1], m0 = meta_s[0], mp = make_int2(1 << 16 | 1 << 20, 0), mpp = mp;
     m1 = make_int2(__builtin_amdgcn_readfirstlane(m1.x), __builtin_amdgcn_readfirstlane(m1.y));
     m0 = make_int2(__builtin_amdgcn_readfirstlane(m0.x), __builtin_amdgcn_readfirstlane(m0.y));
-#define VM_WAIT(YOUNGER) do { const int y_ = (YOUNGER);                                                                   \
-                              if (y_ >= 26) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");                               \
-                              else if (y_ >= 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");                          \
-                              else if (y_ >= 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");                          \
-                              else if (y_ >= 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");                          \
-                              else if (y_ >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                            \
-                              else if (y_ >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                            \
-                              else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
-    // the old dQ partial of step s's tile -> accumulator buffer BUF = s & 1.  Always four loads: the kernel's counts then do not
-    // depend on the tile.  A first visit has no partial: it re-reads the slot the previous step stored (cached; the value is never
-    // used - the first product of a first visit starts from the constant 0, DQM).
-    auto acc_load = [&]<int BUF>(const int2& m, int dummy_qt, int& mark) __attribute__((always_inline)) {
-      const bool first = M_FIRST(m) || (dbg & 128);
-      b1_acc_load<BUF>(acc_g + (int64_t)(first ? dummy_qt : M_QT(m)) * (TQ * DH));
-      vm_n += 4;
-      mark = vm_n;
+    // (exact counts - rounded down to a coarser set the wait for the stage also waited for stores issued moments before it - by a
+    //  computed jump into a table of {s_waitcnt vmcnt(N); s_branch end} pairs: as a C switch the structurised control flow ran
+    //  dozens of scalar branches per wait)
+#define VMW_(N) "s_waitcnt vmcnt(" #N ")\n\ts_branch 1f\n\t"
+#define VM_WAIT(YOUNGER) do { const int y_ = (YOUNGER);                                                                              \
+    asm volatile("s_min_u32 s98, %0, 30\n\ts_lshl_b32 s98, s98, 3\n\ts_getpc_b64 s[96:97]\n\ts_add_u32 s98, s98, 16\n\t"               \
+                 "s_add_u32 s96, s96, s98\n\ts_addc_u32 s97, s97, 0\n\ts_setpc_b64 s[96:97]\n\t"                                    \
+                 VMW_(0) VMW_(1) VMW_(2) VMW_(3) VMW_(4) VMW_(5) VMW_(6) VMW_(7) VMW_(8) VMW_(9) VMW_(10) VMW_(11) VMW_(12) VMW_(13)  \
+                 VMW_(14) VMW_(15) VMW_(16) VMW_(17) VMW_(18) VMW_(19) VMW_(20) VMW_(21) VMW_(22) VMW_(23) VMW_(24) VMW_(25)         \
+                 VMW_(26) VMW_(27) VMW_(28) VMW_(29) VMW_(30) "1:"                                                                   \
+                 :: "s"(y_) : "memory", "s96", "s97", "s98", "scc"); } while (0)
+    // the dQ block of a step (accumulated onto its old partial in buffer BUF) goes out, piece G: as the new partial or, on the
+    // tile's last visit, as dq
+    auto store_dq = [&]<int BUF, int G>(const int2& m) __attribute__((always_inline)) {
+      int ln = lane;          // (addresses from an opaque copy of the lane id: held across the loop they were spilled)
+      asm volatile("" : "+v"(ln));
+      float* slot = acc_s + (int64_t)M_QT(m) * (TQ * DH);
+      if (M_LAST(m)) {
+        float t[4];
+        b1_acc_read4<BUF, G>(t);
+        const int r = (wave >> 1) * 32 + (ln & 31);
+        u16* dqb = a.dq + (int64_t)b * a.dq_bstride + h * DH + (wave & 1) * 32 + 8 * G;          // (wave-uniform)
+        // (a lane past the tile's rows stores to its own dq_acc slot, which nobody reads: every lane issues the store)
+        u16* p = r < M_ROWS(m) ? dqb + (size_t)(unsigned)((M_ROW0(m) + r) * (int)a.dq_ld + 4 * (ln >> 5))
+                               : reinterpret_cast<u16*>(slot + G * 256 + ln * 4);
+        uint2 pk;
+        pk.x = pack2bf_pk(t[0] * a.scale, t[1] * a.scale);
+        pk.y = pack2bf_pk(t[2] * a.scale, t[3] * a.scale);
+        *reinterpret_cast<uint2*>(p) = pk;
+      } else b1_acc_store1<BUF, G>((unsigned)ln * 16u, slot);
     };
     // ONE loop body (every iteration, the first and the last included, runs it whole: the first on a neutral "previous step" -
     // scores of -inf, packed operands and fragments of zero: P = dS = 0 -, the last on the block's NULL step, whose row constants are
@@ -688,7 +692,10 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       asm volatile("" : "+s"(n_off));
       asm volatile("" : "+v"(ods[0]), "+v"(ods[1]));          // (opaque: the sixteen xor-ed variants are recomputed, not hoisted and spilled)
       const int2 m2v = meta_s[has_next2 ? it + 2 : it];          // (read here, ahead of the barrier's lgkmcnt(0); made scalar behind it)
-      const bool prev_first = M_FIRST(mp) || (dbg & 128) || it == 0, prev_last = M_LAST(mp) != 0;
+      const bool prev_first = M_FIRST(mp) || (dbg & 128) || it == 0;
+      const bool st_on = it >= 2 && it - 2 < n_ent && !(dbg & 256);          // step it - 2 is a real step: its dQ block goes out
+      const bool ld_on = it < n_ent && !M_FIRST(m0) && !(dbg & 128);          // step it has an old partial to accumulate onto
+      int2 m2s = m1;
       asm volatile("s_nop 1" ::: "memory");          // register copies of the loop's back edge before the first MFMA reads them
       B1_SB();
 
@@ -728,17 +735,21 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       // (the first product of a tile's first visit starts from the constant 0; behind the counted wait in either case: an unused load
       //  that lands later would overwrite the product)
 #define DQM(K) do { if (B1_ABL & 2) break;                                                                                   \
-                    if ((K) == 0) { VM_WAIT(vm_n - mark_ld[PAR ^ 1]);                                                        \
+                    if ((K) == 0) { if (!(dbg & 4096)) VM_WAIT(vm_n - mark_ld[PAR ^ 1]);                                                     \
                                     if (prev_first) b1_acc_mfma<PAR ^ 1, true, true>(da[0], db[0]);                          \
                                     else b1_acc_mfma<PAR ^ 1, false, true>(da[0], db[0]); }                                  \
                     else b1_acc_mfma<PAR ^ 1, false, !STEADY>(da[(K) & 1], db[(K) & 1]); } while (0)
       // the barrier: this wavefront's dS^T stores are done (lgkmcnt) and its pieces of the NEXT step's stage have landed
-#define BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); VM_WAIT(vm_n - mark_dma);                  \
+#define BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (!(dbg & 2048)) VM_WAIT(vm_n - mark_dma); \
                        __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-#define ISSUE() do { mark_dma = vm_n; if (has_next2 && !(dbg & 512)) {                                                              \
-                       const int2 m2s_ = make_int2(__builtin_amdgcn_readfirstlane(m2v.x), __builtin_amdgcn_readfirstlane(m2v.y));   \
-                       issue(M_QT(m2s_), M_ROW0(m2s_), M_ROWS(m2s_), (it + 2) % B1P_NST);                                            \
-                       vm_n += 5; mark_dma = vm_n; } } while (0)
+#define DMA(P) do { if ((P) == 0) { mark_dma = vm_n; m2s = make_int2(__builtin_amdgcn_readfirstlane(m2v.x), __builtin_amdgcn_readfirstlane(m2v.y)); } \
+                    if (has_next2 && !(dbg & 512)) { dma_piece.template operator()<P>(m2s, (it + 2) % B1P_NST); vm_n += 1; mark_dma = vm_n; } } while (0)
+      // the dQ block of step it - 2 (buffer PAR: its last MFMA ran six slots before the previous iteration ended), then the old
+      // partial of step it's tile into the same registers (the first product of a first visit starts from the constant 0 instead)
+#define ST(G) do { if (st_on) { store_dq.template operator()<PAR, G>(mpp); vm_n += 1; } } while (0)
+#define LD(G) do { if (ld_on) { int ln_ld = lane; asm volatile("" : "+v"(ln_ld));                                                   \
+                                b1_acc_load1<PAR, G>((unsigned)ln_ld * 16u, acc_s + (int64_t)M_QT(m0) * (TQ * DH));                   \
+                                vm_n += 1; if ((G) == 3) mark_ld[PAR] = vm_n; } } while (0)
 #include "attention_bwd1_sched.inc"
 #undef A_M
 #undef A_S
@@ -773,34 +784,9 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
 #undef DQR
 #undef DQM
 #undef BARRIER
-#undef ISSUE
-      // ---- tail: the previous step's dQ block (accumulated onto its old partial) goes out as the new partial or, on the tile's
-      // last visit, as dq; the same accumulator then receives the old partial of the step after next
-      {          // (the last dQ MFMA sits six MFMA slots back in the stream: its result is long written)
-        if (it > 0 && it <= n_ent && !(dbg & 256)) {          // (no previous step in iteration 0; a null step's product goes nowhere)
-          if (prev_last) {
-            float dq[16];
-            b1_acc_read<PAR ^ 1>(dq);
-            // (addresses from an opaque copy of the lane id: held across the loop they were spilled, and every reload drained vmcnt)
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            const int r = (wave >> 1) * 32 + (ln & 31);
-            u16* dqb = a.dq + (int64_t)b * a.dq_bstride + h * DH + (wave & 1) * 32;          // (wave-uniform)
-            // (a lane past the tile's rows stores to its own dq_acc slot, which nobody reads: every lane issues four stores)
-            u16* p = r < M_ROWS(mp) ? dqb + (size_t)(unsigned)((M_ROW0(mp) + r) * (int)a.dq_ld + 4 * (ln >> 5))
-                                    : reinterpret_cast<u16*>(acc_g + (int64_t)M_QT(mp) * (TQ * DH));
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-              uint2 pk;
-              pk.x = pack2bf_pk(dq[4 * g] * a.scale, dq[4 * g + 1] * a.scale);
-              pk.y = pack2bf_pk(dq[4 * g + 2] * a.scale, dq[4 * g + 3] * a.scale);
-              *reinterpret_cast<uint2*>(p + 8 * g) = pk;
-            }
-          } else b1_acc_store<PAR ^ 1>(acc_g + (int64_t)M_QT(mp) * (TQ * DH));
-          vm_n += 4;
-        }
-      }
-      if (it + 1 < n_ent) acc_load.template operator()<PAR ^ 1>(m1, M_QT(m0), mark_ld[PAR ^ 1]);          // (the null step has no partial)
+#undef DMA
+#undef ST
+#undef LD
       {          // addresses of the next iteration
         const unsigned d_st = n_off, d_ds = ds_cur - ds_prev;          // (wave-uniform; unsigned wrap-around is the subtraction)
 #pragma unroll
@@ -810,18 +796,15 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
         a_rc += d_st; a_qb += d_st;
       }
       // the records move on: step it + 2's becomes step it + 1's, ...
-      mp = m0; m0 = m1;
-      m1 = make_int2(__builtin_amdgcn_readfirstlane(m2v.x), __builtin_amdgcn_readfirstlane(m2v.y));
+      mpp = mp; mp = m0; m0 = m1; m1 = m2s;
       B1_SB();
     };
 
-    // (behind the lambdas that use the counters) step 0's old partial, the first two stages; K image, partial and stage 0 landed
-    // Order: the partial's loads are OLDER than stage 1's pieces, so the one wait below covers them: an inline-asm load's
-    // registers count as written for hipcc as soon as the statement ends - it copied them into the loop's registers at the loop
-    // entry, before the data had landed, and the data then landed in registers that held something else by then.
-    acc_load.template operator()<0>(m0, 0, mark_ld[0]);
-    issue(M_QT(m0), M_ROW0(m0), M_ROWS(m0), 0);          // (n_it >= 2: a key block has at least one real step and the null step)
-    issue(M_QT(m1), M_ROW0(m1), M_ROWS(m1), 1);
+    // (behind the lambdas that use the counters) the first two stages; K image and stage 0 landed
+    dma_piece.template operator()<0>(m0, 0); dma_piece.template operator()<1>(m0, 0); dma_piece.template operator()<2>(m0, 0);
+    dma_piece.template operator()<3>(m0, 0); dma_piece.template operator()<4>(m0, 0);          // (n_it >= 2: a key block has at least one real step and the null step)
+    dma_piece.template operator()<0>(m1, 1); dma_piece.template operator()<1>(m1, 1); dma_piece.template operator()<2>(m1, 1);
+    dma_piece.template operator()<3>(m1, 1); dma_piece.template operator()<4>(m1, 1);
     asm volatile("s_waitcnt vmcnt(5)" ::: "memory");          // (only stage 1's five pieces stay in flight)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -860,6 +843,11 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     }
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");          // the last dK / dV MFMAs before the epilogue reads the accumulators
     B1_SB();
+    // an odd number of steps: the last one's dQ block (buffer 0, finished by the null iteration) has no iteration left to go out in
+    if ((n_ent & 1) && !(dbg & 256)) {
+      store_dq.template operator()<0, 0>(mpp); store_dq.template operator()<0, 1>(mpp);
+      store_dq.template operator()<0, 2>(mpp); store_dq.template operator()<0, 3>(mpp);
+    }
 
     // ---- the block's dK = ln 2 * dK^T, dV = dV^T + dvmean
 #pragma unroll

@@ -14,7 +14,8 @@ dQ' = the PREVIOUS step's dQ^T block (16 MFMAs over the workgroup's 256 keys: ne
 The loop is ROTATED: iteration X runs A0..A3, V0..V2, C0, C1, W0..W2 of step X, and V3', W3', C2', C3' and dQ' of step X-1.
 The one barrier of an iteration sits behind W3' (early in the iteration, in the shadow of A0 / C2', whose MFMAs do not depend on
 it); behind it come dQ' and the DMA of step X+2 (three stages); the row constants / fragments of step X+1's first block are read
-at the end of the iteration (their stage landed before this iteration's barrier).
+at the end of the iteration (their stage landed before this iteration's barrier).  The dQ block of step X-2 is stored, and the old
+partial of step X's tile loaded into the same registers, at the head of the iteration, one instruction every other slot.
     MFMA stream:   A0 | C2' | C3' | A1 | A2 | C0 | A3 | C1      with the 16 dQ' MFMAs spread behind the barrier
 The row constants of a block are read STRAIGHT INTO its score accumulators (the start values of the S^T / dP^T chains), so a
 block's constants can only be requested once the vector work of the block that used the set before is done (block 1: V3').
@@ -31,7 +32,7 @@ LDS_LAT = 6      # slots between an LDS read and the MFMA that consumes it (meas
 VW = 2           # slots between a vector write of an MFMA operand (packed P / dS) and that MFMA (hipcc pads nothing around inline asm: 2 wait states)
 BUDGET = 24      # issue cycles of fillers per slot (an MFMA holds the issue port for 8 of its 32 cycles)
 COST = {"VE": 12, "VC": 8, "VEP": 12, "VCP": 8, "RC_L": 4, "RC_D": 4, "RQB": 4, "RF_Q": 4, "RF_O": 4, "TR_O": 8, "TR_Q": 8, "DSW": 6,
-        "DSWP": 6, "DQR": 16, "BARRIER": 24, "ISSUE": 24, "ACC_LD": 16, "NRC_L": 4, "NRC_D": 4, "NRQB": 4, "NRF_Q": 4, "NRF_O": 4}
+        "DSWP": 6, "DQR": 16, "BARRIER": 24, "DMA": 12, "ST": 8, "LD": 6, "NRC_L": 4, "NRC_D": 4, "NRQB": 4, "NRF_Q": 4, "NRF_O": 4}
 
 
 def a_mfmas(j):
@@ -106,7 +107,17 @@ def build():
         for t in range(2):
             add(f"DSWP({sp}, {t})", v3_ready, end)
     add("BARRIER()", 0, DQ_START - LDS_LAT - 1)
-    add("ISSUE()", 0, DQ_START)          # the DMA of step X + 2: right behind the barrier
+    # ---- vector memory, ONE instruction per wavefront every other slot (the four wavefronts of a CU share one address / data path:
+    # 16 cycles per 1-KiB instruction; issued in bursts of 8 - 13 the wavefronts queued behind one another with their MFMA pipes
+    # idle, ~100 us per layer): the dQ block of step X-2 goes out (ST), the old partial of step X's tile comes in (LD, the same
+    # registers, behind the stores), the five DMA pieces of step X+2's stage follow the barrier
+    bar_dl = DQ_START - LDS_LAT - 1
+    pinned = {}
+    for g in range(4):
+        pinned[f"ST({g})"] = 2 * g
+        pinned[f"LD({g})"] = 8 + 2 * g
+    for q in range(5):
+        pinned[f"DMA({q})"] = bar_dl + 3 + 2 * q
     # ---- mask operand / row fragments: ONE register set each.  qb 0 of THIS step was read by the previous iteration (N* items);
     # qb 1 follows behind the readers of qb 0 in A1, the next step's qb 0 behind the readers of qb 1 in A3
     add("RQB(1)", pos["A_M(1)"] + 1, pos["A_M(2)"] - LDS_LAT)
@@ -162,7 +173,6 @@ def build():
         for t in range(2):
             after[f"DSWP({sp}, {t})"] = [f"VCP({4 * sp + 2 * t})", f"VCP({4 * sp + 2 * t + 1})"]
     after["BARRIER()"] = [f"DSWP({sp}, {t})" for sp in range(2) for t in range(2)]
-    after["ISSUE()"] = ["BARRIER()"]
     for k in range(16):
         after[f"DQR({k})"] = ["BARRIER()"]
     for j in range(3):
@@ -198,6 +208,9 @@ def build():
     pending = dict(items)
     for si in range(len(slots)):
         budget = BUDGET if si < n else 10 ** 9
+        for nm, ps in pinned.items():          # (pinned: first in their slot)
+            if ps == si:
+                slots[si]["fill"].append(nm); placed[nm] = si; budget -= COST[nm.split("(")[0]]
         while True:
             ready = [nm for nm, (e, d) in pending.items() if e <= si and all(a in placed for a in after.get(nm, []))]
             if not ready:
@@ -215,6 +228,7 @@ def build():
         late = [nm for nm, (e, d) in pending.items() if d <= si and si < n]
         assert not late, f"slot {si}: deadline missed for {late}"
     assert not pending, pending
+    assert placed["BARRIER()"] < pinned["DMA(0)"], "the stage DMA must follow the barrier"
     return slots, pos, placed
 
 
@@ -231,7 +245,7 @@ def guard_of(item):
         return "PREV && LIVE"
     if name in NEXT_ITEMS:          # (also behind the last step: the values are then unused, and no branch merges two register classes)
         return "CUR && LIVE"
-    if name in ("BARRIER", "ISSUE"):
+    if name in ("BARRIER", "DMA", "ST", "LD"):
         return None
     return "CUR && LIVE"
 
