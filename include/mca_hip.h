@@ -326,8 +326,8 @@ int mca_attn_bwd_dkv_fp8(const mca_attn_bwd2_args* args, const mca_attn_fp8_bwd_
  *   kb_qt[]            = per key block its query tiles | (every pair structurally allowed << 31), ascending
  *   visit[n_kblocks][n_qtiles] = 1 where the block lists the tile;  max_list = longest list (<= 256)
  * rowc (b, heads, n_qtiles + 1, 2, 64) fp32: -lse | -delta of the tile's rows (mca_attn_bwd_prep_onepass; positions past a
- * tile's rows, and the whole last tile - the NULL tile every key block's sweep ends on - hold -inf | 0, written once by the caller).  dq_acc: workspace of batch * heads * n_qtiles * 4096 floats, contents
- * irrelevant on entry.  dq, dk, dv bf16, every element written.  n_qtiles < 256, n_kblocks <= 64, max_list < 256, else MCA_E_UNSUPPORTED
+ * tile's rows, and the whole last tile - the NULL tile every key block's sweep ends on - hold -inf | 0, written once by the caller).  dq_acc: workspace of batch * heads * (n_qtiles + 1) * 4096 floats (the last slot of a
+ * (sample, head) belongs to the null tile: written, never read back into a result), contents irrelevant on entry.  dq, dk, dv bf16, every element written.  n_qtiles < 256, n_kblocks <= 64, max_list <= 250, else MCA_E_UNSUPPORTED
  * (the caller keeps the two-pass form).                                                                                  */
 typedef struct {
   const uint16_t* q; int64_t q_bstride; int64_t q_ld;           /* q[b*q_bstride + head*q_hstride + i*q_ld + d]                       */

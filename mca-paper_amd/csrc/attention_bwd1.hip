@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd1_kernel(mca_attn_bwd1_args a,
   const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
   const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
   const float* rowc_g = a.rowc + bh * (int64_t)(a.n_qtiles + 1) * 128;          // (+ the null tile)
-  float* acc_g = a.dq_acc + bh * (int64_t)a.n_qtiles * (TQ * DH);
+  float* acc_g = a.dq_acc + bh * (int64_t)(a.n_qtiles + 1) * (TQ * DH);          // (+ the null tile's slot: only the pipelined kernel writes it)
   const uint8_t* kinfo_g = a.keyinfo + (int64_t)b * a.nk_pad;
   const u16* khot_g = a.khot + (int64_t)b * a.nk_pad * 16;
 
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd1_kernel(mca_attn_bwd1_args a,
 // =====================================================================================================
 #define B1P_NST 3
 #ifndef B1_ABL          // timing-only ablation builds (tools/ablate_bwd1.py): 1 no vector work, 2 no dQ product, 4 no transposed reads,
-#define B1_ABL 0        // 8 no row reads, 16 no dS^T stores, 32 no score MFMAs, 64 no dV / dK MFMAs.  0 in the product.
+#define B1_ABL 0        // 8 no row reads, 16 no dS^T stores, 32 no score MFMAs, 64 no dV / dK MFMAs, 128 no vector memory in the loop.  0 in the product.
 #endif
 #define B1_SB() __builtin_amdgcn_sched_barrier(0)
 // (PAD: "s_nop 1" ahead of the MFMA inside the statement - two wait states between a compiler-placed register copy or select
@@ -432,6 +432,13 @@ template <int BUF, bool ZERO, bool PAD> __device__ __forceinline__ void b1_acc_m
   do { unsigned keep_;                                                                                                                     \
        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"      \
                     : "=&s"(keep_) : "v"(OFF), "s"(BASE), "s"(LDS_DST) : "memory"); } while (0)
+// the loop's form: BASE / LDS_DST come out of scalar arithmetic (no vector-written scalar register: no five-state hazard); M0 is
+// not saved (a reserved register for hipcc: it holds no value across a statement, and writes it itself right ahead of the
+// instructions that read it); IMM: the instruction's immediate byte offset - added to the global address AND to the LDS address
+#define B1_DMA16L(BASE, OFF, LDS_DST, IMM)                                                                                                 \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #IMM :: "v"(OFF), "s"(BASE), "s"(LDS_DST) : "memory")
+#define B1_DMA4L(BASE, OFF, LDS_DST)                                                                                                       \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(OFF), "s"(BASE), "s"(LDS_DST) : "memory")
 // LDS accesses by 32-bit byte address = per-lane base register + compile-time immediate (pointer arithmetic on u16* made hipcc
 // keep one address register per constant offset and spill them)
 #define LDS_P(T, ADDR) reinterpret_cast<__attribute__((address_space(3))) T*>(static_cast<uintptr_t>(ADDR))
@@ -471,7 +478,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
   const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
   const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
   const float* rowc_g = a.rowc + bh * (int64_t)(a.n_qtiles + 1) * 128;          // (+ the null tile)
-  float* acc_s = a.dq_acc + bh * (int64_t)a.n_qtiles * (TQ * DH) + wave * 1024;          // (wave-uniform; lane l's slot at + 4 l)
+  float* acc_s = a.dq_acc + bh * (int64_t)(a.n_qtiles + 1) * (TQ * DH) + wave * 1024;          // (wave-uniform; lane l's slot at + 4 l)
   const uint8_t* kinfo_g = a.keyinfo + (int64_t)b * a.nk_pad;
   const u16* khot_g = a.khot + (int64_t)b * a.nk_pad * 16;
 
@@ -516,7 +523,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     // per-step records (one 16-byte LDS read per iteration, issued ahead of the barrier's own lgkmcnt(0) and carried in scalar
     // registers from then on: separate reads of the list, the tile table and the visit flags each drained the LDS queue - with
     // every fragment prefetch in it - four times per iteration)
-    for (int i = tid; i < n_it; i += 256) {
+    for (int i = tid; i < n_it + 2; i += 256) {          // (two more null records: the loop reads record it + 2 unconditionally)
       const int qt = i < n_ent ? (int)(a.kb_qt[e_begin + i] & 0x7fffffffu) : a.n_qtiles;
       const int2 qd = qtd_s[qt];
       meta_s[i] = make_int2(qt | (((int)first_s[qt] == kbi ? 1 : 0) << 16) | (((int)last_s[qt] == kbi ? 2 : 0) << 16) | (qd.y << 20), qd.x);
@@ -633,44 +640,51 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       a_tr[t][0] = lds_b + o_tr[t][0]; a_tr[t][1] = lds_b + o_tr[t][1];
       a_da[t] = KIMG_B + o_dqa[t]; a_db[t] = DSIMG_B + (2u * TKB * TQ) + o_dqb[t];          // (iteration 0 reads nothing from it)
     }
-    // counted waits: vm_n = vector-memory operations issued so far in this block; a wait "for everything up to mark m" lets the
-    // vm_n - m younger operations stay in flight (rounded down to an immediate the switch below knows: stricter is always safe)
-    int vm_n = 0, mark_dma = 0, mark_ld[2] = {0, 0};
+    // The vector-memory operations of an iteration are UNCONDITIONAL and in a fixed order - four stores of the dQ block of step
+    // it - 2 (a step that does not exist has the null record: tile n_qtiles, a slot of dq_acc nobody reads), four loads of the
+    // old partial of step it's tile (a first visit loads its slot's stale contents: the first product of a first visit starts from
+    // the constant 0 instead), five DMA pieces of step it + 2's stage (behind the last step: the null tile's) - so that the two
+    // waits of an iteration are compile-time counts (attention_bwd1_sched.inc: B1_W1_YOUNGER, B1_W2_YOUNGER) and no counter,
+    // branch or jump table is needed (they were ~200 scalar instructions per iteration, 4 issue cycles each, in a loop whose
+    // vector pipe is the scarce resource).
     // records of steps it + 1, it, it - 1, it - 2, in scalar registers
-    int2 m1 = meta_s[1], m0 = meta_s[0], mp = make_int2(1 << 16 | 1 << 20, 0), mpp = mp;
+    const int null_rec = a.n_qtiles | (1 << 20);
+    int2 m1 = meta_s[1], m0 = meta_s[0], mp = make_int2(null_rec | (1 << 16), 0), mpp = make_int2(null_rec, 0);
     m1 = make_int2(__builtin_amdgcn_readfirstlane(m1.x), __builtin_amdgcn_readfirstlane(m1.y));
     m0 = make_int2(__builtin_amdgcn_readfirstlane(m0.x), __builtin_amdgcn_readfirstlane(m0.y));
-    // (exact counts - rounded down to a coarser set the wait for the stage also waited for stores issued moments before it - by a
-    //  computed jump into a table of {s_waitcnt vmcnt(N); s_branch end} pairs: as a C switch the structurised control flow ran
-    //  dozens of scalar branches per wait)
-#define VMW_(N) "s_waitcnt vmcnt(" #N ")\n\ts_branch 1f\n\t"
-#define VM_WAIT(YOUNGER) do { const int y_ = (YOUNGER);                                                                              \
-    asm volatile("s_min_u32 s98, %0, 30\n\ts_lshl_b32 s98, s98, 3\n\ts_getpc_b64 s[96:97]\n\ts_add_u32 s98, s98, 16\n\t"               \
-                 "s_add_u32 s96, s96, s98\n\ts_addc_u32 s97, s97, 0\n\ts_setpc_b64 s[96:97]\n\t"                                    \
-                 VMW_(0) VMW_(1) VMW_(2) VMW_(3) VMW_(4) VMW_(5) VMW_(6) VMW_(7) VMW_(8) VMW_(9) VMW_(10) VMW_(11) VMW_(12) VMW_(13)  \
-                 VMW_(14) VMW_(15) VMW_(16) VMW_(17) VMW_(18) VMW_(19) VMW_(20) VMW_(21) VMW_(22) VMW_(23) VMW_(24) VMW_(25)         \
-                 VMW_(26) VMW_(27) VMW_(28) VMW_(29) VMW_(30) "1:"                                                                   \
-                 :: "s"(y_) : "memory", "s96", "s97", "s98", "scc"); } while (0)
-    // the dQ block of a step (accumulated onto its old partial in buffer BUF) goes out, piece G: as the new partial or, on the
-    // tile's last visit, as dq
-    auto store_dq = [&]<int BUF, int G>(const int2& m) __attribute__((always_inline)) {
+#define B1_STR_(X) #X
+#define B1_STR(X) B1_STR_(X)
+    // piece G of the dQ block of a tile's LAST visit (buffer BUF): scaled, as bf16, into dq
+    auto store_dq_last = [&]<int BUF, int G>(const int2& m) __attribute__((always_inline)) {
       int ln = lane;          // (addresses from an opaque copy of the lane id: held across the loop they were spilled)
       asm volatile("" : "+v"(ln));
-      float* slot = acc_s + (int64_t)M_QT(m) * (TQ * DH);
-      if (M_LAST(m)) {
-        float t[4];
-        b1_acc_read4<BUF, G>(t);
-        const int r = (wave >> 1) * 32 + (ln & 31);
-        u16* dqb = a.dq + (int64_t)b * a.dq_bstride + h * DH + (wave & 1) * 32 + 8 * G;          // (wave-uniform)
-        // (a lane past the tile's rows stores to its own dq_acc slot, which nobody reads: every lane issues the store)
-        u16* p = r < M_ROWS(m) ? dqb + (size_t)(unsigned)((M_ROW0(m) + r) * (int)a.dq_ld + 4 * (ln >> 5))
-                               : reinterpret_cast<u16*>(slot + G * 256 + ln * 4);
-        uint2 pk;
-        pk.x = pack2bf_pk(t[0] * a.scale, t[1] * a.scale);
-        pk.y = pack2bf_pk(t[2] * a.scale, t[3] * a.scale);
-        *reinterpret_cast<uint2*>(p) = pk;
-      } else b1_acc_store1<BUF, G>((unsigned)ln * 16u, slot);
+      float t[4];
+      b1_acc_read4<BUF, G>(t);
+      const int r = (wave >> 1) * 32 + (ln & 31);
+      u16* dqb = a.dq + (int64_t)b * a.dq_bstride + h * DH + (wave & 1) * 32 + 8 * G;          // (wave-uniform)
+      // (a lane past the tile's rows stores to its own dq_acc slot, which nobody reads: every lane issues the store)
+      u16* p = r < M_ROWS(m) ? dqb + (size_t)(unsigned)((M_ROW0(m) + r) * (int)a.dq_ld + 4 * (ln >> 5))
+                             : reinterpret_cast<u16*>(acc_s + ((int64_t)M_QT(m) << 12) + G * 256 + ln * 4);
+      uint2 pk;
+      pk.x = pack2bf_pk(t[0] * a.scale, t[1] * a.scale);
+      pk.y = pack2bf_pk(t[2] * a.scale, t[3] * a.scale);
+      *reinterpret_cast<uint2*>(p) = pk;
     };
+    // this wavefront's share of the small pieces of a stage: -lse | -delta (wavefronts 0, 1), the mask operand's halves (2, 3)
+    auto dma_small = [&](const int2& m, unsigned stage_b) __attribute__((always_inline)) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      if (wave < 2) {
+        const float* rb = rowc_g + (int64_t)M_QT(m) * 128 + wave * 64;
+        B1_DMA4L(rb, (unsigned)ln * 4u, stage_b + 16384u + (unsigned)wave * 256u);
+      } else {
+        const int r = (wave - 2) * 32 + (ln >> 1), nrows = M_ROWS(m);
+        const int row = M_ROW0(m) + (r < nrows ? r : nrows - 1);
+        B1_DMA16L(a.qblk, (unsigned)row * 32u + (unsigned)(ln & 1) * 16u, stage_b + 16896u + (unsigned)(wave - 2) * 1024u, 0);
+      }
+    };
+    unsigned st_c = lds_b, st_n = lds_b + STAGE_B, st_nn = lds_b + 2u * STAGE_B;          // stages of steps it, it + 1, it + 2
+    unsigned a_meta = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const int2*)meta_s + 16u;          // record it + 2
     // ONE loop body (every iteration, the first and the last included, runs it whole: the first on a neutral "previous step" -
     // scores of -inf, packed operands and fragments of zero: P = dS = 0 -, the last on the block's NULL step, whose row constants are
     // -inf.  Six specialised copies of a 500-register body made hipcc spill accumulators right behind the MFMAs that wrote them.)
@@ -678,12 +692,11 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     auto iter = [&]<bool LIVE, int PAR>(const int it) __attribute__((always_inline)) {
       constexpr bool PREV = true, CUR = true;
       constexpr bool STEADY = LIVE;          // (a wavefront without a valid key runs its few MFMAs padded)
-      const bool has_next2 = it + 2 < n_it;
       // byte addresses of this lane (carried across the iterations: advanced by wave-uniform deltas at the end of each, so that no
       // loop-invariant offset registers stay live): a_rf / a_tr / a_rc / a_qb point into the stage of step `it`, a_db into the dS^T
-      // image of step it - 1, ds_cur is the image of step `it`
-      const unsigned st_c = lds_b + (unsigned)(it % B1P_NST) * STAGE_B, st_n = lds_b + (unsigned)((it + 1) % B1P_NST) * STAGE_B;
-      const unsigned ds_cur = DSIMG_B + (unsigned)(it & 1) * (2u * TKB * TQ), ds_prev = DSIMG_B + (unsigned)((it & 1) ^ 1) * (2u * TKB * TQ);
+      // image of step it - 1, ds_cur is the image of step `it`; st_c / st_n / st_nn: the stages of steps it, it + 1, it + 2
+      constexpr unsigned DS_HALF = 2u * TKB * TQ;
+      const unsigned ds_cur = DSIMG_B + (PAR ? DS_HALF : 0u), ds_prev = DSIMG_B + (PAR ? 0u : DS_HALF);
       // (opaque to the optimiser: loop strength reduction made every (base + immediate) pair an induction variable of its own -
       //  45 registers, spilled - instead of one base register per fragment and an immediate in the instruction)
       asm volatile("" : "+v"(a_rf[0]), "+v"(a_rf[1]), "+v"(a_rf[2]), "+v"(a_rf[3]), "+v"(a_rc), "+v"(a_qb));
@@ -691,24 +704,29 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       unsigned n_off = st_n - st_c;          // (wave-uniform: the next stage's same addresses)
       asm volatile("" : "+s"(n_off));
       asm volatile("" : "+v"(ods[0]), "+v"(ods[1]));          // (opaque: the sixteen xor-ed variants are recomputed, not hoisted and spilled)
-      const int2 m2v = meta_s[has_next2 ? it + 2 : it];          // (read here, ahead of the barrier's lgkmcnt(0); made scalar behind it)
-      const bool prev_first = M_FIRST(mp) || (dbg & 128) || it == 0;
-      const bool st_on = it >= 2 && it - 2 < n_ent && !(dbg & 256);          // step it - 2 is a real step: its dQ block goes out
-      const bool ld_on = it < n_ent && !M_FIRST(m0) && !(dbg & 128);          // step it has an old partial to accumulate onto
+      const u32x2v m2v = *LDS_P(const u32x2v, a_meta);          // record of step it + 2 (read here, ahead of the barrier's lgkmcnt(0); made scalar behind it)
+      const bool prev_first = M_FIRST(mp) != 0;
+      float* st_base = acc_s + ((int64_t)M_QT(mpp) << 12);          // (wave-uniform: scalar registers)
+      const float* ld_base = acc_s + ((int64_t)M_QT(m0) << 12);
+      unsigned ln16 = (unsigned)lane << 4;
+      asm volatile("" : "+v"(ln16));
       int2 m2s = m1;
+      unsigned o_dma = 0;
+      const u16 *qrow = qbase, *orow = obase;
       asm volatile("s_nop 1" ::: "memory");          // register copies of the loop's back edge before the first MFMA reads them
       B1_SB();
 
 #define A_M(J) if (!(B1_ABL & 32)) MF_ACC_VV(S[(J) & 1], qbf, khf[(J) & 1])
 #define A_S(J, KS) if (!(B1_ABL & 32)) MF_ACC_AA(S[(J) & 1], rfQ[KS], kf[(J) & 1][KS])
 #define A_P(J, KS) if (!(B1_ABL & 32)) MF_ACC_AV(dP[(J) & 1], rfO[KS], vf[(J) & 1][KS])
-#define VE_(SET, R) do { if (B1_ABL & 1) break; const float p_ = __builtin_amdgcn_exp2f(S[SET][R]); S[SET][R] = p_; dP[SET][R] *= p_; } while (0)
+#define VE2_(SET, I) do { if (B1_ABL & 1) break; const float p0_ = __builtin_amdgcn_exp2f(S[SET][2 * (I)]), p1_ = __builtin_amdgcn_exp2f(S[SET][2 * (I) + 1]); \
+                          S[SET][2 * (I)] = p0_; S[SET][2 * (I) + 1] = p1_; dP[SET][2 * (I)] *= p0_; dP[SET][2 * (I) + 1] *= p1_; } while (0)
 #define VC_(SET, I) do { if (B1_ABL & 1) break; pb[SET][(I) >> 2][(I) & 3] = pack2bf_pk(S[SET][2 * (I)], S[SET][2 * (I) + 1]); \
                          sb[SET][(I) >> 2][(I) & 3] = pack2bf_pk(dP[SET][2 * (I)], dP[SET][2 * (I) + 1]); \
                          asm volatile("" :: "v"(pb[SET][(I) >> 2][(I) & 3]), "v"(sb[SET][(I) >> 2][(I) & 3])); } while (0)
-#define VE(J, R) VE_((J) & 1, R)
+#define VE2(J, I) VE2_((J) & 1, I)
 #define VC(J, I) VC_((J) & 1, I)
-#define VEP(R) VE_(1, R)
+#define VEP2(I) VE2_(1, I)
 #define VCP(I) VC_(1, I)
 #define C_V(J, SP, N) if (!(B1_ABL & 64)) MF_ACCA_VV(dv[(J) & 1][N], trO[SP][N], pb[(J) & 1][SP])
 #define C_K(J, SP, N) if (!(B1_ABL & 64)) MF_ACCA_VV(dk[(J) & 1][N], trQ[SP][N], sb[(J) & 1][SP])
@@ -735,30 +753,40 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       // (the first product of a tile's first visit starts from the constant 0; behind the counted wait in either case: an unused load
       //  that lands later would overwrite the product)
 #define DQM(K) do { if (B1_ABL & 2) break;                                                                                   \
-                    if ((K) == 0) { if (!(dbg & 4096)) VM_WAIT(vm_n - mark_ld[PAR ^ 1]);                                                     \
+                    if ((K) == 0) { asm volatile("s_waitcnt vmcnt(" B1_STR(B1_W2_YOUNGER) ")" ::: "memory");                  \
                                     if (prev_first) b1_acc_mfma<PAR ^ 1, true, true>(da[0], db[0]);                          \
                                     else b1_acc_mfma<PAR ^ 1, false, true>(da[0], db[0]); }                                  \
                     else b1_acc_mfma<PAR ^ 1, false, !STEADY>(da[(K) & 1], db[(K) & 1]); } while (0)
       // the barrier: this wavefront's dS^T stores are done (lgkmcnt) and its pieces of the NEXT step's stage have landed
-#define BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (!(dbg & 2048)) VM_WAIT(vm_n - mark_dma); \
+#define BARRIER() do { asm volatile("s_waitcnt vmcnt(" B1_STR(B1_W1_YOUNGER) ") lgkmcnt(0)" ::: "memory");                    \
                        __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-#define DMA(P) do { if ((P) == 0) { mark_dma = vm_n; m2s = make_int2(__builtin_amdgcn_readfirstlane(m2v.x), __builtin_amdgcn_readfirstlane(m2v.y)); } \
-                    if (has_next2 && !(dbg & 512)) { dma_piece.template operator()<P>(m2s, (it + 2) % B1P_NST); vm_n += 1; mark_dma = vm_n; } } while (0)
+      // piece P of step it + 2's stage: 0 / 2 the two Q pieces of this wavefront, 1 / 3 the dO pieces, 4 its share of the row
+      // constants / mask operand
+#define DMA(P) do { if ((B1_ABL & 128) && (P) != 0) break;                                                                    \
+                    if ((P) == 0) { m2s = make_int2(__builtin_amdgcn_readfirstlane((int)m2v[0]), __builtin_amdgcn_readfirstlane((int)m2v[1])); \
+                                    qrow = qbase + (int64_t)M_ROW0(m2s) * DH; orow = obase + (int64_t)M_ROW0(m2s) * DH;            \
+                                    int ln_ = lane; asm volatile("" : "+v"(ln_));                                                  \
+                                    const int r_ = wave * 16 + (ln_ >> 3);                                                         \
+                                    o_dma = (unsigned)(r_ * 128 + (((ln_ & 7) ^ b1_swz(r_)) << 4)); }                              \
+                    if (B1_ABL & 128) break;                                                                                        \
+                    if ((P) == 0) B1_DMA16L(qrow, o_dma, st_nn + (unsigned)(wave * 2048), 0);                                       \
+                    else if ((P) == 1) B1_DMA16L(orow, o_dma, st_nn + 8192u + (unsigned)(wave * 2048), 0);                          \
+                    else if ((P) == 2) { o_dma ^= 64u; B1_DMA16L(qrow, o_dma, st_nn + (unsigned)(wave * 2048), 1024); }     \
+                    else if ((P) == 3) B1_DMA16L(orow, o_dma, st_nn + 8192u + (unsigned)(wave * 2048), 1024);               \
+                    else dma_small(m2s, st_nn); } while (0)
       // the dQ block of step it - 2 (buffer PAR: its last MFMA ran six slots before the previous iteration ended), then the old
-      // partial of step it's tile into the same registers (the first product of a first visit starts from the constant 0 instead)
-#define ST(G) do { if (st_on) { store_dq.template operator()<PAR, G>(mpp); vm_n += 1; } } while (0)
-#define LD(G) do { if (ld_on) { int ln_ld = lane; asm volatile("" : "+v"(ln_ld));                                                   \
-                                b1_acc_load1<PAR, G>((unsigned)ln_ld * 16u, acc_s + (int64_t)M_QT(m0) * (TQ * DH));                   \
-                                vm_n += 1; if ((G) == 3) mark_ld[PAR] = vm_n; } } while (0)
+      // partial of step it's tile into the same registers
+#define ST(G) do { if (B1_ABL & 128) break; if (M_LAST(mpp)) store_dq_last.template operator()<PAR, G>(mpp); else b1_acc_store1<PAR, G>(ln16, st_base); } while (0)
+#define LD(G) do { if (B1_ABL & 128) break; b1_acc_load1<PAR, G>(ln16, ld_base); } while (0)
 #include "attention_bwd1_sched.inc"
 #undef A_M
 #undef A_S
 #undef A_P
-#undef VE_
+#undef VE2_
 #undef VC_
-#undef VE
+#undef VE2
 #undef VC
-#undef VEP
+#undef VEP2
 #undef VCP
 #undef C_V
 #undef C_K
@@ -797,6 +825,8 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       }
       // the records move on: step it + 2's becomes step it + 1's, ...
       mpp = mp; mp = m0; m0 = m1; m1 = m2s;
+      { const unsigned t_ = st_c; st_c = st_n; st_n = st_nn; st_nn = t_; }
+      a_meta += 8u;
       B1_SB();
     };
 
@@ -808,7 +838,6 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     asm volatile("s_waitcnt vmcnt(5)" ::: "memory");          // (only stage 1's five pieces stay in flight)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    vm_n = 5; mark_dma = 5; mark_ld[0] = 0; mark_ld[1] = 0;          // (counted from stage 1's pieces on)
     if (!wave_dead) {
       // the first step's first block: row constants (into score set 0), mask operand, row fragments - the loop reads them an
       // iteration ahead; and the neutral previous step: block 3' scores of -inf (P = 0), packed operands of block 2' and every
@@ -844,9 +873,16 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");          // the last dK / dV MFMAs before the epilogue reads the accumulators
     B1_SB();
     // an odd number of steps: the last one's dQ block (buffer 0, finished by the null iteration) has no iteration left to go out in
-    if ((n_ent & 1) && !(dbg & 256)) {
-      store_dq.template operator()<0, 0>(mpp); store_dq.template operator()<0, 1>(mpp);
-      store_dq.template operator()<0, 2>(mpp); store_dq.template operator()<0, 3>(mpp);
+    if (n_ent & 1) {
+      float* slot = acc_s + ((int64_t)M_QT(mpp) << 12);
+      unsigned ln16 = (unsigned)lane << 4;
+      asm volatile("" : "+v"(ln16));
+      if (M_LAST(mpp)) {
+        store_dq_last.template operator()<0, 0>(mpp); store_dq_last.template operator()<0, 1>(mpp);
+        store_dq_last.template operator()<0, 2>(mpp); store_dq_last.template operator()<0, 3>(mpp);
+      } else {
+        b1_acc_store1<0, 0>(ln16, slot); b1_acc_store1<0, 1>(ln16, slot); b1_acc_store1<0, 2>(ln16, slot); b1_acc_store1<0, 3>(ln16, slot);
+      }
     }
 
     // ---- the block's dK = ln 2 * dK^T, dV = dV^T + dvmean
@@ -899,7 +935,7 @@ extern "C" int mca_attn_bwd_onepass(const mca_attn_bwd1_args* a, mca_stream_t st
   if (!a || !a->q || !a->k || !a->v || !a->d_o || !a->rowc || !a->dvmean || !a->dq || !a->dk || !a->dv || !a->dq_acc) return MCA_E_BADARG;
   if (!a->keyinfo || !a->ktile_flags || !a->khot || !a->qblk || !a->qt_desc || !a->kb_desc || !a->kb_qt || !a->visit) return MCA_E_BADARG;
   if (a->batch <= 0 || a->heads <= 0 || a->n <= 0 || a->n_qtiles <= 0 || a->n_kblocks <= 0) return MCA_E_BADARG;
-  if (a->n_qtiles >= B1_MAX_QT || a->n_kblocks > B1_MAX_KB || a->max_list + 2 > B1_MAX_LIST) return MCA_E_UNSUPPORTED;
+  if (a->n_qtiles >= B1_MAX_QT || a->n_kblocks > B1_MAX_KB || a->max_list + 6 > B1_MAX_LIST) return MCA_E_UNSUPPORTED;          // (list + null steps + the two records read ahead)
   if (a->q_ld % 8 || a->kv_ld % 8 || a->o_ld % 8 || a->q_bstride % 8 || a->kv_bstride % 8 || a->o_bstride % 8 || a->q_hstride % 8 || a->o_hstride % 8) return MCA_E_ALIGN;
   if ((uintptr_t)a->q % 16 || (uintptr_t)a->k % 16 || (uintptr_t)a->v % 16 || (uintptr_t)a->d_o % 16 || (uintptr_t)a->khot % 16 || (uintptr_t)a->qblk % 16) return MCA_E_ALIGN;
   if (a->dq_ld % 8 || a->dq_bstride % 8 || (uintptr_t)a->dq % 16 || a->dkv_ld % 8 || a->dkv_bstride % 8 || (uintptr_t)a->dk % 16 || (uintptr_t)a->dv % 16) return MCA_E_ALIGN;

@@ -86,7 +86,7 @@ class _OnePassSched:
         self.kb_qt = _dev(s.kb_qt.astype(np.uint32).view(np.int32), device)
         self.visit, self.row_slot = _dev(s.visit.astype(np.uint8), device), _dev(s.row_slot.astype(np.int32), device)
         self.n_qt, self.n_kb, self.max_list = len(s.qt_desc), len(s.kb_desc), int(s.kb_desc[:, 3].max())
-        self.fits = self.n_qt < 256 and self.n_kb <= 64 and self.max_list + 2 <= 256          # the kernel's LDS tables
+        self.fits = self.n_qt < 256 and self.n_kb <= 64 and self.max_list + 6 <= 256          # the kernel's LDS tables
 
 
 class _BlockSched:
@@ -572,7 +572,7 @@ class FusionEngine:
             rc = torch.empty(b, self.H, sc.n_qt + 1, 2, 64, dtype=torch.float32, device=self.device)          # (+ the null tile)
             rc[:, :, :, 0] = float("-inf"); rc[:, :, :, 1] = 0.0
             ws["rowc"] = rc
-            ws["dq_acc"] = torch.empty(b * self.H * sc.n_qt * 4096, dtype=torch.float32, device=self.device)
+            ws["dq_acc"] = torch.empty(b * self.H * (sc.n_qt + 1) * 4096, dtype=torch.float32, device=self.device)          # (+ the null tile's slot)
             # head-major packed copies of q and dO (written by the prep launch): a query tile of a head is contiguous memory
             # (+ 64 rows: the kernel reads whole 64-row tiles, the last one past its rows)
             ws["q_hm"] = torch.zeros((b * self.H * N + 64) * 64, dtype=torch.bfloat16, device=self.device)

@@ -675,7 +675,7 @@ def _run_onepass(H, sc, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean_ref, keyin
         assert (rowc[:, :, t, 1, :rn] + delta_ref[:, :, r0:r0 + rn]).abs().max() < 1e-3 * (1 + float(delta_ref.abs().max()))
         assert torch.isinf(rowc[:, :, t, 0, rn:]).all() and (rowc[:, :, t, 1, rn:] == 0).all()
     assert torch.isinf(rowc[:, :, nqt, 0]).all() and (rowc[:, :, nqt, 1] == 0).all()
-    acc = torch.full((b * heads * nqt * 4096,), float("nan"), device=dev)          # contents irrelevant on entry
+    acc = torch.full((b * heads * (nqt + 1) * 4096,), float("nan"), device=dev)          # contents irrelevant on entry
     out = []
     for rep_i in range(2):          # first launch: q / dO from the (b, n, heads*64) matrices; second: from the packed copies (same bits)
         dq = torch.full((b, N, D), 7.0, device=dev, dtype=torch.bfloat16)

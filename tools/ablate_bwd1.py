@@ -1,17 +1,21 @@
 """Timing-only ablations of the pipelined one-pass attention backward (results of those builds are WRONG by construction): one
-library per B1_ABL mask (attention_bwd1.hip), timed at b = 32 on the CMU structure with and without the kernel's memory traffic
-(knob 9 bits 128 | 256 | 512).   usage: ablate_bwd1.py build|run"""
+library per B1_ABL mask (attention_bwd1.hip).  An ablated build computes on garbage, which changes the power the MFMAs draw and
+with it the shader clock (2.25-2.4 GHz against 2.1 GHz for the product kernel): compare CYCLES, not microseconds -
+tools/clocks_onepass.sh measures both (GRBM_GUI_ACTIVE / 8 XCDs and the kernel's wall time).
+usage: ablate_bwd1.py build          (here; the libraries travel to the GPU box with the snapshot)
+       ablate_bwd1.py run            (on the GPU box: one rocprofv3 pass per library)"""
 import importlib, os, subprocess, sys
 here = os.path.dirname(os.path.abspath(__file__)); root = os.path.dirname(here)
 sys.path.insert(0, root)
-MASKS = {"base": 0, "novalu": 1, "nodq": 2, "noreads": 12, "nodsw": 16, "mfma_only": 31, "valu_lds_only": 96 + 2, "noA": 32, "noC": 64, "valu_only": 96 + 2 + 12 + 16}
+MASKS = {"nomem": 128, "novalu": 1, "novalu_nomem": 129, "noreads": 12, "nodq": 2, "mfma_only": 31, "mfma_only_nomem": 159}
 if sys.argv[1] == "build":
     b = importlib.import_module("mca-paper_amd.build")
     for nm, mk in MASKS.items():
         print(b.build_variant(os.path.join(root, "mca-paper_amd", f"libabl_bwd1_{nm}.so"), [f"B1_ABL={mk}"], only=["attention_bwd1.hip"]))
 else:
-    for nm in MASKS:
-        env = dict(os.environ, MCA_HIP_LIB=os.path.join(root, "mca-paper_amd", f"libabl_bwd1_{nm}.so"), MCA_BENCH_ATTN_ABLATE="1")
-        out = subprocess.run([sys.executable, os.path.join(here, "bench_attn.py"), "32"], env=env, capture_output=True, text=True).stdout
-        keep = [l for l in out.splitlines() if l.startswith("bwd one-pass ->") or "no memory" in l]
-        print(f"{nm:14s}", " | ".join(l.split("layer:")[-1].split("us")[0].strip() + " us" + (" (no memory)" if "no memory" in l else "") for l in keep), flush=True)
+    for nm in ["product"] + list(MASKS):
+        env = dict(os.environ, MCA_BENCH_ATTN_ABLATE="2")
+        if nm != "product":
+            env["MCA_HIP_LIB"] = os.path.join(root, "mca-paper_amd", f"libabl_bwd1_{nm}.so")
+        out = subprocess.run(["bash", os.path.join(here, "clocks_onepass.sh"), os.path.join(root, "gpurun_out", f"clk_{nm}")], env=env, capture_output=True, text=True, cwd=root).stdout
+        print(f"{nm:16s}", (out.strip().splitlines() or ["(no output)"])[-1], flush=True)

@@ -44,13 +44,10 @@ eng.dbg["onepass"] = False          # "bwd" = the two-pass form; "bwd one-pass" 
 cases = [("fwd", fwd, {}), ("fwd register-staged (3 wavefronts per SIMD)", fwd, {13: 1}), ("fwd fp8", fwd8, {}), ("fwd fp8 register-staged", fwd8, {9: 32}), ("bwd", bwd, {}), ("bwd one-pass", bwd1, {}), ("bwd fp8", bwd8, {})]
 if os.environ.get("MCA_BENCH_ATTN_ONLY"):
     cases = [c for c in cases if c[0] == os.environ["MCA_BENCH_ATTN_ONLY"]]
-if os.environ.get("MCA_BENCH_ATTN_ABLATE"):          # timing-only ablations of the one-pass backward (knob 9 bits 128 / 256 / 512)
-    cases = [("bwd one-pass", bwd1, {}), ("bwd one-pass no acc loads", bwd1, {9: 128}), ("bwd one-pass no acc stores", bwd1, {9: 256}),
-             ("bwd one-pass no acc traffic", bwd1, {9: 384}), ("bwd one-pass no step DMA", bwd1, {9: 512}), ("bwd one-pass no memory", bwd1, {9: 896}),
-             ("bwd one-pass no wait for the stage", bwd1, {9: 2048}), ("bwd one-pass no wait for the partial", bwd1, {9: 4096}),
-             ("bwd one-pass neither wait", bwd1, {9: 6144}), ("bwd one-pass plain kernel", bwd1, {9: 64}),]
-    if os.environ["MCA_BENCH_ATTN_ABLATE"] == "2":          # (only the product form and the form without memory traffic)
-        cases = [c for c in cases if c[0] in ("bwd one-pass", "bwd one-pass no memory")]
+if os.environ.get("MCA_BENCH_ATTN_ABLATE"):          # the one-pass backward alone: pipelined and plain kernel (knob 9 bit 64)
+    cases = [("bwd one-pass", bwd1, {}), ("bwd one-pass plain kernel", bwd1, {9: 64})]
+    if os.environ["MCA_BENCH_ATTN_ABLATE"] == "2":
+        cases = cases[:1]
 if os.environ.get("MCA_BENCH_ATTN_EXTRA"):
     cases += [("bwd no-atomics", bwd, {6: 1})]
 for nm, fn, knobs in cases:

@@ -6,7 +6,7 @@ guide's attention-backward notes ask for ("assigned to an MFMA gap by a generate
 A wavefront owns 64 keys (two 32-key blocks kb) and a step brings 64 query rows (two 32-row blocks qb): four 32 x 32 score
 BLOCKS j = 2 qb + kb per step.  Per block:
     A(j)  S^T, dP^T: the mask product, then 4 + 4 MFMAs on row fragments of Q / dO (row constants = accumulator start values)
-    V(j)  16 VE (exp2 + multiply of one element) and 8 VC (two packed conversions -> one dword of P, one of dS)
+    V(j)  8 VE2 (exp2 + multiply of two elements) and 8 VC (two packed conversions -> one dword of P, one of dS)
     C(j)  dV^T, dK^T: 8 MFMAs on transposed fragments of dO / Q, B operands = the packed P / dS
     W(j)  dS^T to the [key][query] image (4 stores of 8 bytes)
 dQ' = the PREVIOUS step's dQ^T block (16 MFMAs over the workgroup's 256 keys: needs every wavefront's dS^T, i.e. the barrier).
@@ -31,7 +31,7 @@ LAG = 2          # slots between an MFMA and the first vector instruction that r
 LDS_LAT = 6      # slots between an LDS read and the MFMA that consumes it (measured: with 3 the MFMAs waited 170 us per layer for fragments)
 VW = 2           # slots between a vector write of an MFMA operand (packed P / dS) and that MFMA (hipcc pads nothing around inline asm: 2 wait states)
 BUDGET = 24      # issue cycles of fillers per slot (an MFMA holds the issue port for 8 of its 32 cycles)
-COST = {"VE": 12, "VC": 8, "VEP": 12, "VCP": 8, "RC_L": 4, "RC_D": 4, "RQB": 4, "RF_Q": 4, "RF_O": 4, "TR_O": 8, "TR_Q": 8, "DSW": 6,
+COST = {"VE2": 24, "VC": 8, "VEP2": 24, "VCP": 8, "RC_L": 4, "RC_D": 4, "RQB": 4, "RF_Q": 4, "RF_O": 4, "TR_O": 8, "TR_Q": 8, "DSW": 6,
         "DSWP": 6, "DQR": 16, "BARRIER": 24, "DMA": 12, "ST": 8, "LD": 6, "NRC_L": 4, "NRC_D": 4, "NRQB": 4, "NRF_Q": 4, "NRF_O": 4}
 
 
@@ -97,8 +97,8 @@ def build():
     # its end) and are overwritten by this iteration's A1
     a3_tail = n - 1 - pos["A_P(3, 3)"]
     v3_ready = max(0, LAG - a3_tail)
-    for r in range(16):
-        add(f"VEP({r})", v3_ready, pos["A_M(1)"] - LDS_LAT - 1)
+    for i in range(8):          # (two elements per item: exp, exp, multiply, multiply - a dependent multiply right behind its exp costs a wait state)
+        add(f"VEP2({i})", v3_ready, pos["A_M(1)"] - LDS_LAT - 1)
     for i in range(8):
         sp = i >> 2
         # packed set 1: C1, its last reader, ended the previous iteration; next reader C3'
@@ -149,8 +149,8 @@ def build():
     for j in range(3):
         ready = pos[f"A_P({j}, 3)"] + LAG
         dl_scores = pos[f"A_M({j + 2})"] - LDS_LAT - 1 if j + 2 < 4 else n + pos["A_M(0)"] - LDS_LAT - 1
-        for r in range(16):
-            add(f"VE({j}, {r})", ready, dl_scores)
+        for i in range(8):
+            add(f"VE2({j}, {i})", ready, dl_scores)
         for i in range(8):
             sp = i >> 2
             # the packed set j & 1 is free behind its previous readers: block 0 (set 0): C2'; block 1 (set 1): C3'; block 2 (set 0): C0
@@ -168,7 +168,7 @@ def build():
     # dependencies between fillers (same or later slot, in this order inside a slot)
     after = {}
     for i in range(8):
-        after[f"VCP({i})"] = [f"VEP({2 * i})", f"VEP({2 * i + 1})"]
+        after[f"VCP({i})"] = [f"VEP2({i})"]
     for sp in range(2):
         for t in range(2):
             after[f"DSWP({sp}, {t})"] = [f"VCP({4 * sp + 2 * t})", f"VCP({4 * sp + 2 * t + 1})"]
@@ -177,20 +177,20 @@ def build():
         after[f"DQR({k})"] = ["BARRIER()"]
     for j in range(3):
         for i in range(8):
-            after[f"VC({j}, {i})"] = [f"VE({j}, {2 * i})", f"VE({j}, {2 * i + 1})"]
+            after[f"VC({j}, {i})"] = [f"VE2({j}, {i})"]
         for sp in range(2):
             for t in range(2):
                 # the dS^T image of this step is the one dQ'' (two steps back) read until the previous iteration ended: any wavefront
                 # may write it only behind this iteration's barrier
                 after[f"DSW({j}, {sp}, {t})"] = [f"VC({j}, {4 * sp + 2 * t})", f"VC({j}, {4 * sp + 2 * t + 1})", "BARRIER()"]
-    holder = {1: [f"VEP({r})" for r in range(16)] + [f"VCP({i})" for i in range(8)],
-              2: [f"VE(0, {r})" for r in range(16)] + [f"VC(0, {i})" for i in range(8)],
-              3: [f"VE(1, {r})" for r in range(16)] + [f"VC(1, {i})" for i in range(8)]}
+    holder = {1: [f"VEP2({i})" for i in range(8)] + [f"VCP({i})" for i in range(8)],
+              2: [f"VE2(0, {i})" for i in range(8)] + [f"VC(0, {i})" for i in range(8)],
+              3: [f"VE2(1, {i})" for i in range(8)] + [f"VC(1, {i})" for i in range(8)]}
     for j in (1, 2, 3):
         for g in range(4):
             after[f"RC_L({j}, {g})"] = list(holder[j]); after[f"RC_D({j}, {g})"] = list(holder[j])
     for g in range(4):
-        after[f"NRC_L({g})"] = [f"VE(2, {r})" for r in range(16)] + [f"VC(2, {i})" for i in range(8)]
+        after[f"NRC_L({g})"] = [f"VE2(2, {i})" for i in range(8)] + [f"VC(2, {i})" for i in range(8)]
         after[f"NRC_D({g})"] = list(after[f"NRC_L({g})"])
     for i in range(8):          # V1 overwrites the packed dS dwords W3' stores (set 1)
         after[f"VC(1, {i})"] = after[f"VC(1, {i})"] + [f"DSWP({i >> 2}, {(i & 3) >> 1})"]
@@ -233,7 +233,7 @@ def build():
 
 
 PREV_ITEMS = ("DQM", "DQR")
-PREV_LIVE_ITEMS = ("CP_V", "CP_K", "VEP", "VCP", "DSWP")
+PREV_LIVE_ITEMS = ("CP_V", "CP_K", "VEP2", "VCP", "DSWP")
 NEXT_ITEMS = ("NRC_L", "NRC_D", "NRQB", "NRF_Q", "NRF_O")
 
 
@@ -253,6 +253,20 @@ def guard_of(item):
 def emit(slots, path):
     lines = ["// GENERATED by tools/gen_bwd1_schedule.py - do not edit.  One loop iteration of attn_bwd1p_kernel: MFMA slots and their fillers.",
              f"// {sum(1 for s in slots if s['mfma'])} matrix instructions; LAG {LAG}, LDS latency {LDS_LAT} slots, filler budget {BUDGET} cycles per slot"]
+    # the iteration's vector-memory operations in issue order (an MFMA is emitted ahead of its slot's fillers)
+    vm, bar, dqm0 = [], None, None
+    for si, s in enumerate(slots):
+        if s["mfma"] == "DQM(0)":
+            dqm0 = len(vm)
+        for f in s["fill"]:
+            if f.split("(")[0] in ("ST", "LD", "DMA"):
+                vm.append(f)
+            if f == "BARRIER()":
+                bar = len(vm)
+    assert vm.index("DMA(4)") == len(vm) - 1 and bar is not None and dqm0 is not None and bar <= vm.index("DMA(0)")
+    w1 = bar                                             # the previous iteration's DMA(4) landed: this iteration's operations stay in flight
+    w2 = (len(vm) - 1 - vm.index("LD(3)")) + dqm0        # the previous iteration's LD(3) landed
+    lines += [f"// vector-memory order: {' '.join(vm)}", f"#define B1_W1_YOUNGER {w1}", f"#define B1_W2_YOUNGER {w2}"]
     for si, s in enumerate(slots):
         parts = []
         if s["mfma"]:
