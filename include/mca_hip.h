@@ -324,7 +324,7 @@ int mca_attn_bwd_dkv_fp8(const mca_attn_bwd2_args* args, const mca_attn_fp8_bwd_
  *   qt_desc[n_qtiles]  = {first row, rows (1..64)}                       query tiles, a partition of 0..n-1
  *   kb_desc[n_kblocks] = {first key, keys (1..256), first entry, entries} key blocks, a partition of 0..n-1, 16-byte aligned
  *   kb_qt[]            = per key block its query tiles | (every pair structurally allowed << 31), ascending
- *   visit[n_kblocks][n_qtiles] = 1 where the block lists the tile;  max_list = longest list (<= 256)
+ *   visit[n_kblocks][n_qtiles] = 1 where the block lists the tile;  max_list = longest list (<= 250), n_entries = all lists
  * rowc (b, heads, n_qtiles + 1, 2, 64) fp32: -lse | -delta of the tile's rows (mca_attn_bwd_prep_onepass; positions past a
  * tile's rows, and the whole last tile - the NULL tile every key block's sweep ends on - hold -inf | 0, written once by the caller).  dq_acc: workspace of batch * heads * (n_qtiles + 1) * 4096 floats (the last slot of a
  * (sample, head) belongs to the null tile: written, never read back into a result), contents irrelevant on entry.  dq, dk, dv bf16, every element written.  n_qtiles < 256, n_kblocks <= 64, max_list <= 250, else MCA_E_UNSUPPORTED
@@ -342,6 +342,7 @@ typedef struct {
   const uint8_t* keyinfo; const uint8_t* ktile_flags; const uint16_t* khot; const uint16_t* qblk;
   const int32_t* qt_desc; const int32_t* kb_desc; const uint32_t* kb_qt; const uint8_t* visit;
   int n_qtiles, n_kblocks, max_list;
+  int n_entries;                                               /* length of kb_qt: n_entries + 4 * n_kblocks <= 512                 */
   int batch, heads, n, nk_pad, n_ktiles64;
   float scale;
   int flags;

@@ -25,6 +25,7 @@
 #define B1_MAX_QT 256
 #define B1_MAX_KB 64
 #define B1_MAX_LIST 256
+#define B1_MAX_META 512              // step records of all key blocks of a (sample, head) (pipelined kernel)
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 
@@ -446,6 +447,14 @@ template <int BUF, bool ZERO, bool PAD> __device__ __forceinline__ void b1_acc_m
 #define LDS_RF4(ADDR) (*LDS_P(const f32x4, ADDR))
 #define LDS_TR(ADDR) __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_P(bf16x4, ADDR))
 
+MCA_TRACE_BUFFER(attn_bwd1)      // trace build, knob 9 bit 8: s_memtime stamps of wavefront 0 of workgroup 0 at the block-level points (tools/trace_bwd1.py)
+#ifdef MCA_TRACE_BUILD
+#define B1_STAMP() do { if (trace_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) mca_trace_attn_bwd1[tr_n & 1023] = t_; tr_n++; } } while (0)
+#define B1_NOTE(V) do { if (trace_on) { if (lane == 0) mca_trace_attn_bwd1[tr_n & 1023] = (unsigned long long)(V); tr_n++; } } while (0)
+#else
+#define B1_STAMP() do {} while (0)
+#define B1_NOTE(V) do {} while (0)
+#endif
 // a step's record {tile | (1 first, 2 last visit of the tile by this (sample, head)) << 16 | rows << 20, first row}
 #define M_QT(M) ((M).x & 0xffff)
 #define M_FIRST(M) (((M).x >> 16) & 1)
@@ -459,8 +468,9 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
   u16* stage_s = lds;                                             // B1P_NST stages
   u16* kimg = stage_s + B1P_NST * B1_STAGE_U16;
   u16* dsimg = kimg + TKB * DH;
-  int2* meta_s = reinterpret_cast<int2*>(dsimg + 2 * TKB * TQ);           // the key block's steps: {tile | (1 first, 2 last visit) << 16 | rows << 20, first row}
-  int2* qtd_s = reinterpret_cast<int2*>(meta_s + B1_MAX_LIST);            // query tile table {first row, rows}
+  int2* meta_s = reinterpret_cast<int2*>(dsimg + 2 * TKB * TQ);           // every live key block's steps: {tile | (1 first, 2 last visit) << 16 | rows << 20, first row}
+  int4* kbd_s = reinterpret_cast<int4*>(meta_s + B1_MAX_META);            // key block table {first key, keys, first record in meta_s, steps}
+  int2* qtd_s = reinterpret_cast<int2*>(kbd_s + B1_MAX_KB);               // query tile table {first row, rows}
   uint8_t* first_s = reinterpret_cast<uint8_t*>(qtd_s + B1_MAX_QT);
   uint8_t* last_s = first_s + B1_MAX_QT;
   uint8_t* live_s = last_s + B1_MAX_QT;
@@ -469,6 +479,10 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
   const int lin = (dbg & 16) ? (int)blockIdx.x : xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int h = lin % a.heads, b = lin / a.heads;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MCA_TRACE_BUILD
+  const bool trace_on = lin == 0 && wave == 0 && (dbg & 8);
+  int tr_n = 0;
+#endif
   const int l31 = lane & 31, lh = lane >> 5;
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
   const int64_t bh = (int64_t)b * a.heads + h;
@@ -488,6 +502,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     int live = 0;
     for (int t = d.x >> 6; t <= (d.x + d.y - 1) >> 6; t++) live |= fl[t];
     live_s[tid] = live ? 1 : 0;
+    kbd_s[tid] = d;
   }
   if (tid < DH) dvm_s[tid] = a.dvmean[(int64_t)b * a.heads * DH + h * DH + tid];
   for (int qt = tid; qt < a.n_qtiles; qt += 256) qtd_s[qt] = reinterpret_cast<const int2*>(a.qt_desc)[qt];
@@ -498,6 +513,36 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     for (int kb = 0; kb < a.n_kblocks; kb++)
       if (live_s[kb] && a.visit[kb * a.n_qtiles + qt]) { if (first == 255) first = kb; last = kb; }
     first_s[qt] = (uint8_t)first; last_s[qt] = (uint8_t)last;
+  }
+  // ---- the step records of EVERY live key block, once (per block this was a global read of the block's list in front of its
+  // first DMA: one memory latency per block, eleven per workgroup).  A block's records: its list, then the NULL steps - tile
+  // n_qtiles = {row 0, one row}, row constants -inf | 0: one ends every sweep (the loop is rotated: it finishes the last real
+  // step), a second one makes the iteration count even (the loop is unrolled by two), two more are read ahead by the last iterations
+  int* mtot_s = reinterpret_cast<int*>(dvm_s + DH);
+  if (tid == 0) {
+    int off = 0;
+    for (int kb = 0; kb < a.n_kblocks; kb++) {
+      int4 d = kbd_s[kb];
+      const int e_begin = d.z;
+      d.z = off;
+      if (live_s[kb]) off += ((d.w + 2) & ~1) + 2;
+      kbd_s[kb] = make_int4(d.x, d.y, d.z | (e_begin << 16), d.w);          // (record offset < 2^16, list offset < 2^15)
+    }
+    *mtot_s = off;
+  }
+  __syncthreads();
+  {          // (one flat pass: every thread's global read of its list entry is in flight at once)
+    const int total = *mtot_s;
+    for (int e = tid; e < total; e += 256) {
+      int kb = 0;
+      for (int k = 1; k < a.n_kblocks; k++) if ((kbd_s[k].z & 0xffff) <= e) kb = k;          // the LAST block whose records start at or before e
+      while (!live_s[kb]) kb--;          // (a dead block shares its offset with the next live one; block offsets ascend)
+      const int4 d = kbd_s[kb];
+      const int mo = d.z & 0xffff, e_begin = d.z >> 16, n_ent = d.w, i = e - mo;
+      const int qt = i < n_ent ? (int)(a.kb_qt[e_begin + i] & 0x7fffffffu) : a.n_qtiles;
+      const int2 qd = qtd_s[qt];
+      meta_s[e] = make_int2(qt | (((int)first_s[qt] == kb ? 1 : 0) << 16) | (((int)last_s[qt] == kb ? 2 : 0) << 16) | (qd.y << 20), qd.x);
+    }
   }
   __syncthreads();
   for (int qt = 0; qt < a.n_qtiles; qt++) {          // query tiles nobody visits: dq = 0
@@ -511,57 +556,108 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
   const unsigned STAGE_B = 2u * B1_STAGE_U16, KIMG_B = lds_b + 2u * B1P_NST * B1_STAGE_U16, DSIMG_B = KIMG_B + 2u * TKB * DH;
   const float dk_scale = 0.6931471805599453f;
 
-  for (int kbi = 0; kbi < a.n_kblocks; kbi++) {
-    if (!live_s[kbi]) continue;          // (uniform over the workgroup)
-    const int4 kd = reinterpret_cast<const int4*>(a.kb_desc)[kbi];
-    const int key_start = __builtin_amdgcn_readfirstlane(kd.x), n_keys = __builtin_amdgcn_readfirstlane(kd.y);
-    const int e_begin = __builtin_amdgcn_readfirstlane(kd.z), n_ent = __builtin_amdgcn_readfirstlane(kd.w);
-    // the NULL step(s): tile n_qtiles = {row 0, one row}, row constants -inf | 0.  One ends every sweep (the loop is rotated: it
-    // finishes the last real step); a second one makes the iteration count even (the loop is unrolled by two: no remainder copy
-    // of the body, at whose seams hipcc moved accumulators right ahead of the MFMAs that read them)
-    const int n_it = (n_ent + 2) & ~1;
-    // per-step records (one 16-byte LDS read per iteration, issued ahead of the barrier's own lgkmcnt(0) and carried in scalar
-    // registers from then on: separate reads of the list, the tile table and the visit flags each drained the LDS queue - with
-    // every fragment prefetch in it - four times per iteration)
-    for (int i = tid; i < n_it + 2; i += 256) {          // (two more null records: the loop reads record it + 2 unconditionally)
-      const int qt = i < n_ent ? (int)(a.kb_qt[e_begin + i] & 0x7fffffffu) : a.n_qtiles;
-      const int2 qd = qtd_s[qt];
-      meta_s[i] = make_int2(qt | (((int)first_s[qt] == kbi ? 1 : 0) << 16) | (((int)last_s[qt] == kbi ? 2 : 0) << 16) | (qd.y << 20), qd.x);
+  // ---- the key blocks of this (sample, head), software-pipelined ACROSS blocks: the next block's K image, first two stages and
+  // K / V fragments are requested right behind the barrier that ends a block's loop, ahead of that block's dK / dV epilogue (as a
+  // prologue of its own they were three memory latencies in a row per block, eleven blocks per workgroup)
+    // ---- staging of one step: five 1-KiB / 256-byte pieces per wavefront (Q and dO rows 16 w .. 16 w + 15, and one of: -lse, -delta,
+  // the two halves of the mask operand): every wavefront's vmcnt sees the same count
+  // per-lane byte offsets of this wavefront's two Q / dO pieces inside a tile (row 8 p + lane / 8, swizzled 16-byte chunk): the
+  // packed copies are read WITHOUT clamping to the tile's rows (rows past them belong to the next tile or to the 63 rows of
+  // slack behind the buffer: finite values behind row constants of -inf)
+  // piece P of a stage: 0 / 2 the two Q pieces of this wavefront, 1 / 3 the dO pieces, 4 its share of the row constants / mask operand
+  auto dma_piece = [&]<int P>(const int2& m, int st) __attribute__((always_inline)) {          // m: the step's record (scalar registers)
+    const unsigned sb_ = lds_b + (unsigned)st * STAGE_B;
+    int ln = lane;          // (offsets derived from the lane id HERE: hoisted out of the loop they were registers to spill)
+    asm volatile("" : "+v"(ln));
+    if (P < 4) {
+      constexpr int u = P >> 1;
+      const u16* rowp = ((P & 1) ? obase : qbase) + (int64_t)M_ROW0(m) * DH;
+      const int r = (wave * 2 + u) * 8 + (ln >> 3);
+      const unsigned o_dma = (unsigned)(r * 128 + (((ln & 7) ^ b1_swz(r)) << 4));
+      B1_DMA16(rowp, o_dma, sb_ + ((P & 1) ? 8192u : 0u) + (unsigned)(wave * 2 + u) * 1024u);
+    } else if (wave < 2) {
+      const float* rb = rowc_g + (int64_t)M_QT(m) * 128 + wave * 64;
+      B1_DMA4(rb, (unsigned)ln * 4u, sb_ + 16384u + (unsigned)wave * 256u);
+    } else {
+      const int r = (wave - 2) * 32 + (ln >> 1), nrows = M_ROWS(m);
+      const int row = M_ROW0(m) + (r < nrows ? r : nrows - 1);
+      B1_DMA16(a.qblk, (unsigned)row * 32u + (unsigned)(ln & 1) * 16u, sb_ + 16896u + (unsigned)(wave - 2) * 1024u);
     }
-
-    bf16x8 kf[2][4], vf[2][4], khf[2];
-    bool ok[2];
-    int keyrow[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++) {
-      const int slot = wave * 64 + kb * 32 + l31;
-      const bool valid = slot < n_keys;
-      const int key = key_start + (valid ? slot : n_keys - 1);
-      keyrow[kb] = valid ? key : -1;
-      ok[kb] = valid && kinfo_g[key] != 31;
-#pragma unroll
-      for (int s = 0; s < 4; s++) {
-        kf[kb][s] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * a.kv_ld + 16 * s + 8 * lh);
-        vf[kb][s] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * a.kv_ld + 16 * s + 8 * lh);
-      }
-      khf[kb] = *reinterpret_cast<const bf16x8*>(khot_g + (int64_t)key * 16 + 8 * lh);
-      if (!valid) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) khf[kb][j] = 0;
-        if (lh) khf[kb][7] = (short)0x3F80;
-      }
-    }
-    const bool wave_dead = !__any(ok[0] || ok[1]);
-    // (the mask operands exist HERE: left to hipcc, their selects sank to just ahead of the first inline-asm MFMA that reads them -
-    //  a vector write needs two wait states before an MFMA reads it, and hipcc pads nothing around inline asm: wrong scores on
-    //  some wavefronts)
-    asm volatile("" : "+v"(khf[0]), "+v"(khf[1]));
+  };
+  auto next_live = [&](int from) { int k = from; while (k < a.n_kblocks && !live_s[k]) k++; return k < a.n_kblocks ? k : -1; };
+  bf16x8 kf[2][4], vf[2][4], khf[2];
+  uint8_t kflag[2];          // (raw key flags: compared at the top of the block, so that the wait for them sits there)
+  int key_start = 0, n_keys = 0, meta_off = 0, n_ent = 0;
+  // everything of key block kb that comes from memory: K and V images (LDS-DMA, 8 + 8 pieces of 1 KiB: whole 128-byte rows - as
+  // fragment loads straight from memory, one 16-byte piece of its own row per lane, they were 64 cache lines per instruction and,
+  // with the epilogue's stores, more operations than the 63 a wavefront may have in flight: ~20,000 cycles per block), the stages
+  // of its first two steps (10 pieces; a key block has at least one real step and the null step), this wavefront's mask operand
+  // and key flags
+  auto issue_block = [&](const int kb) __attribute__((always_inline)) {
+    const int4 kd = kbd_s[kb];
+    key_start = __builtin_amdgcn_readfirstlane(kd.x); n_keys = __builtin_amdgcn_readfirstlane(kd.y);
+    meta_off = __builtin_amdgcn_readfirstlane(kd.z) & 0xffff; n_ent = __builtin_amdgcn_readfirstlane(kd.w);
 #pragma unroll
     for (int p = 0; p < 8; p++) {          // K image: wavefront w moves the rows of its own 64 slots
       const int r = wave * 64 + p * 8 + (lane >> 3);
       const int key = key_start + (r < n_keys ? r : n_keys - 1);
       B1_DMA16(kbase, (unsigned)key * (unsigned)(a.kv_ld * 2) + (unsigned)(((lane & 7) ^ b1_swz(r)) << 4), KIMG_B + (unsigned)(wave * 8 + p) * 1024u);
     }
+#pragma unroll
+    for (int p = 0; p < 8; p++) {          // V rows of the same slots, into this wavefront's own rows of the second dS^T image (free until the loop)
+      const int r = wave * 64 + p * 8 + (lane >> 3);
+      const int key = key_start + (r < n_keys ? r : n_keys - 1);
+      B1_DMA16(vbase, (unsigned)key * (unsigned)(a.kv_ld * 2) + (unsigned)(((lane & 7) ^ b1_swz(r)) << 4), DSIMG_B + 2u * TKB * TQ + (unsigned)(wave * 8 + p) * 1024u);
+    }
+    int2 r0 = meta_s[meta_off], r1 = meta_s[meta_off + 1];
+    r0 = make_int2(__builtin_amdgcn_readfirstlane(r0.x), __builtin_amdgcn_readfirstlane(r0.y));
+    r1 = make_int2(__builtin_amdgcn_readfirstlane(r1.x), __builtin_amdgcn_readfirstlane(r1.y));
+    dma_piece.template operator()<0>(r0, 0); dma_piece.template operator()<1>(r0, 0); dma_piece.template operator()<2>(r0, 0);
+    dma_piece.template operator()<3>(r0, 0); dma_piece.template operator()<4>(r0, 0);
+    dma_piece.template operator()<0>(r1, 1); dma_piece.template operator()<1>(r1, 1); dma_piece.template operator()<2>(r1, 1);
+    dma_piece.template operator()<3>(r1, 1); dma_piece.template operator()<4>(r1, 1);
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; kb2++) {          // (32-byte rows of consecutive keys: coalesced)
+      const int slot = wave * 64 + kb2 * 32 + l31;
+      const int key = key_start + (slot < n_keys ? slot : n_keys - 1);
+      khf[kb2] = *reinterpret_cast<const bf16x8*>(khot_g + (int64_t)key * 16 + 8 * lh);          // (raw: a slot without a key is fixed at the top of the block)
+      kflag[kb2] = kinfo_g[key];
+    }
+  };
+  int kbi = __builtin_amdgcn_readfirstlane(next_live(0));
+  if (kbi >= 0) issue_block(kbi);
+  while (kbi >= 0) {
+    B1_STAMP();          // 0: top of the block
+    const int n_it = (n_ent + 2) & ~1;          // (the real steps, the null step, and one more to make the count even)
+    const int2* meta_b = meta_s + meta_off;
+    const int ks_cur = key_start, nk_cur = n_keys;
+    // everything issue_block requested has arrived (and the previous block's epilogue stores have left)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {          // this wavefront's K / V operand fragments: rows of its own 64 slots of the two images
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; kb2++)
+#pragma unroll
+        for (int st = 0; st < 4; st++) {
+          const unsigned o = (unsigned)((wave * 64 + kb2 * 32) * 128) + 2u * (unsigned)b1_off(ln & 31, 2 * st + (ln >> 5));
+          kf[kb2][st] = LDS_R8(KIMG_B + o);
+          vf[kb2][st] = LDS_R8(DSIMG_B + 2u * TKB * TQ + o);
+        }
+    }
+    const bool wave_dead = !__any((wave * 64 + l31 < n_keys && kflag[0] != 31) || (wave * 64 + 32 + l31 < n_keys && kflag[1] != 31));
+    // (the mask operands exist HERE: left to hipcc, their selects sank to just ahead of the first inline-asm MFMA that reads them -
+    //  a vector write needs two wait states before an MFMA reads it, and hipcc pads nothing around inline asm: wrong scores on
+    //  some wavefronts)
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; kb2++)
+      if (!(wave * 64 + kb2 * 32 + l31 < n_keys)) {          // a slot past the block's keys: the padding group's one-hot (masked against every query)
+#pragma unroll
+        for (int j = 0; j < 8; j++) khf[kb2][j] = 0;
+        if (lh) khf[kb2][7] = (short)0x3F80;
+      }
+    asm volatile("" : "+v"(khf[0]), "+v"(khf[1]));
+    B1_STAMP();          // 1: the block's fragments and flags have arrived
     f32x16 dk[2][2], dv[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
@@ -576,33 +672,11 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       }
     }
 
-    // ---- staging of one step: five 1-KiB / 256-byte pieces per wavefront (Q and dO rows 16 w .. 16 w + 15, and one of: -lse, -delta,
-    // the two halves of the mask operand): every wavefront's vmcnt sees the same count
-    // per-lane byte offsets of this wavefront's two Q / dO pieces inside a tile (row 8 p + lane / 8, swizzled 16-byte chunk): the
-    // packed copies are read WITHOUT clamping to the tile's rows (rows past them belong to the next tile or to the 63 rows of
-    // slack behind the buffer: finite values behind row constants of -inf)
-    // piece P of a stage: 0 / 2 the two Q pieces of this wavefront, 1 / 3 the dO pieces, 4 its share of the row constants / mask operand
-    auto dma_piece = [&]<int P>(const int2& m, int st) __attribute__((always_inline)) {          // m: the step's record (scalar registers)
-      const unsigned sb_ = lds_b + (unsigned)st * STAGE_B;
-      int ln = lane;          // (offsets derived from the lane id HERE: hoisted out of the loop they were registers to spill)
-      asm volatile("" : "+v"(ln));
-      if (P < 4) {
-        constexpr int u = P >> 1;
-        const u16* rowp = ((P & 1) ? obase : qbase) + (int64_t)M_ROW0(m) * DH;
-        const int r = (wave * 2 + u) * 8 + (ln >> 3);
-        const unsigned o_dma = (unsigned)(r * 128 + (((ln & 7) ^ b1_swz(r)) << 4));
-        B1_DMA16(rowp, o_dma, sb_ + ((P & 1) ? 8192u : 0u) + (unsigned)(wave * 2 + u) * 1024u);
-      } else if (wave < 2) {
-        const float* rb = rowc_g + (int64_t)M_QT(m) * 128 + wave * 64;
-        B1_DMA4(rb, (unsigned)ln * 4u, sb_ + 16384u + (unsigned)wave * 256u);
-      } else {
-        const int r = (wave - 2) * 32 + (ln >> 1), nrows = M_ROWS(m);
-        const int row = M_ROW0(m) + (r < nrows ? r : nrows - 1);
-        B1_DMA16(a.qblk, (unsigned)row * 32u + (unsigned)(ln & 1) * 16u, sb_ + 16896u + (unsigned)(wave - 2) * 1024u);
-      }
-    };
+    // K image, stages 0 and 1 of this block have landed (older than the fragment loads waited for above); every wavefront is here
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();          // meta_s visible; every wavefront is past the previous block
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    B1_STAMP();          // 2: behind the block's first barrier
 
     // ---- pipeline state
     // (the dQ accumulators of two steps are the owned registers a[224:255]: buffer s & 1 receives the OLD partial of step s's tile
@@ -649,7 +723,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     // vector pipe is the scarce resource).
     // records of steps it + 1, it, it - 1, it - 2, in scalar registers
     const int null_rec = a.n_qtiles | (1 << 20);
-    int2 m1 = meta_s[1], m0 = meta_s[0], mp = make_int2(null_rec | (1 << 16), 0), mpp = make_int2(null_rec, 0);
+    int2 m1 = meta_b[1], m0 = meta_b[0], mp = make_int2(null_rec | (1 << 16), 0), mpp = make_int2(null_rec, 0);
     m1 = make_int2(__builtin_amdgcn_readfirstlane(m1.x), __builtin_amdgcn_readfirstlane(m1.y));
     m0 = make_int2(__builtin_amdgcn_readfirstlane(m0.x), __builtin_amdgcn_readfirstlane(m0.y));
 #define B1_STR_(X) #X
@@ -684,7 +758,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       }
     };
     unsigned st_c = lds_b, st_n = lds_b + STAGE_B, st_nn = lds_b + 2u * STAGE_B;          // stages of steps it, it + 1, it + 2
-    unsigned a_meta = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const int2*)meta_s + 16u;          // record it + 2
+    unsigned a_meta = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const int2*)meta_b + 16u;          // record it + 2
     // ONE loop body (every iteration, the first and the last included, runs it whole: the first on a neutral "previous step" -
     // scores of -inf, packed operands and fragments of zero: P = dS = 0 -, the last on the block's NULL step, whose row constants are
     // -inf.  Six specialised copies of a 500-register body made hipcc spill accumulators right behind the MFMAs that wrote them.)
@@ -830,14 +904,6 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       B1_SB();
     };
 
-    // (behind the lambdas that use the counters) the first two stages; K image and stage 0 landed
-    dma_piece.template operator()<0>(m0, 0); dma_piece.template operator()<1>(m0, 0); dma_piece.template operator()<2>(m0, 0);
-    dma_piece.template operator()<3>(m0, 0); dma_piece.template operator()<4>(m0, 0);          // (n_it >= 2: a key block has at least one real step and the null step)
-    dma_piece.template operator()<0>(m1, 1); dma_piece.template operator()<1>(m1, 1); dma_piece.template operator()<2>(m1, 1);
-    dma_piece.template operator()<3>(m1, 1); dma_piece.template operator()<4>(m1, 1);
-    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");          // (only stage 1's five pieces stay in flight)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
     if (!wave_dead) {
       // the first step's first block: row constants (into score set 0), mask operand, row fragments - the loop reads them an
       // iteration ahead; and the neutral previous step: block 3' scores of -inf (P = 0), packed operands of block 2' and every
@@ -864,6 +930,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
 #pragma unroll
           for (int e = 0; e < 8; e++) { trO[i][j][e] = 0; trQ[i][j][e] = 0; }
     }
+    B1_STAMP();          // 3: loop start
     // iterations 0 .. n_it - 1 (n_it even), parity of `it` as a template argument
     if (!wave_dead) {
       for (int it = 0; it < n_it; it += 2) { iter.template operator()<true, 0>(it); iter.template operator()<true, 1>(it + 1); }
@@ -872,6 +939,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     }
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");          // the last dK / dV MFMAs before the epilogue reads the accumulators
     B1_SB();
+    B1_STAMP();          // 4: loop end
     // an odd number of steps: the last one's dQ block (buffer 0, finished by the null iteration) has no iteration left to go out in
     if (n_ent & 1) {
       float* slot = acc_s + ((int64_t)M_QT(mpp) << 12);
@@ -885,31 +953,60 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       }
     }
 
-    // ---- the block's dK = ln 2 * dK^T, dV = dV^T + dvmean
+    // every wavefront is done with the K image, the stages and the dS^T images: the next block's memory traffic starts here
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (this block's dQ stores stay in flight)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    B1_STAMP();          // 5: behind the barrier that ends the block's loop
+    const int nxt = __builtin_amdgcn_readfirstlane(next_live(kbi + 1));
+    if (nxt >= 0) issue_block(nxt);
+    B1_STAMP();          // 6: the next block's memory traffic is requested
+
+    // ---- the block's dK = ln 2 * dK^T, dV = dV^T + dvmean, through this wavefront's own rows of the first dS^T image: a lane holds 8
+    // bytes of ITS key's row per register group - stored from the registers that was 64 cache lines per instruction (the epilogue
+    // took ~11,000 cycles per block); transposed through LDS (144-byte rows) a store instruction writes eight whole 128-byte rows.
+    // (a row slot without a key stores to the null tile's slot of dq_acc, which nobody reads: every lane issues every store)
+    {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const unsigned stg = DSIMG_B + (unsigned)wave * 8192u;          // (wave-local: no barrier, the LDS counter orders write -> read)
+      const unsigned w_off = stg + (unsigned)((ln & 31) * 144 + 8 * (ln >> 5)), r_off = stg + (unsigned)((ln >> 3) * 144 + (ln & 7) * 16);
+      u16* dummy = reinterpret_cast<u16*>(acc_s + ((int64_t)a.n_qtiles << 12)) + (ln & 31) * 64;          // (inside this wavefront's 4 KiB of the slot)
 #pragma unroll
-    for (int kb = 0; kb < 2; kb++) {
-      if (keyrow[kb] < 0) continue;
-      u16* dkp = a.dk + (int64_t)b * a.dkv_bstride + (int64_t)keyrow[kb] * a.dkv_ld + h * DH;
-      u16* dvp = a.dv + (int64_t)b * a.dkv_bstride + (int64_t)keyrow[kb] * a.dkv_ld + h * DH;
+      for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-      for (int n = 0; n < 2; n++)
+        for (int m = 0; m < 2; m++) {          // m = 0: dK, 1: dV
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const int d = n * 32 + 8 * g + 4 * lh;
-          uint2 pk;
-          pk.x = pack2bf(dk[kb][n][4 * g] * dk_scale, dk[kb][n][4 * g + 1] * dk_scale);
-          pk.y = pack2bf(dk[kb][n][4 * g + 2] * dk_scale, dk[kb][n][4 * g + 3] * dk_scale);
-          *reinterpret_cast<uint2*>(dkp + d) = pk;
-          const f32x4 dvm = *reinterpret_cast<const f32x4*>(dvm_s + d);
-          pk.x = pack2bf(dv[kb][n][4 * g] + dvm[0], dv[kb][n][4 * g + 1] + dvm[1]);
-          pk.y = pack2bf(dv[kb][n][4 * g + 2] + dvm[2], dv[kb][n][4 * g + 3] + dvm[3]);
-          *reinterpret_cast<uint2*>(dvp + d) = pk;
+          for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+              u32x2v pk;
+              if (m == 0) {
+                pk[0] = pack2bf(dk[kb][n][4 * g] * dk_scale, dk[kb][n][4 * g + 1] * dk_scale);
+                pk[1] = pack2bf(dk[kb][n][4 * g + 2] * dk_scale, dk[kb][n][4 * g + 3] * dk_scale);
+              } else {
+                const f32x4 dvm = *reinterpret_cast<const f32x4*>(dvm_s + n * 32 + 8 * g + 4 * lh);
+                pk[0] = pack2bf(dv[kb][n][4 * g] + dvm[0], dv[kb][n][4 * g + 1] + dvm[1]);
+                pk[1] = pack2bf(dv[kb][n][4 * g + 2] + dvm[2], dv[kb][n][4 * g + 3] + dvm[3]);
+              }
+              *LDS_P(u32x2v, w_off + (unsigned)(n * 64 + 16 * g)) = pk;
+            }
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const u32x4v v4 = *LDS_P(const u32x4v, r_off + (unsigned)(i * 8 * 144));
+            const int slot = wave * 64 + kb * 32 + i * 8 + (ln >> 3);
+            u16* base = (m == 0 ? a.dk : a.dv) + (int64_t)b * a.dkv_bstride + (int64_t)(ks_cur + slot) * a.dkv_ld + h * DH + (ln & 7) * 8;
+            *reinterpret_cast<u32x4v*>(slot < nk_cur ? base : dummy) = v4;
+          }
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the block's dK / dV and dQ stores stay in flight)
-    __builtin_amdgcn_s_barrier();          // every wavefront is done with the K image, the records and the stages
-    asm volatile("" ::: "memory");
+    B1_STAMP();          // 7: epilogue stores issued
+    B1_NOTE(n_it);
+    kbi = nxt;
   }
+#ifdef MCA_TRACE_BUILD
+  if (trace_on && lane == 0) mca_trace_attn_bwd1[1023] = (unsigned long long)tr_n;
+#endif
   for (int kbi = 0; kbi < a.n_kblocks; kbi++) {          // key blocks without a valid key in this sample: dK = 0, dV = dvmean
     if (live_s[kbi]) continue;
     const int4 kd = reinterpret_cast<const int4*>(a.kb_desc)[kbi];
@@ -927,7 +1024,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd1p_kernel(mca_attn_bwd1_args a
   extern __shared__ __attribute__((aligned(16))) u16 lds_dyn[];
   attn_bwd1p_body(a, dbg, lds_dyn);
 }
-#define B1P_LDS_BYTES ((B1P_NST * B1_STAGE_U16 + TKB * DH + 2 * TKB * TQ) * 2 + B1_MAX_LIST * 8 + B1_MAX_QT * 8 + 2 * B1_MAX_QT + B1_MAX_KB + DH * 4)
+#define B1P_LDS_BYTES ((B1P_NST * B1_STAGE_U16 + TKB * DH + 2 * TKB * TQ) * 2 + B1_MAX_META * 8 + B1_MAX_KB * 16 + B1_MAX_QT * 8 + 2 * B1_MAX_QT + B1_MAX_KB + DH * 4 + 16)
 
 #define B1_LDS_BYTES ((B1_NST * B1_STAGE_U16 + TKB * DH + 2 * TKB * TQ) * 2 + B1_MAX_LIST * 4 + 2 * B1_MAX_QT + B1_MAX_KB + DH * 4)
 
@@ -935,7 +1032,8 @@ extern "C" int mca_attn_bwd_onepass(const mca_attn_bwd1_args* a, mca_stream_t st
   if (!a || !a->q || !a->k || !a->v || !a->d_o || !a->rowc || !a->dvmean || !a->dq || !a->dk || !a->dv || !a->dq_acc) return MCA_E_BADARG;
   if (!a->keyinfo || !a->ktile_flags || !a->khot || !a->qblk || !a->qt_desc || !a->kb_desc || !a->kb_qt || !a->visit) return MCA_E_BADARG;
   if (a->batch <= 0 || a->heads <= 0 || a->n <= 0 || a->n_qtiles <= 0 || a->n_kblocks <= 0) return MCA_E_BADARG;
-  if (a->n_qtiles >= B1_MAX_QT || a->n_kblocks > B1_MAX_KB || a->max_list + 6 > B1_MAX_LIST) return MCA_E_UNSUPPORTED;          // (list + null steps + the two records read ahead)
+  if (a->n_qtiles >= B1_MAX_QT || a->n_kblocks > B1_MAX_KB || a->max_list + 6 > B1_MAX_LIST ||
+      a->n_entries + 4 * a->n_kblocks > B1_MAX_META) return MCA_E_UNSUPPORTED;          // (lists + null steps + the records read ahead)
   if (a->q_ld % 8 || a->kv_ld % 8 || a->o_ld % 8 || a->q_bstride % 8 || a->kv_bstride % 8 || a->o_bstride % 8 || a->q_hstride % 8 || a->o_hstride % 8) return MCA_E_ALIGN;
   if ((uintptr_t)a->q % 16 || (uintptr_t)a->k % 16 || (uintptr_t)a->v % 16 || (uintptr_t)a->d_o % 16 || (uintptr_t)a->khot % 16 || (uintptr_t)a->qblk % 16) return MCA_E_ALIGN;
   if (a->dq_ld % 8 || a->dq_bstride % 8 || (uintptr_t)a->dq % 16 || a->dkv_ld % 8 || a->dkv_bstride % 8 || (uintptr_t)a->dk % 16 || (uintptr_t)a->dv % 16) return MCA_E_ALIGN;

@@ -86,7 +86,8 @@ class _OnePassSched:
         self.kb_qt = _dev(s.kb_qt.astype(np.uint32).view(np.int32), device)
         self.visit, self.row_slot = _dev(s.visit.astype(np.uint8), device), _dev(s.row_slot.astype(np.int32), device)
         self.n_qt, self.n_kb, self.max_list = len(s.qt_desc), len(s.kb_desc), int(s.kb_desc[:, 3].max())
-        self.fits = self.n_qt < 256 and self.n_kb <= 64 and self.max_list + 6 <= 256          # the kernel's LDS tables
+        self.n_entries = int(len(s.kb_qt))
+        self.fits = self.n_qt < 256 and self.n_kb <= 64 and self.max_list + 6 <= 256 and self.n_entries + 4 * self.n_kb <= 512          # the kernel's LDS tables
 
 
 class _BlockSched:
@@ -592,7 +593,7 @@ class FusionEngine:
         a.dq_acc = ws["dq_acc"].data_ptr()
         a.keyinfo, a.ktile_flags, a.khot, a.qblk = ws["keyinfo"].data_ptr(), ws["kflags"].data_ptr(), ws["khot"].data_ptr(), self.qblk_attn.data_ptr()
         a.qt_desc, a.kb_desc, a.kb_qt, a.visit = sc.qt_desc.data_ptr(), sc.kb_desc.data_ptr(), sc.kb_qt.data_ptr(), sc.visit.data_ptr()
-        a.n_qtiles, a.n_kblocks, a.max_list = sc.n_qt, sc.n_kb, sc.max_list
+        a.n_qtiles, a.n_kblocks, a.max_list, a.n_entries = sc.n_qt, sc.n_kb, sc.max_list, sc.n_entries
         a.batch, a.heads, a.n, a.nk_pad, a.n_ktiles64 = b, self.H, N, self.nk_pad, (N + 63) // 64
         a.scale, a.flags = self.scale, self.attn_flags
         hip.set_tag("layer")

@@ -628,7 +628,13 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first, prescaled=True, spi
         outs = []
         for aligned in (True, False):
             sc_ = S_.build_onepass_schedule(qmask_np, st.kgroup, 64, 256, aligned)
-            got = _run_onepass(H, sc_, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean, keyinfo, kflags, khot, qblk)
+            too_big = len(sc_.qt_desc) >= 256 or len(sc_.kb_desc) > 64 or int(sc_.kb_desc[:, 3].max()) + 6 > 256 or len(sc_.kb_qt) + 4 * len(sc_.kb_desc) > 512
+            try:
+                got = _run_onepass(H, sc_, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean, keyinfo, kflags, khot, qblk)
+            except H.MCAHipError as exc:          # tables past the kernel's LDS budget: refused, the caller keeps the two-pass form
+                assert too_big and "unsupported" in str(exc), str(exc)
+                continue
+            assert not too_big
             for rep in got:
                 if torch.isnan(rep[0].float()).any() or torch.isnan(rep[1].float()).any():          # where: tile, wavefront block, sample
                     nq_, msg = torch.isnan(rep[0].float()), []
@@ -647,7 +653,8 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first, prescaled=True, spi
             d_q, d_k, d_v = rel(got[0][0].float(), ref2[0]), rel(got[0][1][:, :, D:2 * D].float(), ref2[1]), rel(got[0][1][:, :, 2 * D:].float(), ref2[2])
             assert d_q < 6e-3 and d_k < 6e-3 and d_v < 6e-3, f"one-pass vs two-pass: dq {d_q} dk {d_k} dv {d_v} (aligned={aligned})"
             outs.append(got[0])
-        assert rel(outs[0][0].float(), outs[1][0].float()) < 6e-3
+        if len(outs) == 2:
+            assert rel(outs[0][0].float(), outs[1][0].float()) < 6e-3
 
 
 def _run_onepass(H, sc, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean_ref, keyinfo, kflags, khot, qblk):
@@ -694,7 +701,7 @@ def _run_onepass(H, sc, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean_ref, keyin
         a1.dq_acc = acc.data_ptr()
         a1.keyinfo, a1.ktile_flags, a1.khot, a1.qblk = keyinfo.data_ptr(), kflags.data_ptr(), khot.data_ptr(), qblk.data_ptr()
         a1.qt_desc, a1.kb_desc, a1.kb_qt, a1.visit = qt_desc.data_ptr(), kb_desc.data_ptr(), kb_qt.data_ptr(), visit.data_ptr()
-        a1.n_qtiles, a1.n_kblocks, a1.max_list = nqt, nkb, int(sc.kb_desc[:, 3].max())
+        a1.n_qtiles, a1.n_kblocks, a1.max_list, a1.n_entries = nqt, nkb, int(sc.kb_desc[:, 3].max()), int(len(sc.kb_qt))
         a1.batch, a1.heads, a1.n, a1.nk_pad, a1.n_ktiles64 = b, heads, N, nk_pad, (N + 63) // 64
         a1.scale, a1.flags = 0.125, H.ATTN_Q_PRESCALED
         H.call("mca_attn_bwd_onepass", C.byref(a1), H.stream_ptr())
