@@ -451,9 +451,16 @@ MCA_TRACE_BUFFER(attn_bwd1)      // trace build, knob 9 bit 8: s_memtime stamps 
 #ifdef MCA_TRACE_BUILD
 #define B1_STAMP() do { if (trace_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) mca_trace_attn_bwd1[tr_n & 1023] = t_; tr_n++; } } while (0)
 #define B1_NOTE(V) do { if (trace_on) { if (lane == 0) mca_trace_attn_bwd1[tr_n & 1023] = (unsigned long long)(V); tr_n++; } } while (0)
+// inside the step loop: s_memtime into scalar registers (no wait at the stamp: read at the end of the iteration)
+#define B1_TR(K_) asm volatile("s_memtime %0" : "=s"(tr_t[K_]))
+#define B1_TR_END() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_t[6]) :: "memory");                      \
+                         if (trace_on && it == 8 && lane == 0) {                                                                 \
+                           for (int k_ = 0; k_ < 7; k_++) mca_trace_attn_bwd1[512 + tr_blk * 8 + k_] = tr_t[k_]; } } while (0)
 #else
 #define B1_STAMP() do {} while (0)
 #define B1_NOTE(V) do {} while (0)
+#define B1_TR(K_) do {} while (0)
+#define B1_TR_END() do {} while (0)
 #endif
 // a step's record {tile | (1 first, 2 last visit of the tile by this (sample, head)) << 16 | rows << 20, first row}
 #define M_QT(M) ((M).x & 0xffff)
@@ -481,7 +488,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef MCA_TRACE_BUILD
   const bool trace_on = lin == 0 && wave == 0 && (dbg & 8);
-  int tr_n = 0;
+  int tr_n = 0, tr_blk = 0;
 #endif
   const int l31 = lane & 31, lh = lane >> 5;
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
@@ -784,6 +791,9 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       const float* ld_base = acc_s + ((int64_t)M_QT(m0) << 12);
       unsigned ln16 = (unsigned)lane << 4;
       asm volatile("" : "+v"(ln16));
+#ifdef MCA_TRACE_BUILD
+      unsigned long long tr_t[7];
+#endif
       int2 m2s = m1;
       unsigned o_dma = 0;
       const u16 *qrow = qbase, *orow = obase;
@@ -898,6 +908,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
         a_rc += d_st; a_qb += d_st;
       }
       // the records move on: step it + 2's becomes step it + 1's, ...
+      B1_TR_END();
       mpp = mp; mp = m0; m0 = m1; m1 = m2s;
       { const unsigned t_ = st_c; st_c = st_n; st_n = st_nn; st_nn = t_; }
       a_meta += 8u;
@@ -1002,6 +1013,9 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     }
     B1_STAMP();          // 7: epilogue stores issued
     B1_NOTE(n_it);
+#ifdef MCA_TRACE_BUILD
+    tr_blk++;
+#endif
     kbi = nxt;
   }
 #ifdef MCA_TRACE_BUILD

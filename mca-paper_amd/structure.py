@@ -433,6 +433,9 @@ class EAOStructure:
     def attn_block_schedule(self, rows: int = 256, bk: int = 64) -> BlockSchedule:
         return build_block_schedule(self.qmask_attn, self.kgroup, rows, bk)
 
+    def attn_onepass_schedule(self, aligned: bool = True) -> OnePassSchedule:
+        return build_onepass_schedule(self.qmask_attn, self.kgroup, 64, 256, aligned)
+
     def dense_attn_mask(self) -> np.ndarray:
         """True = blocked (the block-diagonal complement), as FusionStructure.dense_attn_mask"""
         return ~(((self.qmask_attn[:, None] >> self.kgroup[None, :].astype(np.uint32)) & 1).astype(bool))

@@ -233,3 +233,32 @@ def test_training_helpers_match_their_reference_contract(pkg):
     assert gn.dtype == torch.float32 and abs(float(gn) - float(want)) < 1e-5
     want_all = torch.sqrt(sum((p.grad ** 2).sum() for p in ps))
     assert abs(float(get_grad_norm(net, skip_first=False)) - float(want_all)) < 1e-5
+
+
+def test_onepass_schedule_is_the_generated_one_and_hazard_free(tmp_path):
+    """The issue order of the one-pass attention backward's loop is GENERATED (tools/gen_bwd1_schedule.py): the committed .inc must
+    be what the generator writes, every MFMA of a step must be in it exactly once, and the compiled kernel must keep the distances
+    hipcc does not pad around inline asm (tools/audit_bwd1_isa.py: cross-compiles the file, no GPU needed)."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    gen = importlib.import_module("gen_bwd1_schedule")
+    slots, pos, placed = gen.build()
+    out = tmp_path / "sched.inc"
+    gen.emit(slots, str(out), placed["BARRIER()"])
+    committed = open(os.path.join(REPO, "mca-paper_amd", "csrc", "attention_bwd1_sched.inc")).read()
+    assert out.read_text() == committed, "attention_bwd1_sched.inc is stale: run python tools/gen_bwd1_schedule.py"
+    mf = [s["mfma"] for s in slots if s["mfma"]]
+    assert len(mf) == len(set(mf)) == 84          # 4 blocks x (1 mask + 4 + 4 score MFMAs) + 4 x 8 dV / dK + 16 dQ
+    fills = [f for s in slots for f in s["fill"]]
+    assert len(fills) == len(set(fills))
+    for nm in [f"ST({g})" for g in range(4)] + [f"LD({g})" for g in range(4)] + [f"DMA({p})" for p in range(5)] + ["BARRIER()"]:
+        assert nm in fills
+    assert "#define B1_W1_YOUNGER 7" in committed and "#define B1_W2_YOUNGER 17" in committed
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    audit = importlib.import_module("audit_bwd1_isa")
+    text = audit.compile_isa()
+    probs, n, n_asm = audit.audit(text)
+    assert n == n_asm and n > 150 and not probs, probs[:5]
+    probs2, n_owned = audit.audit_owned(text)
+    assert n_owned > 100 and not probs2, probs2[:5]

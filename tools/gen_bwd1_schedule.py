@@ -250,7 +250,7 @@ def guard_of(item):
     return "CUR && LIVE"
 
 
-def emit(slots, path):
+def emit(slots, path, placed_barrier):
     lines = ["// GENERATED by tools/gen_bwd1_schedule.py - do not edit.  One loop iteration of attn_bwd1p_kernel: MFMA slots and their fillers.",
              f"// {sum(1 for s in slots if s['mfma'])} matrix instructions; LAG {LAG}, LDS latency {LDS_LAT} slots, filler budget {BUDGET} cycles per slot"]
     # the iteration's vector-memory operations in issue order (an MFMA is emitted ahead of its slot's fillers)
@@ -267,8 +267,11 @@ def emit(slots, path):
     w1 = bar                                             # the previous iteration's DMA(4) landed: this iteration's operations stay in flight
     w2 = (len(vm) - 1 - vm.index("LD(3)")) + dqm0        # the previous iteration's LD(3) landed
     lines += [f"// vector-memory order: {' '.join(vm)}", f"#define B1_W1_YOUNGER {w1}", f"#define B1_W2_YOUNGER {w2}"]
+    marks = {0: 0, placed_barrier: 1, placed_barrier + 1: 2, 24: 3, 44: 4, 64: 5}          # trace build: s_memtime at the head of these slots
     for si, s in enumerate(slots):
         parts = []
+        if si in marks:
+            parts.append(f"B1_TR({marks[si]});")
         if s["mfma"]:
             parts.append(f"if ({guard_of(s['mfma'])}) {{ {s['mfma']}; }}")
         for f in s["fill"]:
@@ -282,7 +285,7 @@ def emit(slots, path):
 if __name__ == "__main__":
     sl, pos, placed = build()
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mca-paper_amd", "csrc", "attention_bwd1_sched.inc")
-    emit(sl, out)
+    emit(sl, out, placed["BARRIER()"])
     cost = [sum(COST[f.split("(")[0]] for f in s["fill"]) for s in sl]
     print(f"{len(sl)} slots, {sum(1 for s in sl if s['mfma'])} MFMAs; filler cycles per slot: max {max(cost[:-1])}, mean {sum(cost[:-1]) / (len(cost) - 1):.1f}; "
           f"tail slot {cost[-1]}; barrier at slot {placed['BARRIER()']} -> {out}")

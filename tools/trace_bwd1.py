@@ -40,3 +40,11 @@ for i in range(0, n - per + 1, per):
     steps += n_it
     print(f"  block {i // per:2d}: {n_it:3d} iterations, " + "  ".join(f"{nm}={v}" for nm, v in zip(names, d)) + f"  | per iteration {d[3] / max(n_it, 1):.0f}")
 print("totals:", {nm: v for nm, v in zip(names, tot)}, "iterations", steps, "loop cycles per iteration", round(tot[3] / max(steps, 1)))
+
+# one iteration (the ninth) of every block with more than eight: stamps at the head of slot 0 | the barrier's slot | the slot behind
+# it | slot 24 | 44 | 64 | end of the iteration
+print("inside iteration 8 of a block (cycles): slots 0..barrier | the barrier's slot | ..24 | ..44 | ..64 | ..end")
+for blk in range(n // per):
+    seg = t[512 + blk * 8: 512 + blk * 8 + 7]
+    if seg[0] and all(seg[k + 1] >= seg[k] for k in range(6)):
+        print(f"  block {blk:2d}: " + "  ".join(str(seg[k + 1] - seg[k]) for k in range(6)) + f"  | total {seg[6] - seg[0]}")
