@@ -89,6 +89,20 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guid
 # algorithmic GFLOP per sample per step, mask-aware, 2 flop/MAC, bwd = 2 x fwd
 STEP_GFLOP = {"cmu_mca": 334.8, "cmu_mma": 337.4, "long_mca": 885.7}
 PMC_JSON = os.path.join("profiles", "r05_hbm_traffic_pmc.json")
+MFMA_BUSY_JSON = os.path.join("profiles", "r05_mfma_busy_pmc.json")          # tools/sq_summary.py: matrix-pipe busy share per kernel
+
+
+def pmc_mfma_busy(kernel_key: str):
+    """Share of SIMD cycles the matrix pipe was executing in the dominant kernel, from the committed counter pass
+    (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), tools/sq_summary.py): the COUNTER beside the algorithmic
+    `frac` - busy cycles include recomputation, masked-out pairs of visited tiles and the mask product, and run at the throttled
+    clock, so mfma_busy >= frac x (2.4 GHz / actual clock).  None when no summary is committed for that kernel."""
+    names = {"mca_attn_bwd_onepass/layer": "attn_bwd1p_kernel", "mca_attn_fwd/layer": "attn_fwd4_kernel",
+             "mca_attn_bwd_dkv/layer": "attn_bwd_dkv_kernel", "mca_attn_bwd_dq/layer": "attn_bwd_dq_kernel"}
+    path = os.path.join(REPO, MFMA_BUSY_JSON)
+    if not os.path.exists(path) or kernel_key not in names:
+        return None
+    return json.load(open(path)).get(names[kernel_key])
 
 
 def pmc_traffic(kernel_key: str):
@@ -467,6 +481,7 @@ def main():
                                 # HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE of the committed PMC passes) or null
                                 "traffic": (tr or {}).get("bytes_per_launch"),
                                 "traffic_source": (tr or {}).get("source"),
+                                "mfma_busy": pmc_mfma_busy(dom[0]) if not long_seq and b == 32 else None,
                                 "avg_launch_us": round(ms / n * 1e3, 1), "alg_flops_per_launch": fl / n,
                                 "sampled_steps": sampled}
             line["kernels"] = kern

@@ -209,24 +209,17 @@ typedef struct {
   float scale;                      /* dim_head ** -0.5                                            */
   int flags;                        /* MCA_ATTN_* bits                                             */
   const uint16_t* khot;             /* optional (mca_build_keyhot): one-hot key groups, the mask as a matrix product */
-  /* optional QUERY-BLOCK schedule (needs khot): blocks of up to 256 query rows cut along the fusion structure, one workgroup
-   * each (4 wavefronts x 64 rows).  qb_desc[n_qblocks] = {first row, rows (1..256), first list entry, entries} in LAUNCH order
-   * (descending work), 16-byte aligned; qb_kt = per block its 64-key tiles | (structurally full << 31).  The blocks must cover
-   * every query row exactly once.  With it mca_attn_fwd runs the round-4 kernel (attention_fwd64.hip); without it (NULL) the
-   * 128-row-tile kernels, which also serve the pooling attention.  Same results up to rounding (the reference maximum of the
-   * online softmax moves lazily); lse, o and the uniform-row rule keep their meaning.                                     */
-  const int32_t* qb_desc; const uint32_t* qb_kt; int n_qblocks;
 } mca_attn_fwd_args;
 /* q already carries scale * log2(e) (folded into the bf16 copy of to_q.weight by mca_cast_pad_bf16_multi's per-tensor
  * scale): the kernels then take q.k as the log2-domain logit and never multiply a score.  lse, o, dq, dk, dv keep their
  * meaning (dq is the gradient w.r.t. the UNSCALED q, so the data- and weight-gradient GEMMs are unchanged).              */
 #define MCA_ATTN_Q_PRESCALED 1
-/* mca_attn_fwd only, optional: LAZY softmax reference.  The score accumulators start from -m (the MFMA C operand) and m moves
- * only when a score exceeds it by more than 12 (log2 units) or a row meets its first real key, instead of following every new
- * row maximum: a third fewer vector instructions per tile (CMU b = 32: 304 against 336 us per layer).  Same contract (o, lse,
- * uniform rows) and the same distance from the exact softmax (tests/test_kernels_gpu.py); P is rounded to bf16 against another
- * reference, so results differ from the default form by rounding (2-3e-3 rel-L2 of o).  Off by default: the gradient
- * statistics the step-level tests pin against the reference's own numbers were calibrated on the default form.           */
+/* mca_attn_fwd only: LAZY softmax reference.  The score accumulators start from -m (the MFMA C operand) and m moves only when
+ * a score exceeds it by more than 12 (log2 units) or a row meets its first real key, instead of following every new row maximum:
+ * a third fewer vector instructions per tile (CMU b = 32: 304 against 336 us per layer).  Same contract (o, lse, uniform rows) and
+ * the same distance from the exact softmax; P is rounded to bf16 against another reference, so results differ from the textbook
+ * form by rounding (2-3e-3 rel-L2 of o).  The engine sets it by default since round 5: over 8 data seeds x {MCA, MMA} the two
+ * forms are statistically indistinguishable in their distance to the fp64 oracle (profiles/r05_lazy_softmax_seed_study.txt).   */
 #define MCA_ATTN_LAZY_REFERENCE 2
 /* dim_head is fixed at 64; query tile 128 rows, key tile 64.                                     */
 int mca_attn_fwd(const mca_attn_fwd_args* args, mca_stream_t stream);

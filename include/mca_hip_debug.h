@@ -21,12 +21,11 @@ extern "C" {
  *    8 / 9  attention kernels (9 also the weight-gradient kernels), bit mask: 8 = s_memtime stamps / clock probe of the launch
  *       (trace build; gemm_tn_256x256_group_kernel in every build), 16 = launch order without the XCD remap, 32 = fp8 forward with
  *       register staging instead of LDS-DMA
- *   12  = 1: general LayerNorm kernels where the trunk forms would be chosen;   13  = 1: register-staged attention forward,
- *       = 2: the LDS-DMA forward (attn_fwd4_kernel) whatever the flags and schedules say, = 3: the query-block kernel
- *       (attention_fwd64.hip) whenever the caller supplies its schedule
+ *   12  = 1: general LayerNorm kernels where the trunk forms would be chosen
  *   14  > 0: cap on the workgroups of the LayerNorm backward kernels (default 256) and of mca_reduce_rows (default 512)
- *   15  = t + 1: the forward attention kernels move their lazy softmax reference when a score exceeds it by more than t
- *       log2 units (default 12; 1 = at every increase, the textbook online softmax) */
+ *   (13 and 15 selected / tuned the forward attention forms of round 4; gone with tools/overlays/fwd64)
+ *   one-pass attention backward (attention_bwd1.hip), knob 9: 8 = s_memtime stamps (trace build, tools/trace_bwd1.py), 16 = launch
+ *       order without the XCD remap, 64 = the plain (compiler-scheduled) kernel instead of the pipelined one (cross-check) */
 int mca_debug_set(int key, int value);
 /* every knob back to 0 */
 int mca_debug_reset(void);

@@ -9,14 +9,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmca_hip.so")
-SOURCES = ["elementwise.hip", "gemm.hip", "attention_fwd.hip", "attention_fwd64.hip", "attention_bwd2.hip", "attention_bwd1.hip", "attention_fp8.hip", "loss.hip", "optim.hip"]
+SOURCES = ["elementwise.hip", "gemm.hip", "attention_fwd.hip", "attention_bwd2.hip", "attention_bwd1.hip", "attention_fp8.hip", "loss.hip", "optim.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++20", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 # per-file extras: keep the attention accumulators in VGPRs (the softmax VALU works on them in place; the default
 # AGPR form costs 256 v_accvgpr moves per key tile)
 EXTRA = {"attention_fwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attention_bwd2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
          "attention_fp8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
          # hand-placed issue order: the SLP vectoriser packs adjacent f32 adds into v_pk_add_f32 and moves whole groups with them
-         "attention_fwd64.hip": ["-fno-slp-vectorize"],
          # generated issue order (attention_bwd1_sched.inc): keep single-instruction multiplies single
          "attention_bwd1.hip": ["-fno-slp-vectorize"]}
 

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd4_kernel(mca_attn_fwd_args a, 
 // =====================================================================================================
 // The LDS-DMA kernel with a LAZY softmax reference (MCA_ATTN_LAZY_REFERENCE; round 4): same tiling, staging and mask product as
 // attn_fwd4_kernel, but the score accumulators start from -m (the MFMA C operand) and m moves only in a rare wave-uniform slow
-// path (attention_fwd64.hip explains the rule).  Per 32 x 64 block that removes 32 subtractions, the 32 multiplies that rescale
+// path.  Per 32 x 64 block that removes 32 subtractions, the 32 multiplies that rescale
 // O, the exponential of the rescale factor and both cross-lane exchanges of the online softmax: a third of the vector
 // instructions of a loop that is bound by vector issue.  16 registers more (-m): three wavefronts per SIMD instead of four,
 // which this kernel does not notice (round 3: 338.5 us with three against 338.6 with four).  Results differ from
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd4l_kernel(mca_attn_fwd_args a,
   for (int n = 0; n < 2; n++)
 #pragma unroll
     for (int r = 0; r < 16; r++) o[n][r] = 0.f;
-  // lazy reference maximum (attention_fwd64.hip's rule): the S^T accumulators START from -m, so the scores leave the matrix pipe as
+  // lazy reference maximum : the S^T accumulators START from -m, so the scores leave the matrix pipe as
   // S - m; m moves only when a score exceeds it by more than thr, or when a row that has accumulated nothing meets its first
   // REAL key (blocked scores, -32768 from the mask product, never set it); l_run is this LANE's share of the row sum
   f32x16 negm;
@@ -738,8 +738,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd4l_kernel(mca_attn_fwd_args a,
   }
 }
 
-int mca_attn_fwd64_launch(const mca_attn_fwd_args* a, hipStream_t stream, int dbg);          // attention_fwd64.hip
-
 extern "C" int mca_attn_fwd(const mca_attn_fwd_args* a, mca_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->o || !a->lse || !a->qmask || !a->keyinfo || !a->ktile_flags || !a->q_ptr ||
       !a->q_kt || !a->q_order || !a->vmean)
@@ -754,17 +752,14 @@ extern "C" int mca_attn_fwd(const mca_attn_fwd_args* a, mca_stream_t stream) {
   if (a->heads > 65535 || a->batch > 65535 || a->n_ktiles > MAX_KTILES) return MCA_E_UNSUPPORTED;
   const dim3 grid(a->n_qtiles, a->heads, a->batch);
   if (!(a->flags & MCA_ATTN_Q_PRESCALED)) return MCA_E_UNSUPPORTED;          // (the un-prescaled forms left the library in round 3)
-  // production: the LDS-DMA kernel (needs the mask product's one-hot operand and 32-bit tile offsets); structures with more
-  // than 15 key groups (no khot) take the register-staged kernel with the element-wise mask.  knob 13 = 1 forces the latter (A/B)
+  // production: the LDS-DMA kernels (they need the mask product's one-hot operand and 32-bit tile offsets) - with the lazy softmax
+  // reference when the caller asks for it (the engine's default since round 5: profiles/r05_lazy_softmax_seed_study.txt); structures
+  // with more than 15 key groups (no khot) take the register-staged kernel with the element-wise mask
   if ((uintptr_t)a->khot % 16) return MCA_E_ALIGN;
-  // round-4 structure, taken when the caller supplies the query-block schedule: blocks of up to 256 rows, one wavefront per
-  // SIMD (knob 13 = 2 forces the 128-row-tile kernel: A/B).  The engine does not supply it by default (MCA_DEBUG=fwd64=1 does).
-  if (a->qb_desc && a->khot && (mca_knobs[13] == 0 || mca_knobs[13] == 3) && (int64_t)a->kv_ld * 64 < (1ll << 30))
-    return mca_attn_fwd64_launch(a, as_stream(stream), mca_knobs[9]);
-  if (a->khot && (a->flags & MCA_ATTN_LAZY_REFERENCE) && mca_knobs[13] == 0 && (int64_t)a->kv_ld * 64 < (1ll << 30))
-    hipLaunchKernelGGL(attn_fwd4l_kernel, grid, dim3(256), 0, as_stream(stream), *a, mca_knobs[9],
-                       mca_knobs[15] > 0 ? (float)(mca_knobs[15] - 1) : 12.f);
-  else if (a->khot && mca_knobs[13] != 1 && (int64_t)a->kv_ld * 64 < (1ll << 30))
+  const bool dma = a->khot && (int64_t)a->kv_ld * 64 < (1ll << 30);
+  if (dma && (a->flags & MCA_ATTN_LAZY_REFERENCE))
+    hipLaunchKernelGGL(attn_fwd4l_kernel, grid, dim3(256), 0, as_stream(stream), *a, mca_knobs[9], 12.f);
+  else if (dma)
     hipLaunchKernelGGL(attn_fwd4_kernel, grid, dim3(256), 0, as_stream(stream), *a, mca_knobs[9]);
   else
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, as_stream(stream), *a, mca_knobs[9] | mca_knobs[8]);

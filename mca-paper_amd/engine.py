@@ -46,10 +46,10 @@ def debug_options() -> dict:
     """The engine's A/B switches, all behind ONE environment variable: ``MCA_DEBUG=key=value,key=value``.  Production runs set
     none of them.  overlap_wgrad=0|1 (weight-gradient GEMMs on a side stream: default by size), group_wgrad=0 (one launch per
     weight gradient instead of one per layer), mask_mfma=0 (element-wise attention mask instead of the mask product),
-    dkv_keys=256 (8-wavefront key blocks in the dK/dV pass), fwd64=1 (the round-4 query-block forward attention kernel,
-    attention_fwd64.hip, instead of the 128-row-tile one: correct, measured 24 % slower), lazy_softmax=1
-    (MCA_ATTN_LAZY_REFERENCE: the forward attention's softmax reference moves lazily, -9 % on that kernel).  Kernel-level knobs: include/mca_hip_debug.h (hip.knobs)."""
-    opts = {"overlap_wgrad": None, "group_wgrad": True, "mask_mfma": True, "dkv_keys": 128, "fwd64": False, "lazy_softmax": False,
+    dkv_keys=256 (8-wavefront key blocks in the dK/dV pass), lazy_softmax=0 (the textbook running-maximum recurrence in the forward
+    attention instead of MCA_ATTN_LAZY_REFERENCE, the default since round 5: -9 % on that kernel, statistically indistinguishable
+    from the textbook form over 8 data seeds, profiles/r05_lazy_softmax_seed_study.txt).  Kernel-level knobs: include/mca_hip_debug.h (hip.knobs)."""
+    opts = {"overlap_wgrad": None, "group_wgrad": True, "mask_mfma": True, "dkv_keys": 128, "lazy_softmax": True,
             "onepass": None}          # onepass=0|1: the one-pass attention backward (attention_bwd1.hip); default: by size
     for item in filter(None, os.environ.get("MCA_DEBUG", "").split(",")):
         k, _, v = item.partition("=")
@@ -88,16 +88,6 @@ class _OnePassSched:
         self.n_qt, self.n_kb, self.max_list = len(s.qt_desc), len(s.kb_desc), int(s.kb_desc[:, 3].max())
         self.n_entries = int(len(s.kb_qt))
         self.fits = self.n_qt < 256 and self.n_kb <= 64 and self.max_list + 6 <= 256 and self.n_entries + 4 * self.n_kb <= 512          # the kernel's LDS tables
-
-
-class _BlockSched:
-    """device copies of a structure.BlockSchedule (query blocks of the round-4 forward attention kernel)"""
-
-    def __init__(self, s, device):
-        self.s = s
-        self.desc = _dev(s.desc.astype(np.int32), device)
-        self.kt = _dev(s.kt.astype(np.uint32).view(np.int32), device)
-        self.n = int(s.desc.shape[0])
 
 
 class FusionEngine:
@@ -226,8 +216,6 @@ class FusionEngine:
             return torch.from_numpy(np.where(bits == 1, 0.0, -32768.0).astype(np.float32)).to(torch.bfloat16).to(dev).contiguous()
         self.qblk_attn, self.qblk_pool = qblk_of(st.qmask_attn), qblk_of(st.qmask_pool)
         self.sched_attn_f = _Sched(st.attn_schedule(FWD_BQ, FWD_BK), dev)
-        # query blocks cut along the structure: the forward kernel of attention_fwd64.hip (needs the mask product); opt-in
-        self.bsched_attn = _BlockSched(st.attn_block_schedule(256, FWD_BK), dev) if (self.mask_mfma and self.dbg["fwd64"]) else None
         # key-block size of the dkv pass: 128 (4 wavefronts, two independent workgroups per CU) is 3 % faster than 256 (8 wavefronts,
         # one workgroup per CU) at N = 2538 and equal at N = 6088
         dkv_keys = self.dbg["dkv_keys"]
@@ -498,8 +486,6 @@ class FusionEngine:
         a.batch, a.heads, a.nq, a.nk, a.nk_pad = b, self.H, nq, N, self.nk_pad
         a.n_qtiles, a.n_ktiles, a.scale, a.flags = sched.s.n_q, sched.s.n_k, self.scale, self.attn_flags
         a.khot = ws["khot"].data_ptr() if ws.get("khot") is not None else None
-        if self.bsched_attn is not None and sched is self.sched_attn_f and a.khot:
-            a.qb_desc, a.qb_kt, a.n_qblocks = self.bsched_attn.desc.data_ptr(), self.bsched_attn.kt.data_ptr(), self.bsched_attn.n
         # mean(V) is the output of fully masked rows only: samples with every modality present have none and are skipped
         if ws.get("present_cur") is not None:
             call("mca_attn_vmean_if_needed", a.v, a.kv_bstride, a.kv_ld, ws["vmean"].data_ptr(), b, N, self.H, ptr(ws["present_cur"]),

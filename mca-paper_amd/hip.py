@@ -64,7 +64,6 @@ class AttnFwdArgs(C.Structure):
         ("batch", C.c_int), ("heads", C.c_int), ("nq", C.c_int), ("nk", C.c_int), ("nk_pad", C.c_int),
         ("n_qtiles", C.c_int), ("n_ktiles", C.c_int), ("scale", C.c_float), ("flags", C.c_int),
         ("khot", C.c_void_p),
-        ("qb_desc", C.c_void_p), ("qb_kt", C.c_void_p), ("n_qblocks", C.c_int),
     ]
 
 

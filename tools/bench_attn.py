@@ -41,7 +41,11 @@ def bwd8():
 def bwd1():
     eng.dbg["onepass"] = True; bwd(); eng.dbg["onepass"] = False
 eng.dbg["onepass"] = False          # "bwd" = the two-pass form; "bwd one-pass" = attention_bwd1.hip
-cases = [("fwd", fwd, {}), ("fwd register-staged (3 wavefronts per SIMD)", fwd, {13: 1}), ("fwd fp8", fwd8, {}), ("fwd fp8 register-staged", fwd8, {9: 32}), ("bwd", bwd, {}), ("bwd one-pass", bwd1, {}), ("bwd fp8", bwd8, {})]
+def fwd_tb():
+    fl = eng.attn_flags; eng.attn_flags = H.ATTN_Q_PRESCALED; fwd(); eng.attn_flags = fl
+def fwd_rs():
+    kh = ws.pop("khot"); fwd_tb(); ws["khot"] = kh
+cases = [("fwd (lazy softmax reference: production)", fwd, {}), ("fwd textbook recurrence", fwd_tb, {}), ("fwd register-staged (3 wavefronts per SIMD)", fwd_rs, {}), ("fwd fp8", fwd8, {}), ("fwd fp8 register-staged", fwd8, {9: 32}), ("bwd", bwd, {}), ("bwd one-pass", bwd1, {}), ("bwd fp8", bwd8, {})]
 if os.environ.get("MCA_BENCH_ATTN_ONLY"):
     cases = [c for c in cases if c[0] == os.environ["MCA_BENCH_ATTN_ONLY"]]
 if os.environ.get("MCA_BENCH_ATTN_ABLATE"):          # the one-pass backward alone: pipelined and plain kernel (knob 9 bit 64)

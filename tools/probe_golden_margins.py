@@ -5,8 +5,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 from util_small import run_native_step, rel_err
 P = importlib.import_module("mca-paper_amd")
-if os.environ.get("K13"):          # forward form: 2 = the lazy-maximum reference form
-    importlib.import_module("mca-paper_amd.hip").lib().mca_debug_set(13, int(os.environ["K13"]))
+# (forward attention form: MCA_DEBUG=lazy_softmax=0 for the textbook recurrence; the lazy reference is the default)
 G = os.path.join(root, "tests", "golden")
 for case in ("cmu_mca_b2", "cmu_mma_d40_b2", "tcga_b2"):
     rec = torch.load(os.path.join(G, case + ".pt"), weights_only=False)

@@ -7,7 +7,7 @@ from util_small import small_config, run_native_step, run_oracle_step, rel_err
 P = importlib.import_module("mca-paper_amd")
 O = importlib.import_module("oracle.mca_oracle")
 H = importlib.import_module("mca-paper_amd.hip")
-H.lib().mca_debug_set(13, int(os.environ.get("K13", "0")))          # 2: lazy-reference second-form forward
+# (forward attention form: MCA_DEBUG=lazy_softmax=0 for the textbook recurrence; the lazy reference is the default)
 for variant, p_drop in [("mca", 0.0), ("mca", 0.35), ("zorro", 0.35), ("bimodal", 0.35), ("tab", 0.35)]:
     cfg = small_config(variant)
     batch = P.data.synthetic_batch(cfg, 6, seed=5, p_drop=p_drop)

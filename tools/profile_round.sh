@@ -14,7 +14,7 @@ run rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OUT/fetch
 run rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OUT/write" -o t -- python3 $B --launch eager --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --sustain-seconds 0 &&
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_long" -o t -- python3 $B --launch eager --workload long --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --sustain-seconds 0 &&
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_long_fp8" -o t -- python3 $B --launch eager --workload long --attn fp8 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --sustain-seconds 0 &&
-run rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES -d "$OUT/sq" -o t -- python3 $ROOT/tools/bench_attn.py 32
+run rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/sq" -o t -- python3 $ROOT/tools/bench_attn.py 32
 cd "$ROOT"
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_same_box.json" 2> "$OUT/bench_same_box.err"
 # keep only the summaries (the traces are tens of MB)
