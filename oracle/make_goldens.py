@@ -298,6 +298,44 @@ def make_cmu(refmodel):
         print(f"cmu_{case}: loss {float(rec['loss']):.5f}")
 
 
+def make_cmu_autocast(refmodel):
+    """The reference's OWN bf16 behaviour at CMU shape, b = 2: the cases of make_cmu with the forward under
+    torch.autocast("cpu", torch.bfloat16) - what Accelerate's mixed_precision="bf16" does to it (reference model.py:448-478 runs
+    unchanged; the loss and the backward see the autocast graph).  Stored beside the fp32 goldens: pooled embeddings, loss terms,
+    per-tensor gradient norms.  The GPU tests bound the native step's distance to the fp32 golden by 2 x the reference's own
+    bf16-vs-fp32 distance, per quantity."""
+    import importlib
+    sys.path.insert(0, REPO)
+    pkg = importlib.import_module("mca-paper_amd")
+    for case, (zorro, p_drop) in {"mca": (False, 0.0), "mma_d40": (True, 0.4)}.items():
+        cfg = pkg.config.cmu_model_config(batch_size=2, zorro=zorro)
+        torch.manual_seed(43)
+        real_save = torch.save
+        torch.save = lambda *a, **k: None
+        try:
+            model = refmodel.MCA(**cfg)
+            sd = pkg.params.init_state_dict(cfg, seed=43)
+            missing = model.load_state_dict(sd, strict=False)
+            assert not missing.unexpected_keys, missing
+            batch = pkg.data.synthetic_batch(cfg, batch_size=2, seed=1234, p_drop=p_drop, lengths="uniform")
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out = model(batch)
+            out["loss"].float().backward()
+        finally:
+            torch.save = real_save
+        names = list(cfg["encoder_configs"].keys())
+        rec = {
+            "case": case, "seed": 43, "data_seed": 1234, "p_drop": p_drop, "autocast": "cpu bfloat16",
+            "pooled": torch.stack([out[n] for n in names] +
+                                  ([out[k] for k in model.fusion_combos] if (cfg["fcl"] and not zorro) else [out["fusion"]]), 1).detach().float(),
+            "losses": {k: v.detach().float() for k, v in out["losses"].items()},
+            "loss": out["loss"].detach().float(),
+            "grad_norms": {n: float(p.grad.float().norm()) for n, p in model.named_parameters()},
+        }
+        torch.save(rec, os.path.join(GOLD, f"cmu_{case}_b2_autocast.pt"))
+        print(f"cmu_{case} under autocast: loss {float(rec['loss']):.5f}")
+
+
 def make_tcga(refmodel):
     """TCGA_config1-shaped run (4 TabularEncoder modalities, N = 2548, 60 loss terms) at b=2 through the reference."""
     import importlib
@@ -446,7 +484,7 @@ def make_collators(refenc):
     print("wrote collators.pt")
 
 
-FLAGS = ("collators", "tcga", "cmu", "init", "tiny", "ckpt", "eao")
+FLAGS = ("collators", "tcga", "cmu", "cmu_autocast", "init", "tiny", "ckpt", "eao")
 
 
 if __name__ == "__main__":
@@ -491,3 +529,5 @@ if __name__ == "__main__":
         make_init_parity(refmodel)
     elif flag == "cmu":
         make_cmu(refmodel)
+    elif flag == "cmu_autocast":
+        make_cmu_autocast(refmodel)

@@ -58,6 +58,7 @@ def test_dp2_native_matches_oracle_objective(tmp_path):
     for p in params.values():
         p.requires_grad_(True)
     full = P.data.synthetic_batch(cfg, b * W, seed=21, p_drop=0.3)
+    keep = {}
     def dp_objective(mode):
         """gradient of (1 / W) sum_r loss_r on the concatenated batch, in the oracle's precision mode `mode`"""
         for p in params.values():
@@ -65,6 +66,7 @@ def test_dp2_native_matches_oracle_objective(tmp_path):
         Pr = O.Prec(mode)
         tokens, padding, sample_mask = O.encode_and_pack(S, sd, full, Pr)
         pooled = O.mca_trunk(S, sd, tokens, padding, Pr)
+        keep["pooled"] = pooled
         tot, loss0 = 0, None
         for r in range(W):
             sm = {n: sample_mask[n][r * b:(r + 1) * b] for n in names}
@@ -75,7 +77,10 @@ def test_dp2_native_matches_oracle_objective(tmp_path):
         return float(loss0), {n: p.grad.detach().clone() for n, p in params.items() if p.grad is not None}
     loss_emu, g_emu = dp_objective("bf16emu")
     loss0, g_ref = dp_objective("fp32")
-    assert abs(got["loss"] - loss0) < 0.03 * abs(loss0) + 0.05
+    # (the single-GPU loss bound of tests/test_step_gpu.py: the loss is a difference of logits, its error scales with their size)
+    pf = keep["pooled"].detach().double()
+    scale = max(float((pf[:, i] @ pf[:, j].t()).abs().max()) for i in range(pf.shape[1]) for j in range(pf.shape[1])) * float(torch.exp(sd["loss.loss_fn.logit_scale"].detach().double()))
+    assert abs(got["loss"] - loss0) <= 1e-4 * scale + 1e-4, (got["loss"], loss0, scale)
     # the single-GPU bound (tests/test_step_gpu.py): no worse than bf16 arithmetic itself, i.e. within a few x the distance of
     # the bf16-EMULATING oracle from the fp32 one, per tensor; median 3 %  (round 3 asserted a blanket 25 % / 5 %)
     errs = []

@@ -159,6 +159,22 @@ def test_cmu_b2_vs_reference_golden(P, case):
           f"p90 {rels[int(len(rels) * 0.9)]:.2e}, max {rels[-1]:.2e}")
     assert not bad, bad[:8]
     assert rels[len(rels) // 2] < TOL_GRADNORM_CMU_MEDIAN and rels[int(len(rels) * 0.9)] < TOL_GRADNORM_CMU_P90
+    # ---- against the reference's OWN bf16 behaviour: the same case run by the reference under torch.autocast("cpu", bfloat16)
+    # (tests/golden/cmu_*_b2_autocast.pt, oracle/make_goldens.py --cmu_autocast; reference model.py:448-478).  Per quantity, the
+    # native step's distance to the fp32 golden is at most 2 x the reference's own bf16-vs-fp32 distance.
+    ac = torch.load(os.path.join(GOLDEN, f"cmu_{case}_b2_autocast.pt"), weights_only=False)
+    d_pooled_ref = rel_err(ac["pooled"], rec["pooled"])
+    d_loss_ref, d_loss_nat = abs(float(ac["loss"]) - float(rec["loss"])), abs(nat["loss"] - float(rec["loss"]))
+    terms = [k for k, v in rec["losses"].items() if torch.isfinite(v) and torch.isfinite(ac["losses"][k])]
+    d_term_ref = max(abs(float(ac["losses"][k]) - float(rec["losses"][k])) for k in terms)
+    d_term_nat = max(abs(nat["losses"][k] - float(rec["losses"][k])) for k in terms)
+    rels_ref = sorted(abs(ac["grad_norms"][n] - g) / g for n, g in rec["grad_norms"].items() if g >= 1e-12 and not n.endswith("logit_scale"))
+    q = lambda v: (v[len(v) // 2], v[int(len(v) * 0.9)], v[-1])
+    print(f"cmu_{case}_b2 native | reference under bf16 autocast (distance to the fp32 golden): pooled {e:.2e} | {d_pooled_ref:.2e}; "
+          f"loss {d_loss_nat:.3f} | {d_loss_ref:.3f}; worst loss term {d_term_nat:.3f} | {d_term_ref:.3f}; gradient norms median / p90 / max "
+          f"{q(rels)[0]:.2e} / {q(rels)[1]:.2e} / {q(rels)[2]:.2e} | {q(rels_ref)[0]:.2e} / {q(rels_ref)[1]:.2e} / {q(rels_ref)[2]:.2e}")
+    assert e <= 2 * d_pooled_ref and d_loss_nat <= 2 * d_loss_ref and d_term_nat <= 2 * d_term_ref
+    assert all(a_ <= 2 * b_ for a_, b_ in zip(q(rels), q(rels_ref))), (q(rels), q(rels_ref))
 
 
 def test_tcga_shape_b2_vs_oracle(P):
