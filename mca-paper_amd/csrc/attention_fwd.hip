@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(mca_attn_fwd_args a, int 
 // CU instead of three (39.4 KB of LDS each).  Measured against attn_fwd_kernel on one box (tools/bench_attn.py): b = 32
 // unpadded 433 -> 420 us, padded 254 -> 238 us, b = 8 127 -> 109 us; the fourth wavefront per SIMD buys 3 % where the
 // chip is full and 14 % where it is not: the loop is bound by vector / matrix ISSUE per SIMD, not by latency.
-// Same arithmetic in the same order as attn_fwd_kernel: the two give the same bits (tests/test_kernels_gpu.py).
+// Same arithmetic in the same order as attn_fwd_kernel: the two give the same bits (tests/test_attention_gpu.py).
 // =====================================================================================================
 __global__ __launch_bounds__(256, 4) void attn_fwd4_kernel(mca_attn_fwd_args a, int dbg) {
   __shared__ __attribute__((aligned(16))) u16 lds[2 * 2 * AK * DH + 2 * AK * 16];   // K, V double-buffered (32 KiB) + one-hot tiles (4 KiB)

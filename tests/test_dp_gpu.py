@@ -1,17 +1,17 @@
-"""DP path end-to-end with the REAL kernels: 2 ranks (gloo backend, both on cuda:0 — the test box has one GPU; on a
-node the backend is RCCL) run the native step through mca-paper_amd/dp.py; the averaged gradients must equal the
-oracle's gradient of (1/W) sum_r loss_r on the concatenated batch (bf16 tolerance)."""
+"""GPU tests of the data-parallel step: two ranks on one GPU against the oracle's objective on the concatenated batch, and against a
+native single-process run of the same objective."""
 import copy
 import importlib
 import os
-import socket
-
 import pytest
+import socket
+import sys
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from util_small import small_config, rel_err, to_device
+from conftest import GOLDEN, REPO
 
 pytestmark = pytest.mark.gpu
 
@@ -38,6 +38,39 @@ def _worker(rank, world, port, out):
         if rank == 0:
             torch.save({"grads": {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()},
                         "loss": float(outp["loss"])}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def P():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return importlib.import_module("mca-paper_amd")
+
+
+# ------------------------------------------------------------------------------------------------ data parallel
+def _dp_worker(rank, world, port, out, p_drop):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P = importlib.import_module("mca-paper_amd")
+        dpm = importlib.import_module("mca-paper_amd.dp")
+        cfg = small_config("mca")
+        b = 4
+        sd = P.params.init_state_dict(cfg, seed=3)
+        full = P.data.synthetic_batch(cfg, b * world, seed=21, p_drop=p_drop)
+        local = {k: {kk: vv[rank * b:(rank + 1) * b] for kk, vv in v.items()} for k, v in full.items()}
+        model = P.MCA(**copy.deepcopy(cfg))
+        model.load_state_dict(sd, strict=False)
+        model = model.cuda()
+        dp = dpm.DataParallelMCA(model)
+        outp = dp(to_device(local, "cuda"))
+        outp["loss"].backward()
+        dp.finish_backward()
+        torch.cuda.synchronize()
+        torch.save({"grads": {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()},
+                    "loss": float(outp["loss"])}, out + f".{rank}")
     finally:
         dist.destroy_process_group()
 
@@ -91,3 +124,44 @@ def test_dp2_native_matches_oracle_objective(tmp_path):
         assert e < 4 * e_emu + 2e-2, (n, e, e_emu)
         errs.append((e, n))
     assert sorted(e for e, _ in errs)[len(errs) // 2] < 0.03, (max(errs), sorted(e for e, _ in errs)[len(errs) // 2])
+
+
+def test_dp2_native_equals_single_process_objective(P, tmp_path):
+    """Two ranks (gloo, both on this GPU) through dp.py + the real kernels against ONE native process that evaluates the same
+    objective (1/W) sum_r loss_r on the concatenated batch: same kernels, same arithmetic; only the order of fp32 atomic adds
+    differs.  Replaces the 25 %-wide comparison with the fp32 oracle (VERDICT r1 weak #2)."""
+    W, b = 2, 4
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_dp_worker, args=(W, port, out, 0.3), nprocs=W, join=True)
+    got = [torch.load(out + f".{r}") for r in range(W)]
+    for n in got[0]["grads"]:
+        assert torch.equal(got[0]["grads"][n], got[1]["grads"][n]), n          # the all-reduce left identical gradients
+    cfg = small_config("mca")
+    sd = P.params.init_state_dict(cfg, seed=3)
+    full = to_device(P.data.synthetic_batch(cfg, b * W, seed=21, p_drop=0.3), "cuda")
+    model = P.MCA(**copy.deepcopy(cfg)); model.load_state_dict(sd, strict=False); model = model.cuda()
+    eng = model.engine
+    eng.refresh_weights()
+    ws = eng.workspace(b * W); ws["gen"] += 1
+    eng._encode(full, ws, True)
+    pooled = eng.forward_trunk(ws).view(b * W, eng.R, eng.D)
+    ls = model.loss.loss_fn
+    ls.logit_scale.data.clamp_(ls.logit_scale_min, ls.logit_scale_max)
+    present = ws["present_cur"]
+    parts, dlogit, losses = [], 0, []
+    for r in range(W):
+        res = eng.loss_fwd_bwd(pooled.contiguous(), present.contiguous(), b, r * b)
+        parts.append(res["d_pooled"].clone()); dlogit = dlogit + res["d_logit"].clone(); losses.append(float(res["loss"]))
+    eng.backward(ws, torch.cat(parts) / W, dlogit / W)
+    torch.cuda.synchronize()
+    for r in range(W):
+        assert abs(got[r]["loss"] - losses[r]) <= 1e-5 * abs(losses[r]) + 1e-6
+    errs = []
+    for n, p in model.named_parameters():
+        g = eng.grad_of(p).cpu()
+        if float(g.abs().max()) == 0:
+            assert float(got[0]["grads"][n].abs().max()) < 1e-6, n
+            continue
+        errs.append((rel_err(got[0]["grads"][n], g), n))
+    assert max(errs)[0] < 1e-2, max(errs)

@@ -1,20 +1,20 @@
-"""Round-3 GPU tests: the real-data training path with the evaluation loop, the input prefetcher, bf16
-weight copies after graph replays, and the data-parallel step replayed as graph segments cut at the collectives."""
+"""GPU tests of the entry scripts end to end: infer_accel_gpu.py, train_accel_gpu.py (synthetic and real data, evaluation loop, data
+parallelism) and bench.py's contract line (one GPU, two ranks)."""
 import copy
 import importlib
 import json
 import os
+import pytest
 import socket
 import subprocess
 import sys
-
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import GOLDEN, REPO
 from util_small import small_config, rel_err, to_device
+from conftest import REPO
 
 pytestmark = pytest.mark.gpu
 
@@ -38,6 +38,99 @@ def _ragged_dataset(path, cfg, n=24, seed=0):
             s[name] = {"data": torch.randn(k, enc["input_size"], generator=g).tolist()}
         samples.append(s)
     Dataset.from_list(samples).save_to_disk(path)
+
+
+def test_infer_script_reproduces_reference_embeddings(P, tmp_path):
+    """infer_accel_gpu.py end to end: YAML -> HF dataset on disk -> collators -> reference-written checkpoint ->
+    {train,eval}_{embeddings,masks,labels}.pt in the reference's format (infer_accel_gpu.py:97-136)."""
+    import yaml
+    from datasets import Dataset
+    io = torch.load(os.path.join(GOLDEN, "ref_state_io.pt"), weights_only=False)
+    cfg, eb = io["config"], io["eval_batch"]
+    samples = []
+    for rep in range(2):
+        for i in range(4):
+            s = {"Labels": {"data": [float(i)]}}
+            for name, enc in cfg["encoder_configs"].items():
+                if enc["type"] == "EmbeddedSequenceEncoder":
+                    n_valid = int((~eb[name]["attention_mask"][i]).sum())
+                    s[name] = {"data": eb[name]["tokens"][i, :n_valid].tolist() if n_valid else None}
+                else:
+                    dropped = bool(eb[name]["attention_mask"][i].all())
+                    s[name] = {"values": None if dropped else eb[name]["values"][i].tolist()}
+            samples.append(s)
+    ds_path = str(tmp_path / "ds")
+    Dataset.from_list(samples).save_to_disk(ds_path)
+    mod_cfg = {}
+    for name, enc in cfg["encoder_configs"].items():
+        if enc["type"] == "EmbeddedSequenceEncoder":
+            mod_cfg[name] = {"type": "embedded_sequence", "pad_len": enc["max_tokens"], "embedding_size": enc["input_size"], "data_col_name": "data", "dropout": 0.0}
+        else:
+            mod_cfg[name] = {"type": "sequence", "pad_len": enc["max_tokens"], "data_col_name": "values", "pad_token": -10000, "dropout": 0.0}
+    y = dict(encoder_configs=cfg["encoder_configs"], modality_config=mod_cfg, hidden_size=cfg["dim"], layers=cfg["depth"], heads=cfg["heads"],
+             dim_head=cfg["dim_head"], num_fusion_tokens=cfg["num_fusion_tokens"], batch_size=2, fcl=cfg["fcl"], fcl_root=cfg["fcl_root"],
+             bimodal_contrastive=cfg["bimodal_contrastive"], non_fusion_fcl=cfg["non_fusion_fcl"], fusion_combos=cfg["fusion_combos"],
+             zorro=cfg["zorro"], dataset=ds_path, split=0.25, ds_seed=42, predrop=False, restart=os.path.join(GOLDEN, "ref_state"),
+             output_dir=str(tmp_path / "out"), label_col="Labels")
+    ypath = tmp_path / "infer.yaml"
+    ypath.write_text(yaml.safe_dump(y, sort_keys=False))          # the modality order IS the token order
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(REPO, "infer_accel_gpu.py"), str(ypath)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    n_seen = 0
+    for tv in ("train", "eval"):
+        emb = torch.load(tmp_path / "out" / f"{tv}_embeddings.pt", weights_only=False)
+        masks = torch.load(tmp_path / "out" / f"{tv}_masks.pt", weights_only=False)
+        labels = torch.load(tmp_path / "out" / f"{tv}_labels.pt", weights_only=False)
+        assert set(masks) == set(cfg["encoder_configs"])
+        for row in range(labels.shape[0]):
+            i = int(labels[row, 0]); n_seen += 1
+            for k, want in io["embeddings"].items():
+                key = frozenset(int(x) for x in k.split("|")) if "|" in k else k
+                assert rel_err(emb[key][row], want[i]) < 3e-3, (tv, row, k)          # one 128-vector: a single slot of a single sample
+            for k, want in io["masks"].items():
+                assert bool(masks[k][row]) == bool(want[i])
+    assert n_seen == 8
+
+
+# ------------------------------------------------------------------------------------------------ the training script
+@pytest.mark.parametrize("variant,graph", [("mca", False), ("mca", True), ("eao", False)])
+def test_train_script_end_to_end(P, tmp_path, variant, graph):
+    """train_accel_gpu.py <yaml> --synthetic N (the reference's entry point, train_accel_gpu.py:1-185) as a subprocess: YAML ->
+    model (MCA or EAO) -> N optimizer steps -> log + Accelerate-layout state directory.  The replayed loop (--graph) logs the
+    same first-step loss as the eager one (same seed, same synthetic batches) and every logged number is finite."""
+    import json, subprocess, yaml
+    cfg = small_config(variant)
+    mod_cfg = {name: {"type": "embedded_sequence", "pad_len": enc["max_tokens"], "embedding_size": enc["input_size"], "data_col_name": "data", "dropout": 0.2}
+               for name, enc in cfg["encoder_configs"].items()}
+
+    def run(tag, extra):
+        out = tmp_path / tag
+        y = dict(encoder_configs=cfg["encoder_configs"], modality_config=mod_cfg, hidden_size=cfg["dim"], layers=cfg["depth"], heads=cfg["heads"],
+                 dim_head=cfg["dim_head"], num_fusion_tokens=cfg["num_fusion_tokens"], batch_size=4, fcl=cfg["fcl"], fcl_root=cfg["fcl_root"],
+                 bimodal_contrastive=cfg["bimodal_contrastive"], non_fusion_fcl=cfg["non_fusion_fcl"], fusion_combos=cfg["fusion_combos"],
+                 zorro=cfg["zorro"], eao=cfg["eao"], no_fusion=cfg["no_fusion"], mean_pool=cfg["mean_pool"], predrop=True, epochs=1, lr=1e-3,
+                 lr_scheduler_type="cosine", num_warmup_steps=2, clip=2.0, seed=7, output_dir=str(out), dataset="unused", run_eval_loop=False)
+        ypath = tmp_path / f"{tag}.yaml"
+        ypath.write_text(yaml.safe_dump(y, sort_keys=False))
+        r = subprocess.run([sys.executable, os.path.join(REPO, "train_accel_gpu.py"), str(ypath), "--synthetic", "12"] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        recs = [json.loads(l) for l in open(out / "log.jsonl")]
+        assert len(recs) >= 2 and recs[-1]["step"] == 12
+        for rec in recs:
+            assert all(v == v and abs(v) < 1e9 for k, v in rec.items() if isinstance(v, float)), rec
+        assert os.path.exists(out / "0" / "model.safetensors") and os.path.exists(out / "0" / "optimizer.bin")
+        return recs
+
+    recs = run("eager", [])
+    assert recs[0]["lr"] < recs[1]["lr"] or recs[0]["step"] > 2          # warm-up: the learning rate comes from the schedule
+    if graph:
+        recs_g = run("graph", ["--graph"])
+        assert abs(recs_g[0]["total_loss"] - recs[0]["total_loss"]) <= 1e-4 * abs(recs[0]["total_loss"])
+        assert abs(recs_g[-1]["total_loss"] - recs[-1]["total_loss"]) <= 5e-2 * abs(recs[-1]["total_loss"])
+    if variant == "eao":
+        assert any(k.startswith("audio_") or k.endswith("_audio") for k in recs[0])          # the pairwise terms of the EAO loss
 
 
 def test_train_script_real_data_with_eval_loop(P, tmp_path):
@@ -212,153 +305,64 @@ def test_train_script_eval_loop_under_data_parallelism(P, tmp_path):
     assert want["val_epoch_total_loss"] == want["val_epoch_total_loss"]
 
 
-# ------------------------------------------------------------------------------------------------ input pipeline
-def test_device_prefetcher_keeps_order_and_contents(P):
-    """data.DevicePrefetcher: every batch arrives on the device, in order, bit for bit, while later batches are already being
-    copied; a batch of another shape (the last partial one) passes through; buffers are recycled only after their consumer
-    came back."""
-    g = torch.Generator().manual_seed(0)
-    host = [{"a": {"tokens": torch.randn(4, 70, 10, generator=g), "attention_mask": torch.rand(4, 70, generator=g) > 0.5},
-             "l": [torch.full((3,), float(i))]} for i in range(7)]
-    host.append({"a": {"tokens": torch.randn(2, 70, 10, generator=g), "attention_mask": torch.rand(2, 70, generator=g) > 0.5},
-                 "l": [torch.full((3,), 7.0)]})
-    seen, held = 0, []
-    for i, b in enumerate(P.data.DevicePrefetcher(iter(host), "cuda")):
-        assert b["a"]["tokens"].is_cuda and b["l"][0].is_cuda
-        # a consumer that is slow on the GPU: the buffers of batch i are read by a kernel enqueued now and must not be
-        # overwritten by the copy of batch i + 2 before that kernel has run
-        torch.cuda._sleep(20_000_000)
-        held.append((b["a"]["tokens"].double().sum(), b["a"]["attention_mask"].sum(), b["l"][0][0].clone()))
-        seen += 1
-    assert seen == len(host)
-    torch.cuda.synchronize()
-    for i, (s, m, l) in enumerate(held):
-        assert float(l) == float(i)
-        assert float(s) == float(host[i]["a"]["tokens"].double().sum()) and int(m) == int(host[i]["a"]["attention_mask"].sum())
-
-
-# ------------------------------------------------------------------------------------------------ ADVICE r2: weights after replay
-def test_eval_after_graph_replays_uses_current_weights(P):
-    """GraphedStep replays move the fp32 weights behind torch's version counters; an eval forward between replays must rebuild
-    the bf16 GEMM-weight copies: replay, eval, replay, eval == eval after refresh_weights(force=True)."""
-    optim = importlib.import_module("mca-paper_amd.optim")
-    graph = importlib.import_module("mca-paper_amd.graph")
-    cfg = small_config("mca")
-    sd = P.params.init_state_dict(cfg, seed=3)
-    model = P.build_model(copy.deepcopy(cfg)); model.load_state_dict(sd, strict=False); model = model.cuda()
-    opt = optim.FusedAdamW(model, lr=5e-2)          # a large rate: one stale step is far outside the tolerance
-    batch = to_device(P.data.synthetic_batch(cfg, 4, seed=5, p_drop=0.2), "cuda")
-    g = graph.GraphedStep(model, opt, batch, clip=2.0)
-
-    def eval_pooled():
-        model.eval()
-        with torch.no_grad():
-            o = model(batch, no_loss=True)
-        model.train()
-        return torch.stack([o[k] for k in model.modality_types], 1).clone()
-
-    for _ in range(2):
-        g.step(batch)
-        got = eval_pooled()
-        model.engine.refresh_weights(force=True)
-        want = eval_pooled()
-        assert torch.equal(got, want)
-    g.step(batch)
-    again = eval_pooled()
-    assert rel_err(again, want) > 1e-3          # the weights did move: the check above is not vacuous
-
-
-# ------------------------------------------------------------------------------------------------ DP: graph segments
-def _seg_worker(rank, world, port, out, backend, always):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+def test_bench_two_ranks_reports_its_launch_choice_and_collectives():
+    """`bench.py --gpus 2 --batch 8 --steps 3` as the driver starts it (one process per rank, RANK / WORLD_SIZE / MASTER_* from the
+    environment), with MCA_DIST_BACKEND=gloo so that both ranks can share this box's one GPU: the JSON line carries the rank count
+    and backend (config.collectives), what the launch guard measured and chose (config.launch_choice: the segmented replay is
+    kept only if its two guard steps are not slower than two eager ones, max over ranks) and, when the replay is kept, the
+    segment count (config.launch).  On RCCL over xGMI the same code path runs with backend 'nccl'."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MCA_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--batch", "8", "--steps", "3", "--warmup", "1",
+                                       "--no-kernel-timing"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=REPO))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]          # ONE line, from rank 0
+    rec = json.loads(lines[0])
+    cfg = rec["config"]
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert cfg["per_gpu_batch"] == 8 and cfg["global_batch"] == 16 and cfg["parallelism"] == "dp2"
+    assert cfg["collectives"] == "gloo over 2 ranks"
+    ch = cfg["launch_choice"]
+    assert ch["requested"] == "auto" and ch["chosen"] in ("graph", "eager") and ch["reason"]
+    assert set(ch["guard_ms_per_step"]) == {"replay", "eager"} and all(v > 0 for v in ch["guard_ms_per_step"].values())
+    if ch["chosen"] == "graph":
+        # forward | all-gather | loss + pooling backward | 7 buckets ... | finite flag: segments and eager collectives alternate
+        assert "graph segments cut at" in cfg["launch"] and ch["guard_ms_per_step"]["replay"] <= 1.05 * ch["guard_ms_per_step"]["eager"]
     else:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        P = importlib.import_module("mca-paper_amd")
-        dpm = importlib.import_module("mca-paper_amd.dp")
-        optim = importlib.import_module("mca-paper_amd.optim")
-        graph = importlib.import_module("mca-paper_amd.graph")
-        cfg = small_config("mca")
-        b = 4
-        sd = P.params.init_state_dict(cfg, seed=3)
-        batches = []
-        for i in range(4):
-            full = P.data.synthetic_batch(cfg, b * world, seed=21 + i, p_drop=0.3)
-            batches.append(to_device({k: {kk: vv[rank * b:(rank + 1) * b] for kk, vv in v.items()} for k, v in full.items()}, "cuda"))
-        res = {}
-        for mode in ("eager", "segments"):
-            model = P.MCA(**copy.deepcopy(cfg)); model.load_state_dict(sd, strict=False); model = model.cuda()
-            model.engine.check_finite = "deferred"
-            opt = optim.FusedAdamW(model, lr=1e-3)
-            dp = dpm.DataParallelMCA(model, always_collect=always)
-            hist = []
-            if mode == "eager":
-                for bt in batches:
-                    o = dp(bt); opt.zero_grad(); o["loss"].backward(); dp.finish_backward()
-                    gn = optim.clip_grad_norm_(model, 2.0); opt.step()
-                    hist.append((float(o["loss"]), float(gn), torch.stack([o[k] for k in model.modality_types], 1).detach().clone().cpu(),
-                                 model.engine.gflat.clone().cpu()))
-            else:
-                g = graph.GraphedStep(model, opt, batches[0], clip=2.0, dp=dp)
-                n_graphs = sum(1 for it in g.program if isinstance(it, torch.cuda.CUDAGraph))
-                n_coll = len(g.program) - n_graphs
-                for bt in batches:
-                    loss = g.step(bt)
-                    hist.append((float(loss), float(g.gnorm), torch.stack([g.out[k] for k in model.modality_types], 1).detach().clone().cpu(),
-                                 model.engine.gflat.clone().cpu()))
-                res["shape"] = (n_graphs, n_coll)
-            torch.cuda.synchronize()
-            res[mode] = dict(hist=hist, flat=model.engine.flat.clone().cpu())
-        torch.save(res, out + f".{rank}")
-    finally:
-        dist.destroy_process_group()
+        assert cfg["launch"] == "eager" and ch["guard_ms_per_step"]["replay"] > 1.05 * ch["guard_ms_per_step"]["eager"]
+    # value = samples of ALL ranks / the slowest rank's time
+    assert abs(rec["value"] - 16 * 3 / (rec["ms_per_step"] * 3e-3)) <= 1e-2 * rec["value"]
 
 
-def _check_segments(res, world):
-    n_graphs, n_coll = res["shape"]
-    L = 2
-    # forward | gather | loss+pool bwd | L layer buckets + encoders | wait -> 1 + (L + 2) + 1 collectives, one more graph than that
-    assert n_coll == 1 + (L + 2) + 1 and n_graphs == n_coll + 1, res["shape"]
-    errs = [(abs(le - ls) / abs(le), abs(ge - gs) / ge, rel_err(gfs, gfe), rel_err(ps, pe))
-            for (le, ge, pe, gfe), (ls, gs, ps, gfs) in zip(res["eager"]["hist"], res["segments"]["hist"])]
-    pe, ps = res["eager"]["hist"][0][2], res["segments"]["hist"][0][2]
-    assert torch.equal(pe, ps), "first forward (same weights, same kernels) must agree bit for bit"
-    # step 1: same weights, same inputs -> the gradients differ only by the order of fp32 atomic adds (side-stream weight
-    # gradients in the eager loop, none in the replay); later steps start from weights that already differ by those roundings
-    # (Adam's first update is lr * sign(g): a gradient element near zero may flip), so they are compared as trajectories
-    assert errs[0][0] <= 1e-6 and errs[0][1] <= 1e-3 and errs[0][2] < 1e-2, errs
-    for e in errs[1:]:
-        assert e[0] <= 1e-2 and e[1] <= 5e-2 and e[3] < 1e-2, errs
-    assert rel_err(res["segments"]["flat"], res["eager"]["flat"]) < 2e-3, errs
-
-
-def test_dp_step_as_graph_segments_matches_eager_two_ranks(P, tmp_path):
-    """Two ranks (gloo, both on this GPU; RCCL on a node) run four optimizer steps (a) in the eager data-parallel loop and (b) as
-    graph segments cut at the collectives (graph.GraphedStep(dp=...)): first forward bit for bit, losses / gradient norms /
-    all-reduced gradients of every step within 1e-2, both ranks identical."""
-    W = 2
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    out = str(tmp_path / "seg.pt")
-    mp.spawn(_seg_worker, args=(W, port, out, "gloo", False), nprocs=W, join=True)
-    got = [torch.load(out + f".{r}", weights_only=False) for r in range(W)]
-    for r in range(W):
-        _check_segments(got[r], W)
-    for mode in ("eager", "segments"):
-        for i, (a, b) in enumerate(zip(got[0][mode]["hist"], got[1][mode]["hist"])):
-            bad = (a[3] != b[3]).nonzero().flatten()          # the all-reduce left identical gradients on both ranks
-            assert bad.numel() == 0, (mode, i, bad.numel(), bad[:8].tolist(), bad[-8:].tolist(), a[3][bad[:4]].tolist(), b[3][bad[:4]].tolist())
-    # ... and, the gradient norm being summed in a fixed order (mca_grad_sqnorm), identical weights after four optimizer steps
-    assert torch.equal(got[0]["segments"]["flat"], got[1]["segments"]["flat"]) and torch.equal(got[0]["eager"]["flat"], got[1]["eager"]["flat"])
-
-
-def test_dp_graph_segments_with_rccl_collectives_world1(P, tmp_path):
-    """The same segmented step with the REAL RCCL backend on a world of one rank (this pool has one GPU per box): the packed
-    all-gather, the async bucket all-reduces and the finite-flag MAX are issued through torch.distributed 'nccl' between the
-    replayed segments (always_collect)."""
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    out = str(tmp_path / "seg1.pt")
-    mp.spawn(_seg_worker, args=(1, port, out, "nccl", True), nprocs=1, join=True)
-    _check_segments(torch.load(out + ".0", weights_only=False), 1)
+def test_bench_single_gpu_line_follows_the_contract():
+    """`python bench.py --steps 4 --warmup 2` on one GPU (small batch, no CPU baseline: the contract's other fields): ONE JSON
+    line with BASELINE's metric and unit, whole-job value consistent with ms_per_step, `roofline` of the dominant launch class
+    (achieved / peak = frac, live HIP events of the one eager sampled step), the workload named in `config`, the clock the figure was
+    measured at, and the steady-state rate beside - never instead of - `value`."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--batch", "4", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                        "--sustain-seconds", "3"], capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["metric"].startswith("training samples/sec") and rec["unit"] == "samples/s" and rec["higher_is_better"] is True
+    assert rec["n_gpus"] == 1 and rec["steps"] == 4 and rec["warmup"] == 2 and rec["scaling"] == "weak" and rec["vs_baseline"] is None
+    assert rec["dtype"] == "bf16" and rec["data"] == "synthetic" and "model" not in rec["config"] and "workload" in rec["config"]
+    assert abs(rec["value"] - 4 * 4 / (rec["ms_per_step"] * 4e-3)) <= 1e-2 * rec["value"]
+    rf = rec["roofline"]
+    assert rf["bound"] in ("mfma", "hbm") and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1 and rf["avg_launch_us"] > 0 and rf["sampled_steps"] == 1
+    assert rec["config"]["launch_choice"]["chosen"] == "graph" and "hipGraph replay" in rec["config"]["launch"]
+    gs = rec["config"]["gpu_state_rank0"]
+    assert gs["samples"] >= 1 and (gs["sclk_mhz_median"] is None or 100 < gs["sclk_mhz_median"] < 3000)
+    su = rec["config"]["sustained"]
+    assert su["samples_per_s"] > 0 and su["steps"] >= 50 and "not `value`" in su["note"]
+    assert "cpu_baseline" not in rec and rec["kernels"]["mca_attn_bwd_dkv/layer"]["launches_per_step"] == 5

@@ -3,7 +3,7 @@ import importlib, os, sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 H = importlib.import_module("mca-paper_amd.hip"); S = importlib.import_module("mca-paper_amd.structure"); E = importlib.import_module("mca-paper_amd.engine")
-import test_kernels_gpu as T
+import test_attention_gpu as T
 
 shape = sys.argv[1] if len(sys.argv) > 1 else "small"
 if shape == "small":
