@@ -1819,6 +1819,8 @@ extern "C" int mca_gemm_tn_acc_group(const mca_tn_desc* d, int n, int64_t R, mca
   // knob 3 = s: s uniform splits and no line (the round-3 partition, A/B); knob 6 = r + 1: relief of 32 r rows, -(r + 1): the same without owner segments
   const int cus = num_cus();
   const int k6 = g_knob[6];
+  // (a FIXED relief: scaling it down with R - at most an eighth of a cell - was measured and is worse at small R: b = 2, 52 / 60 tiles
+  //  73.6 / 78.0 us with 1,536 rows against 76.9 / 95.0 with 512; b = 16 within 2 % either way.  tools/bench_tn_group.py 2 8 16)
   const int64_t relief = k6 != 0 ? 32 * (int64_t)((k6 < 0 ? -k6 : k6) - 1) : TN_SPAN_RELIEF;
   int64_t n_full = cus / tiles, unit, rest, span = 0, spans = 0, own = 0;
   if (g_knob[3] > 0) {
@@ -1839,6 +1841,7 @@ extern "C" int mca_gemm_tn_acc_group(const mca_tn_desc* d, int n, int64_t R, mca
     if (owners && rest >= BR2) {
       own = sp0;
       span = (left * rest + sp0 - 1) / sp0;
+      if (span < 4 * BR2) span = 4 * BR2;
       span = (span + BR2 - 1) / BR2 * BR2;
       spans = sp0;
     } else {

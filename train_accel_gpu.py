@@ -218,12 +218,17 @@ def main():
                 # the clipped norm, and (like param_norm) without the first parameter (utils/training.py): here the fused AdamW
                 # applies the clip coefficient on the fly, so the same number is norm * min(1, clip / (norm + 1e-6)) of the
                 # helper's norm; the unclipped total norm is logged beside it.
-                gn_ref = float(get_grad_norm(model))
-                g_all = float(gnorm) if gnorm is not None else None
+                # ONE device-to-host copy per logged step: every logged scalar stacked on the device first (separate float() reads
+                # were a dozen blocking round trips per step at the reference's every-step cadence)
+                names = [k for k in outputs["losses"] if "|" not in k]
+                dev_vals = [loss.detach(), get_grad_norm(model), get_param_norm(model),
+                            gnorm if gnorm is not None else torch.zeros((), device=device)] + [outputs["losses"][k].detach() for k in names]
+                host = torch.stack([torch.as_tensor(v, device=device).float().reshape(()) for v in dev_vals]).cpu().tolist()
+                total_loss, gn_ref, pn, g_all = host[0], host[1], host[2], (host[3] if gnorm is not None else None)
                 coef = min(1.0, config.clip / (g_all + 1e-6)) if (config.clip and g_all is not None) else 1.0
-                rec = {"epoch": epoch, "step": step, "total_loss": float(loss), "lr": opt.param_groups[0]["lr"],
-                       "param_norm": float(get_param_norm(model)), "grad_norm": gn_ref * coef, "grad_norm_unclipped": g_all,
-                       **{k: float(v) for k, v in outputs["losses"].items() if "|" not in k}}
+                rec = {"epoch": epoch, "step": step, "total_loss": total_loss, "lr": opt.param_groups[0]["lr"],
+                       "param_norm": pn, "grad_norm": gn_ref * coef, "grad_norm_unclipped": g_all,
+                       **dict(zip(names, host[4:]))}
                 print(json.dumps(rec), flush=True)
                 log.write(json.dumps(rec) + "\n"); log.flush()
             if config.n_step_checkpoint and idb % config.n_step_checkpoint == 0 and rank == 0:
