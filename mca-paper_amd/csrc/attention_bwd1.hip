@@ -713,7 +713,10 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
   #pragma unroll
     for (int kb = 0; kb < 2; kb++) { const int r = wave * 64 + kb * 32 + l31_; o_ds[kb] = (unsigned)((r * 128 + 8 * lh_) ^ (b1_swz(r) << 4)); }
     const unsigned o_rc = 16u * (unsigned)lh_, o_qb = (unsigned)(l31_ * 32 + 16 * lh_);
-    unsigned a_rf[4], a_tr[2][2], a_da[2], a_db[2], a_rc = lds_b + 16384u + o_rc, a_qb = lds_b + 16896u + o_qb, ods[2] = {o_ds[0], o_ds[1]};
+    unsigned a_rf[4], a_tr[2][2], a_da[2], a_db[2], a_rc = lds_b + 16384u + o_rc, a_qb = lds_b + 16896u + o_qb;
+    // dS^T store addresses of this lane in the two images (the image bases are multiples of 128 bytes, so the chunk swizzle - an xor on
+    // bits 4..6 - applies to the sum: one xor per store instead of an xor and an add)
+    unsigned a_dsw[2][2] = {{DSIMG_B + o_ds[0], DSIMG_B + o_ds[1]}, {DSIMG_B + 2u * TKB * TQ + o_ds[0], DSIMG_B + 2u * TKB * TQ + o_ds[1]}};
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) a_rf[ks] = lds_b + o_rf[ks];
 #pragma unroll
@@ -784,7 +787,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       asm volatile("" : "+v"(a_tr[0][0]), "+v"(a_tr[0][1]), "+v"(a_tr[1][0]), "+v"(a_tr[1][1]), "+v"(a_da[0]), "+v"(a_da[1]), "+v"(a_db[0]), "+v"(a_db[1]));
       unsigned n_off = st_n - st_c;          // (wave-uniform: the next stage's same addresses)
       asm volatile("" : "+s"(n_off));
-      asm volatile("" : "+v"(ods[0]), "+v"(ods[1]));          // (opaque: the sixteen xor-ed variants are recomputed, not hoisted and spilled)
+      asm volatile("" : "+v"(a_dsw[0][0]), "+v"(a_dsw[0][1]), "+v"(a_dsw[1][0]), "+v"(a_dsw[1][1]));          // (opaque: the xor-ed variants are recomputed, not hoisted and spilled)
       const u32x2v m2v = *LDS_P(const u32x2v, a_meta);          // record of step it + 2 (read here, ahead of the barrier's lgkmcnt(0); made scalar behind it)
       const bool prev_first = M_FIRST(mp) != 0;
       float* st_base = acc_s + ((int64_t)M_QT(mpp) << 12);          // (wave-uniform: scalar registers)
@@ -816,9 +819,9 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
 #define C_K(J, SP, N) if (!(B1_ABL & 64)) MF_ACCA_VV(dk[(J) & 1][N], trQ[SP][N], sb[(J) & 1][SP])
 #define CP_V(J, SP, N) if (!(B1_ABL & 64)) MF_ACCA_VV(dv[(J) & 1][N], trO[SP][N], pb[(J) & 1][SP])
 #define CP_K(J, SP, N) if (!(B1_ABL & 64)) MF_ACCA_VV(dk[(J) & 1][N], trQ[SP][N], sb[(J) & 1][SP])
-#define DSW_(IMG, QB, KB, SET, SP, T) if (!(B1_ABL & 16)) *LDS_P(u32x2v, (IMG) + (ods[KB] ^ (unsigned)(((QB) * 4 + 2 * (SP) + (T)) << 4))) = u32x2v{sb[SET][SP][2 * (T)], sb[SET][SP][2 * (T) + 1]}
-#define DSW(J, SP, T) DSW_(ds_cur, (J) >> 1, (J) & 1, (J) & 1, SP, T)
-#define DSWP(SP, T) DSW_(ds_prev, 1, 1, 1, SP, T)
+#define DSW_(IMG, QB, KB, SET, SP, T) if (!(B1_ABL & 16)) *LDS_P(u32x2v, a_dsw[IMG][KB] ^ (unsigned)(((QB) * 4 + 2 * (SP) + (T)) << 4)) = u32x2v{sb[SET][SP][2 * (T)], sb[SET][SP][2 * (T) + 1]}
+#define DSW(J, SP, T) DSW_(PAR, (J) >> 1, (J) & 1, (J) & 1, SP, T)
+#define DSWP(SP, T) DSW_(PAR ^ 1, 1, 1, 1, SP, T)
 #define RC4_(DST, ADDR, G) do { if (B1_ABL & 8) break; const f32x4 t_ = LDS_RF4(ADDR); DST[4 * (G)] = t_[0]; DST[4 * (G) + 1] = t_[1]; DST[4 * (G) + 2] = t_[2]; DST[4 * (G) + 3] = t_[3]; } while (0)
 #define RC_L(J, G) RC4_(S[(J) & 1], a_rc + (unsigned)(((J) >> 1) * 128 + 32 * (G)), G)
 #define RC_D(J, G) RC4_(dP[(J) & 1], a_rc + (unsigned)(256 + ((J) >> 1) * 128 + 32 * (G)), G)

@@ -655,13 +655,14 @@ __device__ __forceinline__ void attn_bwd_prep_block(const int bx, const int by, 
     const int c = c0 + lane * 8;
     const int hl = lane >> 3;          // head of this lane inside the 512-column slab
     // all PREP_ROWS / 4 rows of this wavefront are requested before any is used (a row at a time the loop is latency-bound)
-    bf16x8 ovs[PREP_ROWS / 4], dvs[PREP_ROWS / 4];
+    bf16x8 ovs[PREP_ROWS / 4], dvs[PREP_ROWS / 4], qvs[PREP_ROWS / 4];
 #pragma unroll
     for (int k = 0; k < PREP_ROWS / 4; k++) {
       int q = q_begin + wave + 4 * k; if (q > nq - 1) q = nq - 1;
       const int cc = c < cols ? c : 0;
       ovs[k] = *reinterpret_cast<const bf16x8*>(o + (int64_t)b * bstride + (int64_t)q * ld + cc);
       dvs[k] = *reinterpret_cast<const bf16x8*>(d_o + (int64_t)b * bstride + (int64_t)q * ld + cc);
+      if (do_hm) qvs[k] = *reinterpret_cast<const bf16x8*>(qsrc + (int64_t)b * q_bstride + (int64_t)q * q_ld + cc);          // (with the others: a row at a time it was one more latency per row)
     }
 #pragma unroll
     for (int k = 0; k < PREP_ROWS / 4; k++) {
@@ -672,7 +673,7 @@ __device__ __forceinline__ void attn_bwd_prep_block(const int bx, const int by, 
       if (do_hm && c < cols) {
         const int64_t dst = (((int64_t)b * heads + h0 + hl) * nq + q) * DH + (lane & 7) * 8;
         *reinterpret_cast<bf16x8*>(do_hm + dst) = dvs[k];
-        *reinterpret_cast<bf16x8*>(q_hm + dst) = *reinterpret_cast<const bf16x8*>(qsrc + (int64_t)b * q_bstride + (int64_t)q * q_ld + c);
+        *reinterpret_cast<bf16x8*>(q_hm + dst) = qvs[k];
       }
       float part = 0.f;
       if (c < cols) {
