@@ -456,7 +456,7 @@ def main():
                                    f"N={N} D=512 L=5 H=8 F=88, lengths={args.lengths}, p_drop={args.p_drop}",
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
                        "inputs": "device-resident, same batch every step" if host_batch is None else ("pinned host memory, copied to the device every step (PCIe-inclusive" + (", one step ahead on a copy stream)" if feed is not None else ", in the compute stream)")), "finite_checks": "on (device flag, polled)",
-                       "attention_operands": args.attn, "launch": ("hipGraph replay (" + ("one launch per step" if world == 1 else f"{sum(1 for it in graphed.program if isinstance(it, torch.cuda.CUDAGraph))} graph segments cut at {sum(1 for it in graphed.program if not isinstance(it, torch.cuda.CUDAGraph))} eager collectives per step") + (f"; {sampled} of {args.steps} steps eager for the kernel timing)" if sampled else ")")) if use_graph else "eager",
+                       "attention_operands": args.attn, "attention_backward": model.engine.backward_form(b), "launch": ("hipGraph replay (" + ("one launch per step" if world == 1 else f"{sum(1 for it in graphed.program if isinstance(it, torch.cuda.CUDAGraph))} graph segments cut at {sum(1 for it in graphed.program if not isinstance(it, torch.cuda.CUDAGraph))} eager collectives per step") + (f"; {sampled} of {args.steps} steps eager for the kernel timing)" if sampled else ")")) if use_graph else "eager",
                        "launch_choice": choice,
                        "collectives": (f"{dist.get_backend()} over {dist.get_world_size()} ranks" if world > 1 else "none")},
         }

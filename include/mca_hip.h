@@ -335,7 +335,7 @@ typedef struct {
   const uint8_t* keyinfo; const uint8_t* ktile_flags; const uint16_t* khot; const uint16_t* qblk;
   const int32_t* qt_desc; const int32_t* kb_desc; const uint32_t* kb_qt; const uint8_t* visit;
   int n_qtiles, n_kblocks, max_list;
-  int n_entries;                                               /* length of kb_qt: n_entries + 4 * n_kblocks <= 512                 */
+  int n_entries;                                               /* length of kb_qt: n_entries + 4 * n_kblocks <= 768                 */
   int batch, heads, n, nk_pad, n_ktiles64;
   float scale;
   int flags;

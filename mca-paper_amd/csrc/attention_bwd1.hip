@@ -25,7 +25,7 @@
 #define B1_MAX_QT 256
 #define B1_MAX_KB 64
 #define B1_MAX_LIST 256
-#define B1_MAX_META 512              // step records of all key blocks of a (sample, head) (pipelined kernel)
+#define B1_MAX_META 768              // step records of all key blocks of a (sample, head) (pipelined kernel)
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 
@@ -477,10 +477,12 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
   u16* dsimg = kimg + TKB * DH;
   int2* meta_s = reinterpret_cast<int2*>(dsimg + 2 * TKB * TQ);           // every live key block's steps: {tile | (1 first, 2 last visit) << 16 | rows << 20, first row}
   int4* kbd_s = reinterpret_cast<int4*>(meta_s + B1_MAX_META);            // key block table {first key, keys, first record in meta_s, steps}
-  int2* qtd_s = reinterpret_cast<int2*>(kbd_s + B1_MAX_KB);               // query tile table {first row, rows}
+  // tables only the set-up below reads live in the (still unused) first dS^T image: the query tile table {first row, rows} and
+  // each tile's first / last live key block (2.5 KiB that the step records can have instead: LONG needs 720 of them)
+  int2* qtd_s = reinterpret_cast<int2*>(dsimg);
   uint8_t* first_s = reinterpret_cast<uint8_t*>(qtd_s + B1_MAX_QT);
   uint8_t* last_s = first_s + B1_MAX_QT;
-  uint8_t* live_s = last_s + B1_MAX_QT;
+  uint8_t* live_s = reinterpret_cast<uint8_t*>(kbd_s + B1_MAX_KB);
   float* dvm_s = reinterpret_cast<float*>(live_s + B1_MAX_KB);
 
   const int lin = (dbg & 16) ? (int)blockIdx.x : xcd_remap((int)blockIdx.x, (int)gridDim.x);
@@ -558,6 +560,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     for (int i = tid; i < qd.y * 8; i += 256)
       *reinterpret_cast<uint4*>(a.dq + (int64_t)b * a.dq_bstride + (int64_t)(qd.x + (i >> 3)) * a.dq_ld + h * DH + (i & 7) * 8) = make_uint4(0, 0, 0, 0);
   }
+  __syncthreads();          // (the set-up tables inside the first dS^T image are dead from here on)
 
   const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const u16*)lds;
   const unsigned STAGE_B = 2u * B1_STAGE_U16, KIMG_B = lds_b + 2u * B1P_NST * B1_STAGE_U16, DSIMG_B = KIMG_B + 2u * TKB * DH;
@@ -1041,7 +1044,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd1p_kernel(mca_attn_bwd1_args a
   extern __shared__ __attribute__((aligned(16))) u16 lds_dyn[];
   attn_bwd1p_body(a, dbg, lds_dyn);
 }
-#define B1P_LDS_BYTES ((B1P_NST * B1_STAGE_U16 + TKB * DH + 2 * TKB * TQ) * 2 + B1_MAX_META * 8 + B1_MAX_KB * 16 + B1_MAX_QT * 8 + 2 * B1_MAX_QT + B1_MAX_KB + DH * 4 + 16)
+#define B1P_LDS_BYTES ((B1P_NST * B1_STAGE_U16 + TKB * DH + 2 * TKB * TQ) * 2 + B1_MAX_META * 8 + B1_MAX_KB * 16 + B1_MAX_KB + DH * 4 + 16)
 
 #define B1_LDS_BYTES ((B1_NST * B1_STAGE_U16 + TKB * DH + 2 * TKB * TQ) * 2 + B1_MAX_LIST * 4 + 2 * B1_MAX_QT + B1_MAX_KB + DH * 4)
 

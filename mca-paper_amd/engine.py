@@ -87,7 +87,7 @@ class _OnePassSched:
         self.visit, self.row_slot = _dev(s.visit.astype(np.uint8), device), _dev(s.row_slot.astype(np.int32), device)
         self.n_qt, self.n_kb, self.max_list = len(s.qt_desc), len(s.kb_desc), int(s.kb_desc[:, 3].max())
         self.n_entries = int(len(s.kb_qt))
-        self.fits = self.n_qt < 256 and self.n_kb <= 64 and self.max_list + 6 <= 256 and self.n_entries + 4 * self.n_kb <= 512          # the kernel's LDS tables
+        self.fits = self.n_qt < 256 and self.n_kb <= 64 and self.max_list + 6 <= 256 and self.n_entries + 4 * self.n_kb <= 768          # the kernel's LDS tables
 
 
 class FusionEngine:
@@ -547,10 +547,20 @@ class FusionEngine:
     ONEPASS_MIN_WG = 192          # (sample, head) pairs from which the one-pass backward is the default: one workgroup per CU
 
     def use_onepass(self, ws, b, nq, dq_f32=False) -> bool:
-        if self.sched_onepass is None or nq != self.N or dq_f32 or ws.get("khot") is None or self.fp8_backward_on(ws, nq):
+        """The one-pass bf16 backward wherever it applies - also with fp8 attention operands: it is faster than the two-pass backward
+        with fp8 score recomputes (LONG b = 128: 9.1 against 10.5 ms per layer), so `set_attention_dtype("fp8")` then means the fp8
+        forward + this backward; the fp8 two-pass backward remains for small batches (and MCA_DEBUG=onepass=0)."""
+        if self.sched_onepass is None or nq != self.N or dq_f32 or ws.get("khot") is None:
             return False
         want = self.dbg["onepass"]
         return bool(want) if want is not None else b * self.H >= self.ONEPASS_MIN_WG
+
+    def backward_form(self, b) -> str:
+        """what the layer attention's backward runs at batch b (reported by bench.py)"""
+        ws = {"khot": True if self.mask_mfma else None}
+        if self.use_onepass(ws, b, self.N):
+            return "bf16 one-pass"
+        return "fp8 two-pass" if (self.attn_dtype == "fp8" and self.mask_mfma and self.dkv_keys == 128) else "bf16 two-pass"
 
     def _attn_bwd1(self, q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, d_o, lse, dq_ptr, dq_bstride, dq_ld, dkv, dk_off, dv_off, dkv_ld, ws, b):
         """one-pass backward of the layer attention (attention_bwd1.hip): dq, dk, dv bf16, every element written"""

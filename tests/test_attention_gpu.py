@@ -244,7 +244,7 @@ def _attention_case(H, st, b, heads, pool, seed, drop_first, prescaled=True, spi
         outs = []
         for aligned in (True, False):
             sc_ = S_.build_onepass_schedule(qmask_np, st.kgroup, 64, 256, aligned)
-            too_big = len(sc_.qt_desc) >= 256 or len(sc_.kb_desc) > 64 or int(sc_.kb_desc[:, 3].max()) + 6 > 256 or len(sc_.kb_qt) + 4 * len(sc_.kb_desc) > 512
+            too_big = len(sc_.qt_desc) >= 256 or len(sc_.kb_desc) > 64 or int(sc_.kb_desc[:, 3].max()) + 6 > 256 or len(sc_.kb_qt) + 4 * len(sc_.kb_desc) > 768
             try:
                 got = _run_onepass(H, sc_, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean, keyinfo, kflags, khot, qblk)
             except H.MCAHipError as exc:          # tables past the kernel's LDS budget: refused, the caller keeps the two-pass form
