@@ -339,6 +339,10 @@ typedef struct {
   int batch, heads, n, nk_pad, n_ktiles64;
   float scale;
   int flags;
+  int split;                                                   /* 0 / 1: one workgroup per (sample, head).  S = 2..8 (small batches): S workgroups per  */
+                                                               /* (sample, head), key block kb swept by workgroup kb mod S, dq_acc holds S slices of   */
+                                                               /* batch * heads * (n_qtiles + 1) slots (slice-major per (sample, head)), summed in      */
+                                                               /* slice order by a second launch of the same call: still no atomics, bitwise repeatable  */
 } mca_attn_bwd1_args;
 int mca_attn_bwd_onepass(const mca_attn_bwd1_args* args, mca_stream_t stream);
 /* mca_attn_bwd_prep for the one-pass form: rowc in tile order (row_slot[q] = tile * 64 + position) instead of delta; dvmean as

@@ -486,7 +486,12 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
   float* dvm_s = reinterpret_cast<float*>(live_s + B1_MAX_KB);
 
   const int lin = (dbg & 16) ? (int)blockIdx.x : xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const int h = lin % a.heads, b = lin / a.heads;
+  // SPLIT mode (a.split = S > 1; batches too small to give every CU a (sample, head)): S workgroups share a (sample, head), workgroup
+  // s owns the key blocks kb with kb mod S == s.  Each keeps its own fp32 dQ partials in its own slice of dq_acc (no visit is a
+  // "last" one: nothing is written to dq here); attn_bwd1_reduce_kernel adds the S slices in a fixed order afterwards.
+  const int S = a.split > 1 ? a.split : 1;
+  const int bh_ = lin / S, sid = lin - bh_ * S;
+  const int h = bh_ % a.heads, b = bh_ / a.heads;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef MCA_TRACE_BUILD
   const bool trace_on = lin == 0 && wave == 0 && (dbg & 8);
@@ -501,7 +506,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
   const u16* kbase = a.k + (int64_t)b * a.kv_bstride + h * DH;
   const u16* vbase = a.v + (int64_t)b * a.kv_bstride + h * DH;
   const float* rowc_g = a.rowc + bh * (int64_t)(a.n_qtiles + 1) * 128;          // (+ the null tile)
-  float* acc_s = a.dq_acc + bh * (int64_t)(a.n_qtiles + 1) * (TQ * DH) + wave * 1024;          // (wave-uniform; lane l's slot at + 4 l)
+  float* acc_s = a.dq_acc + (bh * S + sid) * (int64_t)(a.n_qtiles + 1) * (TQ * DH) + wave * 1024;          // (wave-uniform; lane l's slot at + 4 l)
   const uint8_t* kinfo_g = a.keyinfo + (int64_t)b * a.nk_pad;
   const u16* khot_g = a.khot + (int64_t)b * a.nk_pad * 16;
 
@@ -510,7 +515,8 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     const uint8_t* fl = a.ktile_flags + (int64_t)b * a.n_ktiles64;
     int live = 0;
     for (int t = d.x >> 6; t <= (d.x + d.y - 1) >> 6; t++) live |= fl[t];
-    live_s[tid] = live ? 1 : 0;
+    const bool mine = tid % S == sid;
+    live_s[tid] = (live && mine) ? 1 : ((!live && mine) ? 2 : 0);          // 1: this workgroup sweeps it; 2: its keys are all padded, this workgroup writes dK = 0, dV = dvmean
     kbd_s[tid] = d;
   }
   if (tid < DH) dvm_s[tid] = a.dvmean[(int64_t)b * a.heads * DH + h * DH + tid];
@@ -520,7 +526,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
   for (int qt = tid; qt < a.n_qtiles; qt += 256) {
     int first = 255, last = 255;
     for (int kb = 0; kb < a.n_kblocks; kb++)
-      if (live_s[kb] && a.visit[kb * a.n_qtiles + qt]) { if (first == 255) first = kb; last = kb; }
+      if (live_s[kb] == 1 && a.visit[kb * a.n_qtiles + qt]) { if (first == 255) first = kb; last = kb; }
     first_s[qt] = (uint8_t)first; last_s[qt] = (uint8_t)last;
   }
   // ---- the step records of EVERY live key block, once (per block this was a global read of the block's list in front of its
@@ -534,7 +540,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       int4 d = kbd_s[kb];
       const int e_begin = d.z;
       d.z = off;
-      if (live_s[kb]) off += ((d.w + 2) & ~1) + 2;
+      if (live_s[kb] == 1) off += ((d.w + 2) & ~1) + 2;
       kbd_s[kb] = make_int4(d.x, d.y, d.z | (e_begin << 16), d.w);          // (record offset < 2^16, list offset < 2^15)
     }
     *mtot_s = off;
@@ -545,20 +551,25 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
     for (int e = tid; e < total; e += 256) {
       int kb = 0;
       for (int k = 1; k < a.n_kblocks; k++) if ((kbd_s[k].z & 0xffff) <= e) kb = k;          // the LAST block whose records start at or before e
-      while (!live_s[kb]) kb--;          // (a dead block shares its offset with the next live one; block offsets ascend)
+      while (live_s[kb] != 1) kb--;          // (a dead block shares its offset with the next live one; block offsets ascend)
       const int4 d = kbd_s[kb];
       const int mo = d.z & 0xffff, e_begin = d.z >> 16, n_ent = d.w, i = e - mo;
       const int qt = i < n_ent ? (int)(a.kb_qt[e_begin + i] & 0x7fffffffu) : a.n_qtiles;
       const int2 qd = qtd_s[qt];
-      meta_s[e] = make_int2(qt | (((int)first_s[qt] == kb ? 1 : 0) << 16) | (((int)last_s[qt] == kb ? 2 : 0) << 16) | (qd.y << 20), qd.x);
+      meta_s[e] = make_int2(qt | (((int)first_s[qt] == kb ? 1 : 0) << 16) | (((int)last_s[qt] == kb && S == 1 ? 2 : 0) << 16) | (qd.y << 20), qd.x);
     }
   }
   __syncthreads();
-  for (int qt = 0; qt < a.n_qtiles; qt++) {          // query tiles nobody visits: dq = 0
+  for (int qt = 0; qt < a.n_qtiles; qt++) {          // query tiles this workgroup never visits: dq = 0 (split mode: its partial = 0)
     if (first_s[qt] != 255) continue;
     const int2 qd = qtd_s[qt];
-    for (int i = tid; i < qd.y * 8; i += 256)
-      *reinterpret_cast<uint4*>(a.dq + (int64_t)b * a.dq_bstride + (int64_t)(qd.x + (i >> 3)) * a.dq_ld + h * DH + (i & 7) * 8) = make_uint4(0, 0, 0, 0);
+    if (S == 1) {
+      for (int i = tid; i < qd.y * 8; i += 256)
+        *reinterpret_cast<uint4*>(a.dq + (int64_t)b * a.dq_bstride + (int64_t)(qd.x + (i >> 3)) * a.dq_ld + h * DH + (i & 7) * 8) = make_uint4(0, 0, 0, 0);
+    } else {
+      float* slot = a.dq_acc + ((bh * S + sid) * (int64_t)(a.n_qtiles + 1) + qt) * (TQ * DH);
+      for (int i = tid; i < TQ * DH / 4; i += 256) *reinterpret_cast<f32x4*>(slot + 4 * i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
   __syncthreads();          // (the set-up tables inside the first dS^T image are dead from here on)
 
@@ -594,7 +605,7 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       B1_DMA16(a.qblk, (unsigned)row * 32u + (unsigned)(ln & 1) * 16u, sb_ + 16896u + (unsigned)(wave - 2) * 1024u);
     }
   };
-  auto next_live = [&](int from) { int k = from; while (k < a.n_kblocks && !live_s[k]) k++; return k < a.n_kblocks ? k : -1; };
+  auto next_live = [&](int from) { int k = from; while (k < a.n_kblocks && live_s[k] != 1) k++; return k < a.n_kblocks ? k : -1; };
   bf16x8 kf[2][4], vf[2][4], khf[2];
   uint8_t kflag[2];          // (raw key flags: compared at the top of the block, so that the wait for them sits there)
   int key_start = 0, n_keys = 0, meta_off = 0, n_ent = 0;
@@ -1027,8 +1038,8 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
 #ifdef MCA_TRACE_BUILD
   if (trace_on && lane == 0) mca_trace_attn_bwd1[1023] = (unsigned long long)tr_n;
 #endif
-  for (int kbi = 0; kbi < a.n_kblocks; kbi++) {          // key blocks without a valid key in this sample: dK = 0, dV = dvmean
-    if (live_s[kbi]) continue;
+  for (int kbi = 0; kbi < a.n_kblocks; kbi++) {          // (this workgroup's) key blocks without a valid key in this sample: dK = 0, dV = dvmean
+    if (live_s[kbi] != 2) continue;
     const int4 kd = reinterpret_cast<const int4*>(a.kb_desc)[kbi];
     for (int i = tid; i < kd.y * 8; i += 256) {
       const int key = kd.x + (i >> 3), c = i & 7;
@@ -1037,6 +1048,28 @@ __device__ __forceinline__ void attn_bwd1p_body(const mca_attn_bwd1_args& a, con
       pv.x = pack2bf(dvm_s[c * 8], dvm_s[c * 8 + 1]); pv.y = pack2bf(dvm_s[c * 8 + 2], dvm_s[c * 8 + 3]);
       pv.z = pack2bf(dvm_s[c * 8 + 4], dvm_s[c * 8 + 5]); pv.w = pack2bf(dvm_s[c * 8 + 6], dvm_s[c * 8 + 7]);
       *reinterpret_cast<uint4*>(a.dv + (int64_t)b * a.dkv_bstride + (int64_t)key * a.dkv_ld + h * DH + c * 8) = pv;
+    }
+  }
+}
+// split mode: dq = scale * (sum over the S slices, in slice order) of a tile's fp32 partials, as bf16.  One workgroup per (sample,
+// head, query tile); thread (wave w, lane l) holds, per piece g, the four dims (w & 1) * 32 + 8 g + 4 (l >> 5) + 0..3 of row
+// (w >> 1) * 32 + (l & 31) - the accumulator layout the main kernel stores
+__global__ __launch_bounds__(256) void attn_bwd1_reduce_kernel(mca_attn_bwd1_args a) {
+  const int qt = blockIdx.x, bh = blockIdx.y, h = bh % a.heads, b = bh / a.heads, S = a.split;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int2 qd = reinterpret_cast<const int2*>(a.qt_desc)[qt];
+  const int r = (wave >> 1) * 32 + (lane & 31);
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; s++) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.dq_acc + (((int64_t)bh * S + s) * (a.n_qtiles + 1) + qt) * (TQ * DH) + wave * 1024 + g * 256 + lane * 4);
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    if (r < qd.y) {
+      uint2 pk;
+      pk.x = pack2bf(acc[0] * a.scale, acc[1] * a.scale); pk.y = pack2bf(acc[2] * a.scale, acc[3] * a.scale);
+      *reinterpret_cast<uint2*>(a.dq + (int64_t)b * a.dq_bstride + (int64_t)(qd.x + r) * a.dq_ld + h * DH + (wave & 1) * 32 + 8 * g + 4 * (lane >> 5)) = pk;
     }
   }
 }
@@ -1072,7 +1105,11 @@ extern "C" int mca_attn_bwd_onepass(const mca_attn_bwd1_args* a, mca_stream_t st
   // knob 9 bit 64: the plain (compiler-scheduled) form of the same algorithm instead of the pipelined one (A/B and cross-check)
   // the pipelined kernel reads q / dO from the head-major packed copies only (64-element rows: a tile is 8 KiB contiguous)
   const bool packed = a->q_ld == DH && a->o_ld == DH && a->q_hstride && a->o_hstride;
-  if ((mca_knobs[9] & 64) || !packed) hipLaunchKernelGGL(attn_bwd1_kernel, dim3(a->batch * a->heads), dim3(256), B1_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
-  else hipLaunchKernelGGL(attn_bwd1p_kernel, dim3(a->batch * a->heads), dim3(256), B1P_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
+  const int split = a->split > 1 ? a->split : 1;
+  if (split > 8) return MCA_E_UNSUPPORTED;
+  if (split > 1 && !packed) return MCA_E_UNSUPPORTED;          // (split mode exists in the pipelined kernel only)
+  if ((mca_knobs[9] & 64 && split == 1) || !packed) hipLaunchKernelGGL(attn_bwd1_kernel, dim3(a->batch * a->heads), dim3(256), B1_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
+  else hipLaunchKernelGGL(attn_bwd1p_kernel, dim3(a->batch * a->heads * split), dim3(256), B1P_LDS_BYTES, as_stream(stream), *a, mca_knobs[9]);
+  if (split > 1) hipLaunchKernelGGL(attn_bwd1_reduce_kernel, dim3(a->n_qtiles, a->batch * a->heads), dim3(256), 0, as_stream(stream), *a);
   return launch_status();
 }

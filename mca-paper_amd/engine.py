@@ -553,13 +553,19 @@ class FusionEngine:
         if self.sched_onepass is None or nq != self.N or dq_f32 or ws.get("khot") is None:
             return False
         want = self.dbg["onepass"]
-        return bool(want) if want is not None else b * self.H >= self.ONEPASS_MIN_WG
+        return bool(want) if want is not None else b * self.H * self.onepass_split(b) >= self.ONEPASS_MIN_WG
+
+    def onepass_split(self, b) -> int:
+        """workgroups per (sample, head) of the one-pass backward: 1 where the batch gives every CU a (sample, head), else up to 4
+        (key blocks dealt round robin, partial dQ sums added by the call's second launch) - b = 8, 8 heads: 4 x 64 = 256 workgroups"""
+        wg = b * self.H
+        return 1 if wg >= self.ONEPASS_MIN_WG else max(1, min(4, self.sched_onepass.n_kb if self.sched_onepass else 1, -(-256 // wg)))
 
     def backward_form(self, b) -> str:
         """what the layer attention's backward runs at batch b (reported by bench.py)"""
         ws = {"khot": True if self.mask_mfma else None}
         if self.use_onepass(ws, b, self.N):
-            return "bf16 one-pass"
+            return "bf16 one-pass" + (f" (key blocks split {self.onepass_split(b)} ways)" if self.onepass_split(b) > 1 else "")
         return "fp8 two-pass" if (self.attn_dtype == "fp8" and self.mask_mfma and self.dkv_keys == 128) else "bf16 two-pass"
 
     def _attn_bwd1(self, q, q_bstride, q_ld, kv, k_off, v_off, kv_ld, o, d_o, lse, dq_ptr, dq_bstride, dq_ld, dkv, dk_off, dv_off, dkv_ld, ws, b):
@@ -569,7 +575,7 @@ class FusionEngine:
             rc = torch.empty(b, self.H, sc.n_qt + 1, 2, 64, dtype=torch.float32, device=self.device)          # (+ the null tile)
             rc[:, :, :, 0] = float("-inf"); rc[:, :, :, 1] = 0.0
             ws["rowc"] = rc
-            ws["dq_acc"] = torch.empty(b * self.H * (sc.n_qt + 1) * 4096, dtype=torch.float32, device=self.device)          # (+ the null tile's slot)
+            ws["dq_acc"] = torch.empty(b * self.H * self.onepass_split(b) * (sc.n_qt + 1) * 4096, dtype=torch.float32, device=self.device)          # (+ the null tile's slot)
             # head-major packed copies of q and dO (written by the prep launch): a query tile of a head is contiguous memory
             # (+ 64 rows: the kernel reads whole 64-row tiles, the last one past its rows)
             ws["q_hm"] = torch.zeros((b * self.H * N + 64) * 64, dtype=torch.bfloat16, device=self.device)
@@ -591,7 +597,7 @@ class FusionEngine:
         a.qt_desc, a.kb_desc, a.kb_qt, a.visit = sc.qt_desc.data_ptr(), sc.kb_desc.data_ptr(), sc.kb_qt.data_ptr(), sc.visit.data_ptr()
         a.n_qtiles, a.n_kblocks, a.max_list, a.n_entries = sc.n_qt, sc.n_kb, sc.max_list, sc.n_entries
         a.batch, a.heads, a.n, a.nk_pad, a.n_ktiles64 = b, self.H, N, self.nk_pad, (N + 63) // 64
-        a.scale, a.flags = self.scale, self.attn_flags
+        a.scale, a.flags, a.split = self.scale, self.attn_flags, self.onepass_split(b)
         hip.set_tag("layer")
         call("mca_attn_bwd_onepass", C.byref(a), stream_ptr(), flops=8.0 * 64 * sc.s.allowed_pairs * self.H * b)
         hip.set_tag("")

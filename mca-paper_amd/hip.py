@@ -112,7 +112,7 @@ class AttnBwd1Args(C.Structure):
         ("qt_desc", C.c_void_p), ("kb_desc", C.c_void_p), ("kb_qt", C.c_void_p), ("visit", C.c_void_p),
         ("n_qtiles", C.c_int), ("n_kblocks", C.c_int), ("max_list", C.c_int), ("n_entries", C.c_int),
         ("batch", C.c_int), ("heads", C.c_int), ("n", C.c_int), ("nk_pad", C.c_int), ("n_ktiles64", C.c_int),
-        ("scale", C.c_float), ("flags", C.c_int),
+        ("scale", C.c_float), ("flags", C.c_int), ("split", C.c_int),
     ]
 
 

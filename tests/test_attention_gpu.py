@@ -323,6 +323,27 @@ def _run_onepass(H, sc, b, heads, N, nk_pad, qkv, o, d_o, lse, dvmean_ref, keyin
         H.call("mca_attn_bwd_onepass", C.byref(a1), H.stream_ptr())
         torch.cuda.synchronize()
         out.append((dq, dkv))
+        if rep_i == 1:
+            # ---- SPLIT mode (small batches): S workgroups per (sample, head), key block kb swept by workgroup kb mod S, the S slices of
+            # dQ partials added in slice order by the call's second launch.  dK / dV: the SAME bits as one workgroup per (sample, head)
+            # (a key block's sweep does not depend on who runs it); dQ: the same sum in another order (equal up to fp32 rounding before
+            # the one bf16 rounding); bitwise repeatable; NaN-poisoned slices on entry
+            for S in (2, 3):
+                res = []
+                for _ in range(2):
+                    accS = torch.full((b * heads * S * (nqt + 1) * 4096,), float("nan"), device=dev)
+                    dqS = torch.full((b, N, D), 7.0, device=dev, dtype=torch.bfloat16)
+                    dkvS = torch.zeros(b, N, 3 * D, dtype=torch.bfloat16, device=dev)
+                    a1.dq, a1.dk, a1.dv, a1.dq_acc, a1.split = dqS.data_ptr(), dkvS.data_ptr() + D * 2, dkvS.data_ptr() + 2 * D * 2, accS.data_ptr(), S
+                    H.call("mca_attn_bwd_onepass", C.byref(a1), H.stream_ptr())
+                    torch.cuda.synchronize()
+                    res.append((dqS, dkvS))
+                assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), f"split {S}: not repeatable"
+                assert not torch.isnan(res[0][0].float()).any() and not torch.isnan(res[0][1].float()).any(), f"split {S}: NaN"
+                assert torch.equal(res[0][1], dkv), f"split {S}: dK / dV differ from the unsplit kernel"
+                e = rel(res[0][0].float(), dq.float())
+                assert e < 3e-3, f"split {S}: dq differs from the unsplit kernel by {e}"
+            a1.split = 0
     return out
 
 
