@@ -423,7 +423,8 @@ def test_attention_backward_bitwise_deterministic_at_cmu_size(P, variant):
 def test_full_size_gradients_new_vs_conservative_kernels(P, kind, b):
     """Whole-chip cross-check of the pipelined kernels (b = 32, every CU busy): one forward + backward with the production
     kernels (persistent / fused GEMMs, 256x256 weight-gradient tiles, XCD-remapped order) against the same step with the
-    conservative ones (one tile per workgroup, unfused GEGLU / LayerNorm residual, 256x128 weight gradients, launch order).
+    conservative ones (one tile per workgroup, unfused GEGLU / LayerNorm residual, 256x128 weight gradients, launch order, the
+    two-pass attention backward instead of the one-pass kernel).
     Gradients only differ by rounding placement and the order of fp32 atomics; a pipeline race (stale LDS, mis-counted wait)
     shows as percent-level error on the tensors fed by the broken kernel."""
     hipm = importlib.import_module("mca-paper_amd.hip")
@@ -440,6 +441,8 @@ def test_full_size_gradients_new_vs_conservative_kernels(P, kind, b):
         eng = model.engine
         eng.check_finite = False
         eng.fuse_ln_residual = eng.fuse_geglu_bwd = not conservative
+        if conservative:
+            eng.dbg["onepass"] = False          # the two-pass attention backward against the one-pass production form
         out = model(batch)
         out["loss"].backward()
         torch.cuda.synchronize()
