@@ -50,13 +50,13 @@ def P():
 
 
 # ------------------------------------------------------------------------------------------------ data parallel
-def _dp_worker(rank, world, port, out, p_drop):
+def _dp_worker(rank, world, port, out, p_drop, variant="mca"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         P = importlib.import_module("mca-paper_amd")
         dpm = importlib.import_module("mca-paper_amd.dp")
-        cfg = small_config("mca")
+        cfg = small_config(variant)
         b = 4
         sd = P.params.init_state_dict(cfg, seed=3)
         full = P.data.synthetic_batch(cfg, b * world, seed=21, p_drop=p_drop)
@@ -126,20 +126,22 @@ def test_dp2_native_matches_oracle_objective(tmp_path):
     assert sorted(e for e, _ in errs)[len(errs) // 2] < 0.03, (max(errs), sorted(e for e, _ in errs)[len(errs) // 2])
 
 
-def test_dp2_native_equals_single_process_objective(P, tmp_path):
+@pytest.mark.parametrize("variant,p_drop", [("mca", 0.3), ("zorro", 0.4)])
+def test_dp2_native_equals_single_process_objective(P, tmp_path, variant, p_drop):
     """Two ranks (gloo, both on this GPU) through dp.py + the real kernels against ONE native process that evaluates the same
     objective (1/W) sum_r loss_r on the concatenated batch: same kernels, same arithmetic; only the order of fp32 atomic adds
-    differs.  Replaces the 25 %-wide comparison with the fp32 oracle (VERDICT r1 weak #2)."""
+    differs.  MCA with the fusion-channel loss, and MMA (zorro masks) with 40 % of the modalities dropped (reference
+    utils/contrastive_loss_with_temperature.py:26-31, model.py:198-207)."""
     W, b = 2, 4
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_dp_worker, args=(W, port, out, 0.3), nprocs=W, join=True)
+    mp.spawn(_dp_worker, args=(W, port, out, p_drop, variant), nprocs=W, join=True)
     got = [torch.load(out + f".{r}") for r in range(W)]
     for n in got[0]["grads"]:
         assert torch.equal(got[0]["grads"][n], got[1]["grads"][n]), n          # the all-reduce left identical gradients
-    cfg = small_config("mca")
+    cfg = small_config(variant)
     sd = P.params.init_state_dict(cfg, seed=3)
-    full = to_device(P.data.synthetic_batch(cfg, b * W, seed=21, p_drop=0.3), "cuda")
+    full = to_device(P.data.synthetic_batch(cfg, b * W, seed=21, p_drop=p_drop), "cuda")
     model = P.MCA(**copy.deepcopy(cfg)); model.load_state_dict(sd, strict=False); model = model.cuda()
     eng = model.engine
     eng.refresh_weights()
@@ -165,3 +167,50 @@ def test_dp2_native_equals_single_process_objective(P, tmp_path):
             continue
         errs.append((rel_err(got[0]["grads"][n], g), n))
     assert max(errs)[0] < 1e-2, max(errs)
+
+
+
+def _steps_worker(rank, world, port, out, variant, p_drop, steps):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P = importlib.import_module("mca-paper_amd")
+        dpm = importlib.import_module("mca-paper_amd.dp")
+        optim = importlib.import_module("mca-paper_amd.optim")
+        cfg = small_config(variant)
+        b = 2
+        sd = P.params.init_state_dict(cfg, seed=3)
+        model = P.MCA(**copy.deepcopy(cfg)); model.load_state_dict(sd, strict=False); model = model.cuda()
+        model.engine.check_finite = "deferred"
+        opt = optim.FusedAdamW(model, lr=1e-3)
+        dp = dpm.DataParallelMCA(model)
+        losses = []
+        for i in range(steps):
+            full = P.data.synthetic_batch(cfg, b * world, seed=31 + i, p_drop=p_drop)
+            local = to_device({k: {kk: vv[rank * b:(rank + 1) * b] for kk, vv in v.items()} for k, v in full.items()}, "cuda")
+            o = dp(local); opt.zero_grad(); o["loss"].backward(); dp.finish_backward()
+            optim.clip_grad_norm_(model, 2.0); opt.step()
+            losses.append(float(o["loss"]))
+        torch.cuda.synchronize()
+        torch.save({"flat": model.engine.flat.detach().clone().cpu(), "losses": losses}, out + f".{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("variant,p_drop", [("mca", 0.3), ("zorro", 0.4)])
+def test_dp4_replica_weights_stay_bit_identical_over_four_steps(P, tmp_path, variant, p_drop):
+    """Four ranks (gloo, all on this GPU: within the box's process limit) train four optimizer steps through dp.py, the bucketed
+    all-reduce, the clip and the fused AdamW: every replica must hold the SAME BITS in its flat parameter buffer afterwards (the
+    all-reduced gradients are identical by construction; clip coefficient and update are deterministic functions of them)."""
+    W, steps = 4, 4
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "dp4.pt")
+    mp.spawn(_steps_worker, args=(W, port, out, variant, p_drop, steps), nprocs=W, join=True)
+    got = [torch.load(out + f".{r}") for r in range(W)]
+    for r in range(1, W):
+        assert torch.equal(got[0]["flat"], got[r]["flat"]), f"rank {r} diverged from rank 0"
+    sd0 = P.params.init_state_dict(small_config(variant), seed=3)
+    assert all(l == l for g in got for l in g["losses"])          # finite
+    moved = max(float((got[0]["flat"] != 0).float().mean()), 0.0)
+    assert moved > 0.5          # (the buffer holds trained weights, not zeros)
