@@ -262,3 +262,4 @@ def test_onepass_schedule_is_the_generated_one_and_hazard_free(tmp_path):
     assert n == n_asm and n > 150 and not probs, probs[:5]
     probs2, n_owned = audit.audit_owned(text)
     assert n_owned > 100 and not probs2, probs2[:5]
+    assert not audit.audit_m0(text)

@@ -9,7 +9,8 @@ pipelined kernel:
       (8-pass XDL result), nor read as the A / B operand of another MFMA within 12 (an MFMA taking it whole as C is free).
 Wait states are counted as a LOWER bound: one per instruction in between, N + 1 for s_nop N; the check does not follow
 branches (a block boundary counts as 0: conservative), and an s_waitcnt / s_barrier counts as one.
-Exit code 1 and a listing if anything is closer than that.  Used by tests/test_host_cpu.py."""
+Exit code 1 and a listing if anything is closer than that.  Also: (c) nothing but inline asm touches the owned accumulators
+a[224:255], (d) nothing hipcc generates uses M0 (the loop's LDS-DMA statements leave their own value in it).  Used by tests/test_host_cpu.py."""
 import os
 import re
 import subprocess
@@ -144,6 +145,24 @@ def audit_owned(text: str):
     return problems, n_asm
 
 
+def audit_m0(text: str):
+    """(d) the loop's LDS-DMA statements write M0 and do not restore it (hipcc treats M0 as reserved and rewrites it itself ahead of
+    its own users): nothing hipcc generates in this kernel may READ M0 behind them - here: no compiler instruction names m0 at all."""
+    start = text.index(f"_Z17{KERNEL}")
+    end = text.index(".amdhsa_kernel", start) if ".amdhsa_kernel" in text[start:] else len(text)
+    problems, in_asm = [], False
+    for ln, raw in enumerate(text[start:end].split("\n")):
+        s_ = raw.strip()
+        if s_.startswith(";;#ASMSTART"):
+            in_asm = True; continue
+        if s_.startswith(";;#ASMEND"):
+            in_asm = False; continue
+        code = raw.split(";")[0]
+        if not in_asm and re.search(r"\bm0\b", code):
+            problems.append(f"line {ln}: compiler instruction uses m0: {code.strip()}")
+    return problems
+
+
 if __name__ == "__main__":
     txt = open(sys.argv[1]).read() if len(sys.argv) > 1 else compile_isa()
     probs, n, na = audit(txt)
@@ -154,4 +173,8 @@ if __name__ == "__main__":
     print(f"{KERNEL}: {nl} inline-asm instructions on the owned accumulators a[224:255], {len(probs2)} compiler instruction(s) touching them")
     for p in probs2[:20]:
         print("  " + p)
-    sys.exit(1 if (probs or probs2) else 0)
+    probs3 = audit_m0(txt)
+    print(f"{KERNEL}: {len(probs3)} compiler instruction(s) using m0")
+    for p in probs3[:10]:
+        print("  " + p)
+    sys.exit(1 if (probs or probs2 or probs3) else 0)
