@@ -360,8 +360,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd1_kernel(mca_attn_bwd1_args a,
 //     them), packed P / dS, the V fragments and the transposed fragments in the vector half.  (Left to hipcc, the plain form moves 730 registers between the halves per step.)
 //   * the loop is rotated: iteration X computes the scores of blocks 0..3 of step X, and finishes step X-1 (block 3's vector work
 //     fills the shadow of A0; the dV / dK products of its blocks 2 and 3; its dQ product behind the iteration's ONE barrier); Q / dO / row-constant /
-//     mask-operand tiles arrive by LDS-DMA two steps ahead (three stages), the dQ partial of the next tile is requested a
-//     whole iteration ahead; waits are counted (vmcnt by the number of younger operations).
+//     mask-operand tiles arrive by LDS-DMA two steps ahead (three stages), the dQ partial of a step's tile is requested a
+//     whole iteration ahead of its product.  The loop's 13 vector-memory operations are unconditional and in a fixed order, so
+//     its two waits are compile-time vmcnt immediates (B1_W1_YOUNGER / B1_W2_YOUNGER of the generated schedule).
+//   * key blocks are pipelined across their boundaries (the next block's images, stages and flags are requested behind the barrier
+//     that ends a block's loop, ahead of its dK / dV epilogue); every step record is built once at kernel start; small batches
+//     deal the key blocks of a (sample, head) to several workgroups (split) and add their dQ slices in a second launch.
 //   * an inline-asm MFMA gets no hazard padding from hipcc: the schedule keeps LAG slots between a matrix instruction and the
 //     first vector reader of its result; the two places outside the schedule (dQ store, block epilogue) pad by hand.
 // =====================================================================================================
