@@ -3,14 +3,15 @@ split four ways): many rounds with fresh random q / k / v / dO and a fresh rando
 modalities - i.e. dead wavefronts, dead key blocks, uniform rows), every round: the one-pass result twice (must be the same bits)
 and the two-pass result (must agree to the parity tolerance, 6e-3 relative per tensor).  The kernel's asynchronous pieces - counted
 waits, owned accumulator registers, cross-block requests - are exercised under varying block / tile liveness.
-usage: stress_onepass.py [seconds per batch size, default 60]"""
+usage: stress_onepass.py [seconds per batch size, default 60] [long]      (long: the LONG structure, N = 6088, at b = 32 and b = 16)"""
 import importlib, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 P = importlib.import_module("mca-paper_amd"); H = importlib.import_module("mca-paper_amd.hip")
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 def rel(a, b): return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
-for b in (32, 8):
-    cfg = P.config.cmu_model_config(batch_size=b); cfg["depth"] = 1
+long_seq = len(sys.argv) > 2 and sys.argv[2] == "long"
+for b in ((32, 16) if long_seq else (32, 8)):
+    cfg = P.config.cmu_model_config(batch_size=b, long_seq=long_seq); cfg["depth"] = 1
     torch.manual_seed(0)
     eng = P.MCA(**cfg).cuda().engine
     ws = eng.workspace(b); N, D = eng.N, eng.D
